@@ -1,0 +1,176 @@
+/*
+ * pbrhip.h -- C ABI of the MI355X-native path-tracing core that sits behind pbrlab's
+ * Scene / Render() / RenderLayer API (libpbrhip.so, built from pbrlab_amd/csrc).
+ *
+ * This is the drop-in boundary: scene construction keeps pbrlab's builder calls,
+ * BVH build/flatten and tile dispatch stay on the host inside the library, and the per-sample hot
+ * path -- camera ray -> GetRadiance bounce loop -> RenderLayer accumulation -- runs as HIP kernels.
+ * Plain pointers and sizes only; host pointers in, host pointers out unless a function says "device".
+ * Every entry point cites the reference interface it replaces (file:line under lighttransport/pbrlab).
+ *
+ * All functions return 0 on success or a negative PBRHIP_E* code; pbrhip_last_error() returns a
+ * thread-local message.  The library fails loudly (PBRHIP_ENODEVICE) when no HIP device is usable:
+ * there is no CPU fallback.
+ */
+#ifndef PBRHIP_H_
+#define PBRHIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PBRHIP_OK 0
+#define PBRHIP_EINVAL (-1)    /* bad argument / id out of range */
+#define PBRHIP_ESIZE (-2)     /* std::runtime_error("... param error") cases of scene.cc:64-94 */
+#define PBRHIP_ENODEVICE (-3) /* no usable HIP device */
+#define PBRHIP_EHIP (-4)      /* a HIP runtime call failed */
+#define PBRHIP_EUNSUPPORTED (-5)
+#define PBRHIP_ESTATE (-6)    /* scene not committed / already committed */
+#define PBRHIP_EOVERFLOW (-7) /* traversal stack overflow (BVH deeper than the kernel supports) */
+
+#define PBRHIP_NONE 0xFFFFFFFFu
+
+typedef struct pbrhip_scene pbrhip_scene;
+
+/* pbrlab::CyclesPrincipledBsdfParameter (src/material-param.h:24-49), name dropped */
+typedef struct {
+  float base_color[3];
+  float subsurface;
+  float subsurface_radius[3];
+  float subsurface_color[3];
+  float metallic, specular, specular_tint, roughness, anisotropic, anisotropic_rotation;
+  float sheen, sheen_tint, clearcoat, clearcoat_roughness, ior, transmission, transmission_roughness;
+  uint32_t base_color_tex_id, subsurface_color_tex_id; /* PBRHIP_NONE: textures are row N4 (not yet) */
+} pbrhip_principled_param;
+
+/* pbrlab::HairBsdfParameter (src/material-param.h:51-72) */
+typedef struct {
+  uint32_t coloring_hair; /* 0 = kRGB, 1 = kMelanin */
+  float base_color[3];
+  float melanin, melanin_redness, melanin_randomize;
+  float roughness, azimuthal_roughness, ior, shift;
+  float specular_tint[3], second_specular_tint[3], transmission_tint[3];
+} pbrhip_hair_param;
+
+/* pbrlab::Ray (src/ray.h:9-14), packed as two float4 */
+typedef struct {
+  float org[3];
+  float tmin;
+  float dir[3];
+  float tmax;
+} pbrhip_ray;
+
+/* pbrlab::TraceResult (src/raytracer/raytracer.h:9-17) */
+typedef struct {
+  float normal_g[3];
+  float t, u, v;
+  uint32_t instance_id, geom_id, prim_id;
+} pbrhip_hit;
+
+/* arguments of pbrlab::Render (src/render.h:14-17) plus what the reference hard-wires */
+typedef struct {
+  uint32_t width, height, num_sample; /* Render(scene, width, height, num_sample, ...) */
+  uint32_t first_pass;                /* passes [first_pass, first_pass+num_sample) (progressive resume) */
+  uint64_t seed_seq;                  /* PCG32 initseq; the reference uses 1234567890 (render.cc:215) */
+  uint32_t tile_rank, tile_world;     /* 64x64 tiles (render.cc:107-108) with index % world == rank */
+  uint32_t max_paths_in_flight;       /* 0 = default (32 Mi): passes are rendered in chunks of this many paths */
+  uint32_t flags;                     /* PBRHIP_RENDER_* */
+} pbrhip_render_desc;
+
+#define PBRHIP_RENDER_STATS 1u   /* count BVH nodes / primitives visited (slower; for algorithmic bytes) */
+#define PBRHIP_RENDER_TIMING 2u  /* time every kernel launch with HIP events on the render stream */
+#define PBRHIP_RENDER_NO_CLEAR 4u /* keep the layer's current contents (Render() clears: render.cc:99-100) */
+
+/* filled by pbrhip_render when stats != NULL */
+typedef struct {
+  uint64_t samples, iterations, chunks;
+  uint64_t closest_rays, closest_nodes, closest_tris, closest_curves; /* PBRHIP_RENDER_STATS */
+  uint64_t shadow_rays, shadow_nodes, shadow_tris, shadow_curves;
+  /* PBRHIP_RENDER_TIMING: total ms and launch count per kernel */
+  double ms_generate, ms_trace_closest, ms_surface, ms_shade_principled, ms_shade_hair, ms_sss_step, ms_trace_shadow,
+      ms_accumulate;
+  uint64_t n_trace_closest, n_trace_shadow, n_surface, n_shade_principled, n_shade_hair, n_sss_step;
+  double ms_total; /* wall time of the call measured on the host */
+} pbrhip_render_stats;
+
+const char* pbrhip_last_error(void);
+int pbrhip_device_count(int* count);
+/* selects the HIP device used by subsequently created scenes (one process per GPU: LOCAL_RANK) */
+int pbrhip_set_device(int device);
+
+/* ---- scene construction: pbrlab::Scene (src/scene.h:14-111) ---- */
+int pbrhip_scene_create(pbrhip_scene** out); /* Scene::Scene, scene.cc:11 */
+int pbrhip_scene_destroy(pbrhip_scene*);     /* Scene::~Scene, scene.cc:12 */
+
+/* Scene::AddTriangleMesh (scene.h:19-24) with the TriangleMesh ctor (mesh/triangle-mesh.cc:17-57) and the
+ * shared Attribute buffers (mesh/attribute.h:8-12).  The reference shares the buffers by pointer
+ * (raytracer.h:34); this call copies them.  normal_ids / texcoord_ids / material_ids may be NULL
+ * (ids default to uint32(-1)).  vertices: xyzw * num_vertices, normals: xyzw, texcoords: uv. */
+int pbrhip_scene_add_triangle_mesh(pbrhip_scene*, const float* vertices_xyzw, uint32_t num_vertices,
+                                   const float* normals_xyzw, uint32_t num_normals, const float* texcoords_uv,
+                                   uint32_t num_texcoords, const uint32_t* vertex_ids, const uint32_t* normal_ids,
+                                   const uint32_t* texcoord_ids, const uint32_t* material_ids, uint32_t num_faces,
+                                   uint32_t* mesh_id);
+/* Scene::AddCubicBezierCurveMesh (scene.h:26-32, mesh/cubic-bezier-curve-mesh.cc:7-15):
+ * vertices xyz+radius, indices = first control point of each cubic segment */
+int pbrhip_scene_add_curve_mesh(pbrhip_scene*, const float* vertices_xyzr, uint32_t num_vertices,
+                                const uint32_t* indices, const uint32_t* material_ids, uint32_t num_segments,
+                                uint32_t* mesh_id);
+/* Scene::AddMaterialParam (scene.h:39-44) for the two alternatives of MaterialParameter */
+int pbrhip_scene_add_principled_material(pbrhip_scene*, const pbrhip_principled_param*, uint32_t* material_id);
+int pbrhip_scene_add_hair_material(pbrhip_scene*, const pbrhip_hair_param*, uint32_t* material_id);
+/* Scene::AddLightParam (scene.h:34-37) with AreaLightParameter (light-param.h:20-23) */
+int pbrhip_scene_add_area_light(pbrhip_scene*, const float emission[3], uint32_t* light_id);
+/* Scene::CreateLocalScene (scene.cc:157-164), AddMeshToLocalScene (scene.cc:14-62), CreateInstance (scene.cc:106-155;
+ * transform = float[4][4], row-vector convention v' = v*M; only the identity is supported so far) */
+int pbrhip_scene_create_local_scene(pbrhip_scene*, uint32_t* local_scene_id);
+int pbrhip_scene_add_mesh_to_local_scene(pbrhip_scene*, uint32_t local_scene_id, uint32_t mesh_id, uint32_t* geom_id);
+int pbrhip_scene_create_instance(pbrhip_scene*, uint32_t local_scene_id, const float* transform4x4,
+                                 uint32_t* instance_id);
+/* Scene::AttachLightParamIdsToInstance / AttachMaterialParamIdsToInstance (scene.cc:64-94), one geometry at a
+ * time; a size mismatch returns PBRHIP_ESIZE where the reference throws std::runtime_error */
+int pbrhip_scene_attach_light_ids(pbrhip_scene*, uint32_t instance_id, uint32_t geom_id, const uint32_t* light_ids,
+                                  uint32_t n);
+int pbrhip_scene_attach_material_ids(pbrhip_scene*, uint32_t instance_id, uint32_t geom_id,
+                                     const uint32_t* material_ids, uint32_t n);
+/* Scene::CommitScene (scene.cc:96-104): light tables (LightManager::RegisterInstanceMesh/Commit,
+ * light-manager.cc:29-184), BVH build + flatten (replaces Embree's rtcCommitScene, raytracer_impl.cc:93-197),
+ * upload to HBM, scene bounds (rtcGetSceneBounds, raytracer_impl.cc:199-211) */
+int pbrhip_scene_commit(pbrhip_scene*);
+/* Scene::FetchSceneAABB (scene.cc:251-259) */
+int pbrhip_scene_aabb(const pbrhip_scene*, float bmin[3], float bmax[3]);
+/* Scene::FetchMeshMaterialParameters + EditQueue edits between renders (pc/pc-common.cc:57-84): replace one
+ * material's parameters in place on a committed scene */
+int pbrhip_scene_update_principled_material(pbrhip_scene*, uint32_t material_id, const pbrhip_principled_param*);
+int pbrhip_scene_update_hair_material(pbrhip_scene*, uint32_t material_id, const pbrhip_hair_param*);
+/* BVH facts for reports: node count, leaf slots, depth, device bytes */
+int pbrhip_scene_info(const pbrhip_scene*, uint64_t* num_nodes, uint64_t* num_slots, uint32_t* depth,
+                      uint64_t* device_bytes);
+
+/* ---- the hot path ---- */
+/* pbrlab::Render (src/render.h:14-17, render.cc:192-241).  Blocking.  rgba: width*height*4 floats (sum of
+ * radiance, A = sample count), count: width*height (RenderLayer, render-layer.h:11-26).  *cancel is polled
+ * between chunks of passes; *finish_pass is advanced as passes complete (monotone, render.cc:224-231).
+ * Per-sample RNG: RNG((pass << 32) + y*width + x, seed_seq). */
+int pbrhip_render(pbrhip_scene*, const pbrhip_render_desc*, const volatile int* cancel, float* rgba, uint32_t* count,
+                  size_t* finish_pass, pbrhip_render_stats* stats);
+/* Same, writing into DEVICE buffers owned by the caller (e.g. a torch tensor that is then reduced over RCCL):
+ * d_rgba / d_count are device pointers on the scene's device; nothing is copied to the host. */
+int pbrhip_render_device(pbrhip_scene*, const pbrhip_render_desc*, const volatile int* cancel, float* d_rgba,
+                         uint32_t* d_count, size_t* finish_pass, pbrhip_render_stats* stats);
+
+/* Raytracer::FirstHitTrace1 / AnyHit1 (src/raytracer/raytracer.h:95-111, raytracer_impl.cc:268-287) over an
+ * array of rays: test hooks for hit-index parity */
+int pbrhip_trace_closest(pbrhip_scene*, const pbrhip_ray* rays, size_t n, pbrhip_hit* hits);
+int pbrhip_trace_any(pbrhip_scene*, const pbrhip_ray* rays, size_t n, uint8_t* occluded);
+
+/* CreateTiles (src/render-tile.cc:29-41): out = sx,tx,sy,ty per tile (may be NULL to query the count) */
+int pbrhip_create_tiles(uint32_t width, uint32_t height, uint32_t* out_sx_tx_sy_ty, uint32_t* num_tiles);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PBRHIP_H_ */

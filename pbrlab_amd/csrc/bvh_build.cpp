@@ -1,0 +1,237 @@
+// bvh_build.cpp -- host BVH2 builder + flatten (replaces Embree's rtcCommitScene,
+// src/raytracer/raytracer_impl.cc:136-147,181-192).  Binned SAH (16 bins), leaves of <= kMaxLeaf
+// primitives of a single kind, 64-byte nodes that carry both children's boxes so that one node fetch
+// decides both descents.  Large subtrees are built on worker threads.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <future>
+#include <limits>
+#include <thread>
+
+#include "host_scene.h"
+
+namespace pb {
+namespace {
+
+constexpr int kBins = 16;
+constexpr float kTraversalCost = 1.0f;
+constexpr float kPrimCost = 1.5f;
+
+struct Box {
+  float lo[3], hi[3];
+  void reset() {
+    for (int a = 0; a < 3; a++) lo[a] = std::numeric_limits<float>::infinity(), hi[a] = -lo[a];
+  }
+  void grow(const float* l, const float* h) {
+    for (int a = 0; a < 3; a++) {
+      lo[a] = std::min(lo[a], l[a]);
+      hi[a] = std::max(hi[a], h[a]);
+    }
+  }
+  void grow(const Box& b) { grow(b.lo, b.hi); }
+  float area() const {
+    float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    if (!(dx >= 0 && dy >= 0 && dz >= 0)) return 0.f;
+    return 2.f * (dx * dy + dy * dz + dz * dx);
+  }
+};
+
+struct TNode {  // build-time tree
+  Box box;
+  int32_t left = -1, right = -1;  // children (indices into the owning pool) or -1 for leaf
+  uint32_t first = 0, count = 0;  // leaf range in the order array
+  uint8_t kind = 0;
+  uint32_t depth = 1;
+};
+
+struct Builder {
+  const float* lo;
+  const float* hi;
+  const uint8_t* kinds;
+  std::vector<float> cen;
+  std::vector<uint32_t> order;
+
+  struct Pool {
+    std::vector<TNode> nodes;
+  };
+
+  bool uniform_kind(uint32_t first, uint32_t count) const {
+    uint8_t k = kinds[order[first]];
+    for (uint32_t i = first + 1; i < first + count; i++)
+      if (kinds[order[i]] != k) return false;
+    return true;
+  }
+
+  // returns node index inside pool
+  int32_t build(Pool& pool, uint32_t first, uint32_t count, uint32_t depth) {
+    int32_t id = (int32_t)pool.nodes.size();
+    pool.nodes.emplace_back();
+    Box box, cbox;
+    box.reset(), cbox.reset();
+    for (uint32_t i = first; i < first + count; i++) {
+      uint32_t g = order[i];
+      box.grow(lo + 3 * g, hi + 3 * g);
+      cbox.grow(&cen[3 * g], &cen[3 * g]);
+    }
+    pool.nodes[id].box = box;
+    pool.nodes[id].depth = depth;
+    bool uni = uniform_kind(first, count);
+    if (count <= (uint32_t)kMaxLeaf && uni) {
+      pool.nodes[id].first = first, pool.nodes[id].count = count, pool.nodes[id].kind = kinds[order[first]];
+      return id;
+    }
+    uint32_t mid = first;
+    if (!uni && count <= (uint32_t)kMaxLeaf) {
+      // mixed small range: split by kind
+      mid = (uint32_t)(std::partition(order.begin() + first, order.begin() + first + count,
+                                      [&](uint32_t g) { return kinds[g] == 0; }) -
+                       order.begin());
+    } else {
+      int best_axis = -1, best_bin = 0;
+      float best_cost = std::numeric_limits<float>::infinity();
+      for (int a = 0; a < 3; a++) {
+        float ext = cbox.hi[a] - cbox.lo[a];
+        if (!(ext > 0.f)) continue;
+        Box bb[kBins];
+        uint32_t bc[kBins];
+        for (int k = 0; k < kBins; k++) bb[k].reset(), bc[k] = 0;
+        float scale = (float)kBins / ext;
+        for (uint32_t i = first; i < first + count; i++) {
+          uint32_t g = order[i];
+          int k = std::min(kBins - 1, std::max(0, (int)((cen[3 * g + a] - cbox.lo[a]) * scale)));
+          bb[k].grow(lo + 3 * g, hi + 3 * g);
+          bc[k]++;
+        }
+        float rarea[kBins];
+        uint32_t rcnt[kBins];
+        Box acc;
+        acc.reset();
+        uint32_t n = 0;
+        for (int k = kBins - 1; k > 0; k--) {
+          acc.grow(bb[k]);
+          n += bc[k];
+          rarea[k] = acc.area();
+          rcnt[k] = n;
+        }
+        acc.reset();
+        n = 0;
+        for (int k = 0; k < kBins - 1; k++) {
+          acc.grow(bb[k]);
+          n += bc[k];
+          if (n == 0 || rcnt[k + 1] == 0) continue;
+          float cost = acc.area() * (float)n + rarea[k + 1] * (float)rcnt[k + 1];
+          if (cost < best_cost) best_cost = cost, best_axis = a, best_bin = k;
+        }
+      }
+      if (best_axis >= 0) {
+        float scale = (float)kBins / (cbox.hi[best_axis] - cbox.lo[best_axis]);
+        float base = cbox.lo[best_axis];
+        mid = (uint32_t)(std::partition(order.begin() + first, order.begin() + first + count,
+                                        [&](uint32_t g) {
+                                          int k = std::min(kBins - 1, std::max(0, (int)((cen[3 * g + best_axis] - base) * scale)));
+                                          return k <= best_bin;
+                                        }) -
+                         order.begin());
+      }
+      if (mid == first || mid == first + count) {
+        // all centroids coincide (or SAH found no split): median split on the widest axis
+        int a = 0;
+        for (int c = 1; c < 3; c++)
+          if (cbox.hi[c] - cbox.lo[c] > cbox.hi[a] - cbox.lo[a]) a = c;
+        mid = first + count / 2;
+        std::nth_element(order.begin() + first, order.begin() + mid, order.begin() + first + count,
+                         [&](uint32_t x, uint32_t y) { return cen[3 * x + a] < cen[3 * y + a] || (cen[3 * x + a] == cen[3 * y + a] && x < y); });
+      }
+    }
+    int32_t l = build(pool, first, mid - first, depth + 1);
+    int32_t r = build(pool, mid, first + count - mid, depth + 1);
+    pool.nodes[id].left = l;
+    pool.nodes[id].right = r;
+    return id;
+  }
+};
+
+uint32_t leaf_ref(const TNode& n) {
+  return kLeafBit | (n.kind ? kCurveBit : 0u) | (n.first << 3) | (n.count - 1u);
+}
+
+}  // namespace
+
+void build_bvh(const std::vector<float>& lo, const std::vector<float>& hi, const std::vector<uint8_t>& kinds,
+               FlatBvh* out) {
+  out->nodes.clear();
+  out->slot_gid.clear();
+  out->depth = 0;
+  uint32_t n = (uint32_t)kinds.size();
+  if (n == 0) return;
+  Builder b;
+  b.lo = lo.data(), b.hi = hi.data(), b.kinds = kinds.data();
+  b.cen.resize(3 * (size_t)n);
+  b.order.resize(n);
+  for (uint32_t g = 0; g < n; g++) {
+    for (int a = 0; a < 3; a++) b.cen[3 * g + a] = 0.5f * (lo[3 * g + a] + hi[3 * g + a]);
+    b.order[g] = g;
+  }
+  Builder::Pool pool;
+  pool.nodes.reserve(2 * (size_t)n / 2 + 16);
+  int32_t root = b.build(pool, 0, n, 1);
+
+  // flatten: internal nodes get consecutive indices in DFS order; node 0 is always internal
+  const std::vector<TNode>& T = pool.nodes;
+  auto nan_box = [](float* l, float* h) {
+    for (int a = 0; a < 3; a++) l[a] = h[a] = std::numeric_limits<float>::quiet_NaN();
+  };
+  std::vector<BvhNode>& N = out->nodes;
+  uint32_t depth = 0;
+  if (T[root].left < 0) {
+    BvhNode nd;
+    memset(&nd, 0, sizeof(nd));
+    memcpy(nd.lo0, T[root].box.lo, 12), memcpy(nd.hi0, T[root].box.hi, 12);
+    nan_box(nd.lo1, nd.hi1);
+    nd.c0 = leaf_ref(T[root]);
+    nd.c1 = kEmptyChild;
+    N.push_back(nd);
+    depth = 1;
+  } else {
+    struct Item {
+      int32_t t;
+      uint32_t out;
+    };
+    std::vector<Item> stack;
+    N.emplace_back();
+    stack.push_back({root, 0});
+    while (!stack.empty()) {
+      Item it = stack.back();
+      stack.pop_back();
+      const TNode& t = T[it.t];
+      depth = std::max(depth, t.depth);
+      BvhNode nd;
+      memset(&nd, 0, sizeof(nd));
+      const TNode &l = T[t.left], &r = T[t.right];
+      memcpy(nd.lo0, l.box.lo, 12), memcpy(nd.hi0, l.box.hi, 12);
+      memcpy(nd.lo1, r.box.lo, 12), memcpy(nd.hi1, r.box.hi, 12);
+      if (l.left < 0) {
+        nd.c0 = leaf_ref(l);
+      } else {
+        nd.c0 = (uint32_t)N.size();
+        N.emplace_back();
+        stack.push_back({t.left, nd.c0});
+      }
+      if (r.left < 0) {
+        nd.c1 = leaf_ref(r);
+      } else {
+        nd.c1 = (uint32_t)N.size();
+        N.emplace_back();
+        stack.push_back({t.right, nd.c1});
+      }
+      N[it.out] = nd;
+    }
+  }
+  out->slot_gid = b.order;
+  out->depth = depth;
+}
+
+}  // namespace pb

@@ -1,0 +1,305 @@
+// dmath.h -- leaf arithmetic of the MI355X path tracer (host + device).
+//
+// Every function states which pbrlab function it re-implements (file:line relative to the reference
+// tree).  The whole library is compiled with -ffp-contract=off, IEEE division and square root
+// (hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt) and denormals enabled, so that '+', '*',
+// '/', sqrt round exactly once in the order written here -- the order the reference writes them.
+// cos/sin/exp/log go through the device's double-precision functions and are rounded once to float
+// ("f64r"); the hair closure uses the reference's own fmaf polynomials.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#define PB_HD __host__ __device__ __forceinline__
+
+namespace pb {
+
+// src/pbrlab_math.h:7-11
+constexpr float kPi = 3.141592653589793f;
+constexpr float kPiInv = 0.318309886183f;
+constexpr float kEps = 1e-3f;
+constexpr float kInf = 1.844E18f;
+constexpr float kFltEps = 1.1920928955078125e-07f;  // std::numeric_limits<float>::epsilon()
+constexpr float kFltMin = 1.17549435082228750797e-38f;
+constexpr float kFltMax = 3.40282346638528859812e+38f;
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+
+// ------------------------------------------------------------------ transcendental policy (f64r)
+PB_HD float f_cos(float x) { return (float)cos((double)x); }
+PB_HD float f_sin(float x) { return (float)sin((double)x); }
+PB_HD float f_exp(float x) { return (float)exp((double)x); }
+PB_HD float f_log(float x) { return (float)log((double)x); }
+
+// std::max / std::min as libstdc++ defines them (comparison order matters for NaN)
+PB_HD float smax(float a, float b) { return (a < b) ? b : a; }
+PB_HD float smin(float a, float b) { return (b < a) ? b : a; }
+// pbrlab-util.h:9-17
+PB_HD float clampf(float x, float a, float b) { return smax(a, smin(b, x)); }
+PB_HD float saturate(float x) { return clampf(x, 0.0f, 1.0f); }
+PB_HD float sqr(float v) { return v * v; }
+// pbrlab_math.h:17
+PB_HD float safe_sqrt(float f) { return sqrtf(smax(f, 0.0f)); }
+PB_HD bool finite_f(float x) { return isfinite(x); }
+
+PB_HD uint32_t f2u(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __float_as_uint(f);
+#else
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  return u;
+#endif
+}
+PB_HD float u2f(uint32_t u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __uint_as_float(u);
+#else
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+#endif
+}
+
+// ------------------------------------------------------------------ V3 == nanort::real3<float> (nanort.h:313-404)
+struct V3 {
+  float x, y, z;
+  PB_HD V3() {}
+  PB_HD explicit V3(float v) : x(v), y(v), z(v) {}
+  PB_HD V3(float a, float b, float c) : x(a), y(b), z(c) {}
+  PB_HD float operator[](int i) const { return i == 0 ? x : (i == 1 ? y : z); }
+};
+PB_HD V3 operator+(V3 a, V3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+PB_HD V3 operator-(V3 a, V3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+PB_HD V3 operator*(V3 a, V3 b) { return V3(a.x * b.x, a.y * b.y, a.z * b.z); }
+PB_HD V3 operator/(V3 a, V3 b) { return V3(a.x / b.x, a.y / b.y, a.z / b.z); }
+PB_HD V3 operator*(V3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
+PB_HD V3 operator*(float s, V3 a) { return V3(a.x * s, a.y * s, a.z * s); }
+PB_HD V3 operator/(V3 a, float s) { return V3(a.x / s, a.y / s, a.z / s); }  // via real3(float)
+PB_HD V3 operator-(V3 a) { return V3(-a.x, -a.y, -a.z); }
+PB_HD float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+PB_HD V3 cross(V3 a, V3 b) { return V3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+PB_HD float length(V3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+// nanort.h:379-390 (guarded; Q11)
+PB_HD V3 vnormalize(V3 a) {
+  float len = length(a);
+  if (fabsf(len) > kFltEps) {
+    float inv = 1.0f / len;
+    a.x *= inv, a.y *= inv, a.z *= inv;
+  }
+  return a;
+}
+// render.cc:243-249 / raytracer_impl.cc:213-220 (unguarded; Q11)
+PB_HD V3 normalize_raw(V3 v) {
+  float inv = 1.0f / sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+  return V3(v.x * inv, v.y * inv, v.z * inv);
+}
+// pbrlab_math.h:30-38
+PB_HD V3 lerp(V3 v0, V3 v1, float u) { return (1.0f - u) * v0 + u * v1; }
+PB_HD V3 lerp3(V3 v0, V3 v1, V3 v2, float u, float v) { return (1.0f - u - v) * v0 + u * v1 + v * v2; }
+
+// pbrlab-util.h:19-61
+PB_HD float average(V3 c) { return (c.x + c.y + c.z) / 3.f; }
+PB_HD float spectrum_norm(V3 c) {  // std::max({r,g,b})
+  float m = c.x;
+  if (m < c.y) m = c.y;
+  if (m < c.z) m = c.z;
+  return m;
+}
+PB_HD V3 safe_divide_spectrum(V3 a, V3 b) {
+  return V3((fabsf(b.x) < kFltEps) ? 0.0f : a.x / b.x, (fabsf(b.y) < kFltEps) ? 0.0f : a.y / b.y,
+            (fabsf(b.z) < kFltEps) ? 0.0f : a.z / b.z);
+}
+PB_HD float rgb_to_y(V3 c) { return 0.212671f * c.x + 0.715160f * c.y + 0.072169f * c.z; }
+PB_HD bool is_black(V3 v) { return (fabsf(v.x) + fabsf(v.y) + fabsf(v.z)) < kFltEps; }
+PB_HD bool is_finite(V3 v) { return isfinite(v.x) && isfinite(v.y) && isfinite(v.z); }
+
+// ------------------------------------------------------------------ PCG32 (src/random/rng.h:17-69)
+// `inc` is identical for every path of a render (it only depends on initseq), so the per-path state is
+// the 64-bit `state` alone; inc travels as a kernel argument.
+struct Rng {
+  uint64_t state, inc;
+};
+PB_HD uint32_t pcg32(Rng& r) {
+  uint64_t old = r.state;
+  r.state = old * 6364136223846793005ULL + r.inc;
+  uint32_t xs = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+  uint32_t rot = (uint32_t)(old >> 59u);
+  return (xs >> rot) | (xs << ((32u - rot) & 31u));
+}
+PB_HD Rng rng_seed(uint64_t initstate, uint64_t initseq) {
+  Rng r;
+  r.state = 0u;
+  r.inc = (initseq << 1u) | 1u;
+  pcg32(r);
+  r.state += initstate;
+  pcg32(r);
+  return r;
+}
+PB_HD float draw(Rng& r) { return u2f((pcg32(r) >> 9) | 0x3f800000u) - 1.0f; }
+
+// ------------------------------------------------------------------ sampling (sampler/sampling-utils.h)
+PB_HD V3 cosine_sample_hemisphere(float u1, float u2) {  // :10-14
+  float a = u1 * 2.0f * kPi, r = sqrtf(u2);
+  return V3(f_cos(a) * r, f_sin(a) * r, sqrtf(smax(1.0f - u2, 0.0f)));
+}
+PB_HD V3 uniform_sample_sphere(float u1, float u2) {  // :16-23
+  float u = 2.0f * u2 - 1.0f;
+  float norm = sqrtf(smax(0.0f, 1.0f - u * u));
+  float theta = 2.0f * kPi * u1;
+  return V3(norm * f_cos(theta), u, norm * f_sin(theta));
+}
+PB_HD float power_heuristic(float sampled_pdf, float other_pdf) {  // :27-57
+  float r, mis;
+  if (sampled_pdf > other_pdf) {
+    r = other_pdf / sampled_pdf;
+    mis = 1 / (1 + r * r);
+  } else if (sampled_pdf < other_pdf) {
+    r = sampled_pdf / other_pdf;
+    mis = 1 - 1 / (1 + r * r);
+  } else {
+    mis = 0.5f;
+  }
+  return mis;
+}
+PB_HD void triangle_uniform_sampler(float u1, float u2, float& a, float& b) {  // :59-66
+  bool flag = (u1 > u2);
+  float M = flag ? u1 : u2;
+  float m = (!flag) ? u1 : u2;
+  a = 1.0f - M;
+  b = M - m;
+}
+
+// Pixar branchless ONB (shader/shader-utils.h:44-50)
+PB_HD void branchless_onb(V3 n, V3& x, V3& y) {
+  float sign = copysignf(1.0f, n.z);
+  float a = -1.0f / (sign + n.z);
+  float b = n.x * n.y * a;
+  x = V3(1.0f + sign * n.x * n.x * a, sign * b, -sign * n.x);
+  y = V3(b, sign + n.y * n.y * a, -n.y);
+}
+
+// Row-vector 3x3 frames.  to_local == MultV(v, GrobalToShadingLocal(ex,ey,ez)),
+// to_global == MultV(v, ShadingLocalToGlobal(ex,ey,ez)) (shader-utils.h:66-114, matrix.cc:218-222);
+// the trailing "+ 0.0f" is the reference's zero translation row and is kept for its -0 -> +0 effect.
+struct Frame {
+  V3 ex, ey, ez;
+};
+PB_HD V3 to_local(const Frame& f, V3 v) {
+  return V3(f.ex.x * v.x + f.ex.y * v.y + f.ex.z * v.z + 0.0f, f.ey.x * v.x + f.ey.y * v.y + f.ey.z * v.z + 0.0f,
+            f.ez.x * v.x + f.ez.y * v.y + f.ez.z * v.z + 0.0f);
+}
+PB_HD V3 to_global(const Frame& f, V3 v) {
+  return V3(f.ex.x * v.x + f.ey.x * v.y + f.ez.x * v.z + 0.0f, f.ex.y * v.x + f.ey.y * v.y + f.ez.y * v.z + 0.0f,
+            f.ex.z * v.x + f.ey.z * v.y + f.ez.z * v.z + 0.0f);
+}
+
+// ------------------------------------------------------------------ OIIO fast math (pbrlab_math.h:96-341)
+namespace fastm {
+PB_HD float reduce_pi(float x, int& q) {
+  q = (int)rintf(x * (float)0.31830988618379067154);
+  float qf = (float)q;
+  x = fmaf(qf, -0.78515625f * 4, x);
+  x = fmaf(qf, -0.00024187564849853515625f * 4, x);
+  x = fmaf(qf, -3.7747668102383613586e-08f * 4, x);
+  x = fmaf(qf, -1.2816720341285448015e-12f * 4, x);
+  return (float)1.57079632679489661923 - ((float)1.57079632679489661923 - x);
+}
+PB_HD float sin_poly(float x, float s) {
+  float u = 2.6083159809786593541503e-06f;
+  u = fmaf(u, s, -0.0001981069071916863322258f);
+  u = fmaf(u, s, +0.00833307858556509017944336f);
+  u = fmaf(u, s, -0.166666597127914428710938f);
+  return fmaf(s, u * x, x);
+}
+PB_HD float cos_poly(float s) {
+  float u = -2.71811842367242206819355e-07f;
+  u = fmaf(u, s, +2.47990446951007470488548e-05f);
+  u = fmaf(u, s, -0.00138888787478208541870117f);
+  u = fmaf(u, s, +0.0416666641831398010253906f);
+  u = fmaf(u, s, -0.5f);
+  return fmaf(u, s, +1.0f);
+}
+PB_HD float fsin(float x) {  // :135-161
+  int q;
+  x = reduce_pi(x, q);
+  float s = x * x;
+  if ((q & 1) != 0) x = -x;
+  float u = sin_poly(x, s);
+  if (fabsf(u) > 1.0f) u = 0.0f;
+  return u;
+}
+PB_HD float fcos(float x) {  // :163-185
+  int q;
+  x = reduce_pi(x, q);
+  float u = cos_poly(x * x);
+  if ((q & 1) != 0) u = -u;
+  if (fabsf(u) > 1.0f) u = 0.0f;
+  return u;
+}
+PB_HD void fsincos(float x, float& sine, float& cosine) {  // :187-215
+  int q;
+  x = reduce_pi(x, q);
+  float s = x * x;
+  if ((q & 1) != 0) x = -x;
+  float su = sin_poly(x, s);
+  float cu = cos_poly(s);
+  if ((q & 1) != 0) cu = -cu;
+  if (fabsf(su) > 1.0f) su = 0.0f;
+  if (fabsf(cu) > 1.0f) cu = 0.0f;
+  sine = su;
+  cosine = cu;
+}
+PB_HD float fexp2(float xval) {  // :217-241
+  float x = smax(-126.0f, smin(126.0f, xval));
+  int m = (int)x;
+  x -= (float)m;
+  x = 1.0f - (1.0f - x);
+  float r = 1.33336498402e-3f;
+  r = fmaf(x, r, 9.810352697968e-3f);
+  r = fmaf(x, r, 5.551834031939e-2f);
+  r = fmaf(x, r, 0.2401793301105f);
+  r = fmaf(x, r, 0.693144857883f);
+  r = fmaf(x, r, 1.0f);
+  return u2f(f2u(r) + ((uint32_t)m << 23));
+}
+PB_HD float fexp(float x) { return fexp2(x * (float)(1 / 0.69314718055994530942)); }  // :243-248
+PB_HD float fatan2(float y, float x) {                                                // :250-278
+  float a = fabsf(x);
+  float b = fabsf(y);
+  float k = (b == 0) ? 0.0f : ((a == b) ? 1.0f : (b > a ? a / b : b / a));
+  float s = 1.0f - (1.0f - k);
+  float t = s * s;
+  float r = s * fmaf(0.430165678f, t, 1.0f) / fmaf(fmaf(0.0579354987f, t, 0.763007998f), t, 1.0f);
+  if (b > a) r = 1.570796326794896557998982f - r;
+  if (f2u(x) & 0x80000000u) r = kPi - r;
+  return copysignf(r, y);
+}
+PB_HD float fasin(float x) {  // :280-294
+  float f = fabsf(x);
+  float m = (f < 1.0f) ? 1.0f - (1.0f - f) : 1.0f;
+  float a = (float)1.57079632679489661923 -
+            sqrtf(1.0f - m) * (1.5707963267f + m * (-0.213300989f + m * (0.077980478f + m * -0.02164095f)));
+  return copysignf(a, x);
+}
+PB_HD float flog2(float xval) {  // :314-338
+  float x = smax(kFltMin, smin(kFltMax, xval));
+  uint32_t bits = f2u(x);
+  int exponent = (int)(bits >> 23) - 127;
+  float f = u2f((bits & 0x007FFFFFu) | 0x3f800000u) - 1.0f;
+  float f2 = f * f;
+  float f4 = f2 * f2;
+  float hi = fmaf(f, -0.00931049621349f, 0.05206469089414f);
+  float lo = fmaf(f, 0.47868480909345f, -0.72116591947498f);
+  hi = fmaf(f, hi, -0.13753123777116f);
+  hi = fmaf(f, hi, 0.24187369696082f);
+  hi = fmaf(f, hi, -0.34730547155299f);
+  lo = fmaf(f, lo, 1.442689881667200f);
+  return ((f4 * hi) + (f * lo)) + (float)exponent;
+}
+PB_HD float flog(float x) { return flog2(x) * (float)0.69314718055994530942; }  // :340-344
+}  // namespace fastm
+
+}  // namespace pb

@@ -1,0 +1,104 @@
+// dscene.h -- flat, device-resident scene layout (what pbrhip_scene_commit uploads).
+//
+// HBM layout (all arrays 16-byte aligned, read-only during a render):
+//   nodes      BVH2, 64 B per node: both children's AABBs + two child references
+//   slots      leaf-ordered primitives, 64 B per slot (4 x float4):
+//                triangle: v0.xyz,_ | v1.xyz,_ | v2.xyz,_ | unused     (world space)
+//                curve   : 4 cubic Bezier control points xyz + radius  (world space)
+//   slot_meta  uint4 per slot: canonical primitive id (gid), material id, light record, flags
+//   slot_ids   uint4 per slot: instance_id, geom_id, prim_id, kind     (TraceResult ids)
+//   slot_nrm   3 x float4 per slot: per-corner shading normals (triangles with normals only)
+//   materials  one closure record per material (ParamToBsdf hoisted to commit time)
+//   lights     per-light and per-light-primitive sampling tables (LightManager::Commit)
+#pragma once
+
+#include "dclosures.h"
+
+namespace pb {
+
+// child reference: internal node index, or leaf = 0x80000000 | kind<<30 | first_slot<<3 | (count-1)
+constexpr uint32_t kLeafBit = 0x80000000u;
+constexpr uint32_t kCurveBit = 0x40000000u;
+constexpr uint32_t kEmptyChild = 0xFFFFFFFFu;  // (a leaf reference that can never be produced)
+constexpr int kMaxLeaf = 4;
+constexpr int kStackDepth = 40;
+
+struct alignas(16) BvhNode {
+  float lo0[3], hi0[3];
+  float lo1[3], hi1[3];
+  uint32_t c0, c1;
+  uint32_t pad[2];
+};
+static_assert(sizeof(BvhNode) == 64, "node must be 64 B");
+
+constexpr uint32_t kSlotHasNormals = 1u;
+constexpr uint32_t kSlotIsCurve = 2u;
+
+// closure set of one material == struct CyclesPrincipledBsdf (cycles-principled-shader.cc:20-45)
+struct PrincipledBsdf {
+  int enable_diffuse;
+  V3 diffuse_weight;
+  int enable_subsurface;
+  V3 subsurface_weight, subsurface_albedo, subsurface_radius;
+  int enable_specular;
+  V3 specular_weight;
+  float alpha_x, alpha_y, ior;
+  V3 specular_color;
+  int enable_clearcoat;
+  V3 clearcoat_weight;
+  float clearcoat_alpha_x, clearcoat_alpha_y, clearcoat_ior;
+  V3 clearcoat_color;
+};
+PB_HD PrincipledBsdf default_bsdf() {
+  PrincipledBsdf b;
+  b.enable_diffuse = 0, b.diffuse_weight = V3(0.f);
+  b.enable_subsurface = 0, b.subsurface_weight = V3(0.f), b.subsurface_albedo = V3(0.f), b.subsurface_radius = V3(0.f);
+  b.enable_specular = 0, b.specular_weight = V3(0.f), b.alpha_x = 1.f, b.alpha_y = 1.f, b.ior = 1.5f;
+  b.specular_color = V3(0.f);
+  b.enable_clearcoat = 0, b.clearcoat_weight = V3(0.f), b.clearcoat_alpha_x = 1.f, b.clearcoat_alpha_y = 1.f;
+  b.clearcoat_ior = 1.5f, b.clearcoat_color = V3(0.f);
+  return b;
+}
+
+enum : uint32_t { kMatPrincipled = 0, kMatHair = 1 };
+
+struct alignas(16) Material {
+  uint32_t kind;
+  uint32_t pad[3];
+  PrincipledBsdf bsdf;  // kMatPrincipled
+  HairBsdf hair;        // kMatHair: everything except h (= hit v), hair-shader.cc:100-151
+};
+
+struct alignas(16) LightRec {  // one per (area light, primitive) ; light-manager.h:79-170
+  float p0[3], pdf;            // pdf = P(light) * P(prim) * 1/area  (float, in that order)
+  float p1[3], pad0;
+  float p2[3], pad1;
+  float normal[3], pad2;  // CalcGeometryNormal (triangle-mesh.cc:181-184)
+  float emission[3], pad3;
+};
+
+struct LightHead {
+  uint32_t first, count;  // range in LightRec / prim cdf
+};
+
+struct DScene {
+  const BvhNode* nodes;
+  const float4* slots;
+  const uint4* slot_meta;
+  const uint4* slot_ids;
+  const float4* slot_nrm;
+  const Material* materials;
+  const float* light_cdf;
+  const LightHead* light_heads;
+  const float* lprim_cdf;
+  const LightRec* lrecs;
+  uint32_t num_nodes, num_slots, num_lights, num_materials;
+};
+
+// camera of RenderingTile (render.cc:132-158), derived on the host from the scene AABB
+struct Camera {
+  float org[3];
+  float x_corner, y_corner, z_corner, dx, dy;
+};
+
+}  // namespace pb

@@ -1,0 +1,327 @@
+// dshade.h -- per-hit shading building blocks (device): surface reconstruction, light sampling,
+// principled closure set, random-walk SSS coefficients, hair set-up.  file:line = pbrlab code.
+#pragma once
+
+#include "dtrace.h"
+
+namespace pb {
+
+enum : int { kFront = 0, kBack = 1, kAmbiguous = 2 };
+
+// SurfaceInfo (shader/shader-utils.h:18-41), rebuilt from the 16-byte hit record
+struct Surface {
+  V3 pos, n_s, n_g;
+  int face;
+  uint32_t material, lightrec, flags;
+};
+
+// TraceResultToSufaceInfo (shader-utils.h:131-164) + Scene::FetchMeshShadingNormal (scene.cc:210-228,
+// mesh/triangle-mesh.cc:62-101) + EmbreeRayToTraceResult's normalisation (raytracer_impl.cc:221-240)
+__device__ __forceinline__ Surface make_surface(const DScene& sc, V3 org, V3 dir, const Hit& h) {
+  Surface s;
+  uint4 meta = sc.slot_meta[h.slot];
+  s.material = meta.y, s.lightrec = meta.z, s.flags = meta.w;
+  const float4* g = sc.slots + (size_t)h.slot * 4;
+  if (meta.w & kSlotIsCurve) {
+    float4 cp[4] = {g[0], g[1], g[2], g[3]};
+    s.n_g = normalize_raw(bezier_tangent(cp, h.u));
+    s.n_s = s.n_g;  // scene.cc:222-223
+  } else {
+    V3 v0 = ld3(g[0]), v1 = ld3(g[1]), v2 = ld3(g[2]);
+    s.n_g = normalize_raw(cross(v1 - v0, v2 - v0));
+    if (meta.w & kSlotHasNormals) {
+      const float4* n = sc.slot_nrm + (size_t)h.slot * 3;
+      s.n_s = vnormalize(lerp3(ld3(n[0]), ld3(n[1]), ld3(n[2]), h.u, h.v));
+    } else {
+      s.n_s = vnormalize(cross(v1 - v0, v2 - v1));  // CalcGeometryNormal, triangle-mesh.cc:181-184
+    }
+  }
+  s.pos = org + h.t * dir;
+  float dg = dot(dir, s.n_g), ds = dot(dir, s.n_s);
+  s.face = (dg < 0.0f && ds < 0.0f) ? kFront : ((dg > 0.0f && ds > 0.0f) ? kBack : kAmbiguous);
+  return s;
+}
+
+// std::lower_bound on a float CDF, clamped to the last entry (Q10)
+__device__ __forceinline__ uint32_t cdf_lower_bound(const float* cdf, uint32_t n, float u) {
+  uint32_t lo = 0, len = n;
+  while (len > 0) {
+    uint32_t half = len >> 1;
+    if (cdf[lo + half] < u) {
+      lo = lo + half + 1;
+      len = len - half - 1;
+    } else {
+      len = half;
+    }
+  }
+  return lo < n ? lo : n - 1;
+}
+
+// DirectIllumination up to the shadow ray (shader-utils.h:166-190) with LightManager::SampleAllLight
+// (light-manager.h:79-170: 4 draws, none when the scene has no light).  Returns true when a shadow ray
+// has to be traced; dir/dist describe it, pdf_sigma/emission feed nee_contribution().
+struct Nee {
+  V3 dir, emission;
+  float dist, pdf_sigma;
+};
+__device__ __forceinline__ bool nee_sample(const DScene& sc, Rng& rng, V3 pos, V3 global_normal, bool hemisphere, Nee& n) {
+  if (sc.num_lights == 0) return false;
+  float u0 = draw(rng);
+  uint32_t li = cdf_lower_bound(sc.light_cdf, sc.num_lights, u0);
+  LightHead head = sc.light_heads[li];
+  float u1 = draw(rng);
+  uint32_t pi = cdf_lower_bound(sc.lprim_cdf + head.first, head.count, u1);
+  float u2 = draw(rng);
+  float u3 = draw(rng);
+  float bu, bv;
+  triangle_uniform_sampler(u2, u3, bu, bv);
+  const float4* lr = reinterpret_cast<const float4*>(sc.lrecs + head.first + pi);
+  float4 a = lr[0], b = lr[1], c = lr[2], nn = lr[3], e = lr[4];
+  V3 light_pos = lerp3(ld3(a), ld3(b), ld3(c), bu, bv);  // FetchLocalPosition, triangle-mesh.cc:102-112
+  V3 light_normal = ld3(nn);
+  float pdf = a.w;
+  n.emission = ld3(e);
+  n.dir = vnormalize(light_pos - pos);
+  n.dist = length(pos - light_pos);
+  float wl_dot_nl = -dot(n.dir, light_normal);
+  float wl_dot_np = dot(n.dir, global_normal);
+  n.pdf_sigma = fabsf(pdf * n.dist * n.dist / (wl_dot_nl * wl_dot_np));
+  return (!hemisphere) || (wl_dot_nl > 0.0f && wl_dot_np > 0.0f);
+}
+// shader-utils.h:195-208
+__device__ __forceinline__ V3 nee_contribution(const Nee& n, V3 bsdf_f, float bsdf_pdf) {
+  float w = power_heuristic(n.pdf_sigma, bsdf_pdf);
+  return bsdf_f * n.emission * w / n.pdf_sigma;
+}
+
+// ------------------------------------------------------------------ principled closure set
+// SpecularColor (cycles-principled-shader.cc:54-61)
+PB_HD V3 specular_color_fn(V3 wi, V3 wo, V3 color, float ior) {
+  V3 h = vnormalize(wi + wo);
+  float f0 = fresnel_dielectric_cos(1.0f, ior);
+  float fh = (fresnel_dielectric_cos(dot(h, wo), ior) - f0) / (1.0f - f0);
+  return color * (1.f - fh) + V3(fh);
+}
+struct SampleWeight {
+  float diffuse, subsurface, specular, clearcoat;
+};
+// FetchClosureSampleWeight (:63-112), Q7
+PB_HD SampleWeight closure_sample_weight(V3 wo, const PrincipledBsdf& b) {
+  SampleWeight w;
+  V3 refl(-wo.x, -wo.y, wo.z);
+  w.diffuse = b.enable_diffuse ? rgb_to_y(b.diffuse_weight) : 0.f;
+  w.subsurface = b.enable_subsurface ? rgb_to_y(b.subsurface_weight) : 0.f;
+  w.specular = b.enable_specular ? rgb_to_y(b.specular_weight * specular_color_fn(refl, wo, b.specular_color, b.ior)) : 0.f;
+  w.clearcoat =
+      b.enable_clearcoat ? rgb_to_y(b.clearcoat_weight * specular_color_fn(refl, wo, b.clearcoat_color, b.clearcoat_ior)) : 0.f;
+  float sum = 0.0f;
+  sum += w.diffuse;
+  sum += w.subsurface;
+  sum += w.specular;
+  sum += w.clearcoat;
+  w.diffuse /= sum;
+  w.subsurface /= sum;
+  w.specular /= sum;
+  w.clearcoat /= sum;
+  if (!isfinite(w.diffuse)) w.diffuse = 0.f;
+  if (!isfinite(w.subsurface)) w.subsurface = 0.f;
+  if (!isfinite(w.specular)) w.specular = 0.f;
+  if (!isfinite(w.clearcoat)) w.clearcoat = 0.f;
+  return w;
+}
+// EvalBsdf (:114-155)
+PB_HD void eval_bsdf(V3 wi, V3 wo, const PrincipledBsdf& b, const SampleWeight& w, V3& f, float& pdf) {
+  f = V3(0.0f);
+  pdf = 0.0f;
+  if (b.enable_diffuse) {
+    float p;
+    float v = lambert_eval(wi, p);
+    f = f + b.diffuse_weight * v;
+    pdf += w.diffuse * p;
+  }
+  if (b.enable_specular) {
+    float p;
+    float v = ggx_eval(wi, wo, b.alpha_x, b.alpha_y, 2, p);
+    f = f + b.specular_weight * specular_color_fn(wi, wo, b.specular_color, b.ior) * v;
+    pdf += w.specular * p;
+  }
+  if (b.enable_clearcoat) {
+    float p;
+    float v = ggx_eval(wi, wo, b.clearcoat_alpha_x, b.clearcoat_alpha_y, 1, p);
+    f = f + b.clearcoat_weight * specular_color_fn(wi, wo, b.clearcoat_color, b.clearcoat_ior) * v;
+    pdf += w.clearcoat * p;
+  }
+}
+// SampleBsdf's closure pick (:169-242): 0 diffuse, 1 subsurface, 2 specular, 3 clearcoat (also the
+// fall-through when every weight is 0, Q7)
+PB_HD int pick_closure(float select, const SampleWeight& w) {
+  if (select < w.diffuse) return 0;
+  if (select < w.diffuse + w.subsurface) return 1;
+  if (select < w.diffuse + w.subsurface + w.specular) return 2;
+  return 3;
+}
+
+// ------------------------------------------------------------------ ParamToBsdf, hoisted to commit time
+struct PrincipledParam {  // == pbrhip_principled_param == CyclesPrincipledBsdfParameter (material-param.h:24-49)
+  float base_color[3];
+  float subsurface;
+  float subsurface_radius[3];
+  float subsurface_color[3];
+  float metallic, specular, specular_tint, roughness, anisotropic, anisotropic_rotation;
+  float sheen, sheen_tint, clearcoat, clearcoat_roughness, ior, transmission, transmission_roughness;
+  uint32_t base_color_tex_id, subsurface_color_tex_id;
+};
+struct HairParam {  // == pbrhip_hair_param == HairBsdfParameter (material-param.h:51-72)
+  uint32_t coloring_hair;
+  float base_color[3];
+  float melanin, melanin_redness, melanin_randomize;
+  float roughness, azimuthal_roughness, ior, shift;
+  float specular_tint[3], second_specular_tint[3], transmission_tint[3];
+};
+
+// random-walk-sss.h:35-104 (BssrdfSetup with burley radius, mfp scaling, eq. 5)
+PB_HD float burley_fitting5(float A) { return 1.85f - A + 7.0f * fabsf((A - 0.8f) * (A - 0.8f) * (A - 0.8f)); }
+PB_HD void bssrdf_setup(V3& weight, V3 albedo, V3& radius, V3& diffuse_weight) {
+  diffuse_weight = V3(0.0f);
+  const float kMinRadius = 1e-8f;
+  float kd[3] = {0, 0, 0}, w[3] = {weight.x, weight.y, weight.z}, r[3] = {radius.x, radius.y, radius.z};
+  int channels = 3;
+  for (int i = 0; i < 3; i++)
+    if (r[i] < kMinRadius) {
+      kd[i] = w[i];
+      w[i] = 0.f;
+      r[i] = 0.f;
+      channels--;
+    }
+  weight = V3(w[0], w[1], w[2]);
+  radius = V3(r[0], r[1], r[2]);
+  if (channels < 3) diffuse_weight = V3(kd[0], kd[1], kd[2]);
+  if (channels > 0) {
+    V3 l = 0.25f * (1.0f / kPi) * radius;
+    V3 s(burley_fitting5(albedo.x), burley_fitting5(albedo.y), burley_fitting5(albedo.z));
+    radius = l / s;
+  }
+}
+// cycles-principled-shader.cc:244-412 without textures (row N4)
+PB_HD PrincipledBsdf param_to_bsdf(const PrincipledParam& m) {
+  const V3 weight(1.f);
+  V3 base_color(m.base_color[0], m.base_color[1], m.base_color[2]);
+  float subsurface = m.subsurface;
+  V3 subsurface_radius(m.subsurface_radius[0], m.subsurface_radius[1], m.subsurface_radius[2]);
+  V3 subsurface_color(m.subsurface_color[0], m.subsurface_color[1], m.subsurface_color[2]);
+  const float cutoff = kEps;
+  PrincipledBsdf b = default_bsdf();
+  float diffuse_w = (1.0f - saturate(m.metallic)) * (1.0f - saturate(m.transmission));
+  float final_transmission = saturate(m.transmission) * (1.0f - saturate(m.metallic));
+  float specular_w = (1.0f - final_transmission);
+  V3 mixed = subsurface_color * subsurface + base_color * (1.0f - subsurface);
+  if (average(mixed) > cutoff) {
+    if (subsurface < cutoff && diffuse_w > cutoff) {
+      b.enable_diffuse = 1;
+      b.diffuse_weight = weight * base_color * diffuse_w;
+    } else if (subsurface > cutoff) {
+      b.enable_subsurface = 1;
+      b.subsurface_weight = weight * mixed * diffuse_w;
+      b.subsurface_albedo = mixed;
+      b.subsurface_radius = subsurface_radius * subsurface;
+      V3 add_diffuse(0.f);
+      bssrdf_setup(b.subsurface_weight, b.subsurface_albedo, b.subsurface_radius, add_diffuse);
+      if (!is_black(add_diffuse)) {
+        b.enable_diffuse = 1;
+        b.diffuse_weight = b.diffuse_weight + add_diffuse;
+      }
+    }
+  }
+  if (specular_w > cutoff && (m.specular > cutoff || m.metallic > cutoff)) {
+    b.enable_specular = 1;
+    b.specular_weight = weight * specular_w;
+    b.ior = (2.0f / (1.0f - safe_sqrt(0.08f * m.specular))) - 1.0f;
+    float aspect = safe_sqrt(1.0f - m.anisotropic * 0.9f);
+    float r2 = m.roughness * m.roughness;
+    b.alpha_x = r2 / aspect;
+    b.alpha_y = r2 * aspect;
+    float y = rgb_to_y(base_color);
+    V3 rho_tint = y > 0.0f ? base_color / y : V3(0.0f);
+    V3 rho_specular = lerp(V3(1.0f), rho_tint, m.specular_tint);
+    b.specular_color = lerp(0.08f * m.specular * rho_specular, base_color, m.metallic);
+  }
+  if (m.clearcoat > cutoff) {
+    b.enable_clearcoat = 1;
+    b.clearcoat_weight = V3(0.25f * m.clearcoat);
+    b.clearcoat_alpha_x = m.clearcoat_roughness * m.clearcoat_roughness;
+    b.clearcoat_alpha_y = m.clearcoat_roughness * m.clearcoat_roughness;
+    b.clearcoat_color = V3(0.04f);
+    b.clearcoat_ior = 1.5f;
+  }
+  return b;
+}
+
+PB_HD float pow_n(float v, int n) {  // pbrlab_math.h:40-55
+  if (n == 0) return 1.f;
+  if (n == 1) return v;
+  float h = pow_n(v, n / 2);
+  return h * h * pow_n(v, n & 1);
+}
+// hair-shader.cc:19-151 : everything of ParamToBsdf that does not depend on the hit (h is filled per hit)
+PB_HD HairBsdf hair_param_to_bsdf(const HairParam& m) {
+  HairBsdf b;
+  if (m.coloring_hair == 0) {
+    float bn = m.azimuthal_roughness;  // Q12: sigma_a from RGB uses beta_n
+    float c[3] = {m.base_color[0], m.base_color[1], m.base_color[2]}, r[3];
+    for (int i = 0; i < 3; i++)
+      r[i] = sqr(fastm::flog(c[i]) / (5.969f - 0.215f * bn + 2.532f * sqr(bn) - 10.73f * pow_n(bn, 3) +
+                                      5.574f * pow_n(bn, 4) + 0.245f * pow_n(bn, 5)));
+    b.sigma_a = V3(r[0], r[1], r[2]);
+  } else {
+    const float random_value = 0.5f;
+    float factor = 1.f + 2.f * (random_value - 0.5f);
+    float melanin = clampf(m.melanin, 0.0f, 1.0f) * factor;
+    float redness = clampf(m.melanin_redness, 0.0f, 1.0f);
+    melanin = -fastm::flog(smax(1.0f - melanin, 0.0001f));
+    float eu = melanin * (1.0f - redness);
+    float pheo = melanin * redness;
+    b.sigma_a = V3(smax(0.0f, eu * 0.506f + pheo * 0.343f), smax(0.0f, eu * 0.841f + pheo * 0.733f),
+                   smax(0.0f, eu * 1.653f + pheo * 1.924f));
+  }
+  b.h = 0.f;
+  float bm = m.roughness;
+  b.v[0] = sqr(0.726f * bm + 0.812f * sqr(bm) + 3.7f * pow_n(bm, 20));
+  b.v[1] = 0.25f * b.v[0];
+  b.v[2] = 4.0f * b.v[0];
+  b.v[3] = b.v[2];
+  float bn2 = sqr(m.azimuthal_roughness);
+  b.s = sqrtf(kPi / 8.0f) * (0.265f * m.azimuthal_roughness + 1.194f * bn2 + 5.372f * pow_n(bn2, 11));
+  b.eta = m.ior;
+  b.alpha = m.shift * kPi / 180.f;
+  b.tints[0] = V3(m.specular_tint[0], m.specular_tint[1], m.specular_tint[2]);
+  b.tints[1] = V3(m.transmission_tint[0], m.transmission_tint[1], m.transmission_tint[2]);
+  b.tints[2] = V3(m.second_specular_tint[0], m.second_specular_tint[1], m.second_specular_tint[2]);
+  b.tints[3] = V3(1.f);
+  b.transparent_scale = 1.f;
+  return b;
+}
+
+// ------------------------------------------------------------------ random-walk SSS pieces (random-walk-sss.h)
+PB_HD void scattering_from_albedo(float A, float d, float& sigma_t, float& sigma_s) {  // :111-122
+  float a = 1.0f - f_exp(A * (-5.09406f + A * (2.61188f - A * 4.31805f)));
+  float s = 1.9f - A + 3.5f * sqr(A - 0.8f);
+  sigma_t = 1.0f / smax(d * s, 1e-16f);
+  sigma_s = sigma_t * a;
+}
+// SampleScatterDistance + SampleChannel (:141-188)
+PB_HD float sample_scatter_distance(V3 throughput, V3 sigma_s, V3 sigma_t, float u0, float u1, V3& channel_pdf) {
+  V3 albedo = safe_divide_spectrum(sigma_s, sigma_t);
+  V3 w(fabsf(throughput.x * albedo.x), fabsf(throughput.y * albedo.y), fabsf(throughput.z * albedo.z));
+  float sum = w.x + w.y + w.z;
+  if (sum > 0.0f)
+    channel_pdf = V3(w.x / sum, w.y / sum, w.z / sum);
+  else
+    channel_pdf = V3(1.0f / 3.0f, 1.0f / 3.0f, 1.0f / 3.0f);
+  float st = (u0 < channel_pdf.x) ? sigma_t.x : ((u0 < channel_pdf.x + channel_pdf.y) ? sigma_t.y : sigma_t.z);
+  return -f_log(1.0f - u1) / st;
+}
+PB_HD V3 attenuate_transmission(V3 sigma_t, float d) {  // :190-198
+  return V3(f_exp(-sigma_t.x * d), f_exp(-sigma_t.y * d), f_exp(-sigma_t.z * d));
+}
+
+}  // namespace pb

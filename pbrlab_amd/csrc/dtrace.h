@@ -1,0 +1,196 @@
+// dtrace.h -- ray/primitive tests and BVH2 traversal (device).
+//
+// Stands in for Embree's rtcIntersect1 / rtcOccluded1 behind pbrlab's Raytracer facade
+// (src/raytracer/raytracer_impl.cc:268-287).  Intersection contract:
+//   * a primitive hit is accepted for  tmin < t <= tmax
+//   * closest hit = smallest t; equal t -> smaller canonical primitive id (instance, geom, prim)
+//     => the answer is independent of BVH shape and traversal order
+//   * any-hit = "some primitive has an accepted hit"
+//   * boxes are tested conservatively (interval widened by 2^-16 relative)
+#pragma once
+
+#include "dscene.h"
+
+namespace pb {
+
+struct Hit {
+  float t, u, v;
+  uint32_t slot;  // kNone = miss
+};
+
+struct TravStats {
+  uint32_t nodes, tris, curves;
+};
+
+__device__ __forceinline__ V3 ld3(const float4& a) { return V3(a.x, a.y, a.z); }
+
+// Moeller-Trumbore; u,v are the barycentrics of v1,v2 (what Lerp3 expects, pbrlab_math.h:35-38)
+__device__ __forceinline__ bool tri_test(V3 v0, V3 v1, V3 v2, V3 o, V3 d, float tmin, float& t, float& u, float& v) {
+  V3 e1 = v1 - v0, e2 = v2 - v0;
+  V3 p = cross(d, e2);
+  float det = dot(e1, p);
+  if (!(det != 0.0f)) return false;
+  float inv = 1.0f / det;
+  V3 s = o - v0;
+  float uu = dot(s, p) * inv;
+  if (!(uu >= 0.0f && uu <= 1.0f)) return false;
+  V3 q = cross(s, e1);
+  float vv = dot(d, q) * inv;
+  if (!(vv >= 0.0f && uu + vv <= 1.0f)) return false;
+  float tt = dot(e2, q) * inv;
+  if (!(tt > tmin)) return false;
+  t = tt, u = uu, v = vv;
+  return true;
+}
+
+__device__ __forceinline__ void bezier_eval(const float4 cp[4], float u, float out[4]) {
+  float s = 1.0f - u;
+  float b0 = s * s * s, b1 = 3.0f * u * s * s, b2 = 3.0f * u * u * s, b3 = u * u * u;
+  out[0] = ((cp[0].x * b0 + cp[1].x * b1) + cp[2].x * b2) + cp[3].x * b3;
+  out[1] = ((cp[0].y * b0 + cp[1].y * b1) + cp[2].y * b2) + cp[3].y * b3;
+  out[2] = ((cp[0].z * b0 + cp[1].z * b1) + cp[2].z * b2) + cp[3].z * b3;
+  out[3] = ((cp[0].w * b0 + cp[1].w * b1) + cp[2].w * b2) + cp[3].w * b3;
+}
+// dP/du of the cubic: what Embree reports as Ng for flat curves (hair-shader.cc:165-166 uses it as tangent)
+__device__ __forceinline__ V3 bezier_tangent(const float4 cp[4], float u) {
+  float s = 1.0f - u;
+  float c0 = 3.0f * s * s, c1 = 6.0f * u * s, c2 = 3.0f * u * u;
+  V3 p0 = ld3(cp[0]), p1 = ld3(cp[1]), p2 = ld3(cp[2]), p3 = ld3(cp[3]);
+  return (p1 - p0) * c0 + (p2 - p1) * c1 + (p3 - p2) * c2;
+}
+
+// Ray-facing flat ribbon, 4 linear sub-segments per cubic (RTC_GEOMETRY_TYPE_FLAT_BEZIER_CURVE,
+// raytracer_impl.cc:158-159): u = curve parameter, v in [-1,1] across the width.
+__device__ __forceinline__ bool curve_test(const float4 cp[4], V3 o, V3 d, float tmin, float tmax, float& t, float& u,
+                                           float& v) {
+  float inv_len = 1.0f / sqrtf(dot(d, d));
+  V3 dn = d * inv_len;
+  V3 bx, by;
+  branchless_onb(dn, bx, by);
+  float px[5], py[5], pz[5], pr[5];
+#pragma unroll
+  for (int i = 0; i < 5; i++) {
+    float c[4];
+    bezier_eval(cp, (float)i * 0.25f, c);
+    V3 rel = V3(c[0], c[1], c[2]) - o;
+    px[i] = dot(rel, bx), py[i] = dot(rel, by), pz[i] = dot(rel, dn), pr[i] = c[3];
+  }
+  bool found = false;
+  float best = tmax;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    float ex = px[i + 1] - px[i], ey = py[i + 1] - py[i];
+    float len2 = ex * ex + ey * ey;
+    if (!(len2 > 0.0f)) continue;
+    float s = -(px[i] * ex + py[i] * ey) / len2;
+    if (!(s >= 0.0f && s <= 1.0f)) continue;
+    float dist = (ey * px[i] - ex * py[i]) / sqrtf(len2);
+    float r = pr[i] + s * (pr[i + 1] - pr[i]);
+    if (!(r > 0.0f && fabsf(dist) <= r)) continue;
+    float tt = (pz[i] + s * (pz[i + 1] - pz[i])) * inv_len;
+    if (!(tt > tmin)) continue;
+    if (found ? !(tt < best) : !(tt <= best)) continue;
+    best = tt, found = true;
+    t = tt, u = ((float)i + s) * 0.25f, v = dist / r;
+  }
+  return found;
+}
+
+// conservative slab test against [tmin, tmax]; returns entry distance in tnear
+__device__ __forceinline__ bool box_test(const float* lo, const float* hi, V3 o, V3 inv, float tmin, float tmax,
+                                         float& tnear) {
+  float t0 = (lo[0] - o.x) * inv.x, t1 = (hi[0] - o.x) * inv.x;
+  float a = fminf(t0, t1), b = fmaxf(t0, t1);
+  t0 = (lo[1] - o.y) * inv.y, t1 = (hi[1] - o.y) * inv.y;
+  a = fmaxf(a, fminf(t0, t1)), b = fminf(b, fmaxf(t0, t1));
+  t0 = (lo[2] - o.z) * inv.z, t1 = (hi[2] - o.z) * inv.z;
+  a = fmaxf(a, fminf(t0, t1)), b = fminf(b, fmaxf(t0, t1));
+  a = a - fabsf(a) * 1.52587890625e-05f;
+  b = b + fabsf(b) * 1.52587890625e-05f;
+  tnear = a;
+  return a <= b && b >= tmin && a <= tmax;
+}
+
+// Leaf processing.  ANY: returns true on the first accepted hit.
+template <bool ANY, bool STATS>
+__device__ __forceinline__ bool leaf_test(const DScene& sc, uint32_t leaf, V3 o, V3 d, float tmin, float& best_t,
+                                          Hit& hit, TravStats& st) {
+  uint32_t first = (leaf & 0x3FFFFFFFu) >> 3, count = (leaf & 7u) + 1u;
+  bool is_curve = (leaf & kCurveBit) != 0;
+  for (uint32_t s = first; s < first + count; s++) {
+    const float4* g = sc.slots + (size_t)s * 4;
+    float t, u, v;
+    bool ok;
+    if (!is_curve) {
+      float4 a = g[0], b = g[1], c = g[2];
+      if (STATS) st.tris++;
+      ok = tri_test(ld3(a), ld3(b), ld3(c), o, d, tmin, t, u, v) && (t <= best_t);
+    } else {
+      float4 cp[4] = {g[0], g[1], g[2], g[3]};
+      if (STATS) st.curves++;
+      ok = curve_test(cp, o, d, tmin, best_t, t, u, v);
+    }
+    if (!ok) continue;
+    if (ANY) return true;
+    if (t == best_t && hit.slot != kNone) {  // tie: the smaller canonical primitive id wins
+      if (!(sc.slot_meta[s].x < sc.slot_meta[hit.slot].x)) continue;
+    }
+    best_t = t;
+    hit.t = t, hit.u = u, hit.v = v, hit.slot = s;
+  }
+  return false;
+}
+
+// BVH2 traversal, near child first, far child on a per-lane stack (stack[i * stride]).
+template <bool ANY, bool STATS>
+__device__ __forceinline__ bool traverse(const DScene& sc, V3 o, V3 d, float tmin, float tmax, Hit& hit,
+                                         uint32_t* stack, uint32_t stride, TravStats& st, uint32_t* overflow) {
+  hit.slot = kNone;
+  hit.t = tmax, hit.u = 0.f, hit.v = 0.f;
+  if (sc.num_nodes == 0) return false;
+  V3 inv(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  float best_t = tmax;
+  int sp = 0;
+  uint32_t cur = 0;
+  for (;;) {
+    // cur is an internal node
+    const float4* np = reinterpret_cast<const float4*>(sc.nodes + cur);
+    float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+    if (STATS) st.nodes++;
+    float lo0[3] = {n0.x, n0.y, n0.z}, hi0[3] = {n0.w, n1.x, n1.y};
+    float lo1[3] = {n1.z, n1.w, n2.x}, hi1[3] = {n2.y, n2.z, n2.w};
+    uint32_t c0 = __float_as_uint(n3.x), c1 = __float_as_uint(n3.y);
+    float t0, t1;
+    bool h0 = box_test(lo0, hi0, o, inv, tmin, best_t, t0);
+    bool h1 = box_test(lo1, hi1, o, inv, tmin, best_t, t1);
+    uint32_t next = kEmptyChild;
+    if (h0 && h1) {
+      uint32_t nearc = c0, farc = c1;
+      if (t1 < t0) nearc = c1, farc = c0;
+      if (sp < kStackDepth) {
+        stack[(uint32_t)sp * stride] = farc;
+        sp++;
+      } else {
+        *overflow = 1u;
+      }
+      next = nearc;
+    } else if (h0) {
+      next = c0;
+    } else if (h1) {
+      next = c1;
+    }
+    for (;;) {
+      if (next == kEmptyChild) {
+        if (sp == 0) return hit.slot != kNone;
+        sp--;
+        next = stack[(uint32_t)sp * stride];
+      }
+      if (!(next & kLeafBit)) break;
+      if (leaf_test<ANY, STATS>(sc, next, o, d, tmin, best_t, hit, st)) return true;
+      next = kEmptyChild;
+    }
+    cur = next;
+  }
+}
+
+}  // namespace pb

@@ -1,0 +1,69 @@
+// host_scene.h -- host-side scene model kept by libpbrhip (the "scene upload / BVH flatten / tile
+// dispatch stay in C++" part of the design).  Mirrors the read side of pbrlab's Scene
+// (src/scene.h:93-110), LightManager (src/light-manager.h:172-193) and Raytracer facade.
+#pragma once
+
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "dshade.h"
+
+namespace pb {
+
+struct HostMesh {
+  int kind = 0;  // 0 triangle mesh, 1 cubic Bezier curve mesh (mesh/mesh.h:23)
+  // triangles (mesh/attribute.h, mesh/triangle-mesh.h)
+  std::vector<float> vertices, normals, texcoords;  // xyzw, xyzw, uv
+  std::vector<uint32_t> vid, nid, tid, mat;
+  uint32_t nfaces = 0;
+  // curves (mesh/cubic-bezier-curve-mesh.h)
+  std::vector<float> cverts;  // xyz + radius
+  std::vector<uint32_t> cidx, cmat;
+  uint32_t num_prims() const { return kind == 0 ? nfaces : (uint32_t)cidx.size(); }
+};
+
+struct HostAreaLight {  // LightManager::AreaLight (light-manager.h:174-182)
+  std::vector<uint32_t> light_param_ids;
+  std::vector<float> choose_prob, cdf, area_pdf;
+  float intensity_sum = 0.f;
+  uint32_t global_id = kNone;
+};
+
+struct HostInstance {  // MeshInstance (mesh-instance.h:22-36)
+  uint32_t local_scene = 0;
+  float xf[16];
+  std::vector<std::vector<uint32_t>> material_ids, light_ids;
+  std::vector<int> has_area_light;  // per geom
+  std::vector<HostAreaLight> area_lights;
+};
+
+struct HostMaterial {
+  uint32_t kind = kMatPrincipled;
+  PrincipledParam pr;
+  HairParam hr;
+};
+
+struct HostLight {  // LightManager::Light (light-manager.h:184-188)
+  float choose_prob = 0.f;
+  uint32_t instance_id = 0, geom_id = 0;
+};
+
+// canonical primitive reference; index in the flattened list = gid
+struct PrimRef {
+  uint32_t instance_id, geom_id, prim_id, kind;
+};
+
+struct FlatBvh {
+  std::vector<BvhNode> nodes;
+  std::vector<uint32_t> slot_gid;  // leaf order -> gid
+  uint32_t depth = 0;
+};
+
+// Binned-SAH BVH2 over primitive boxes; leaves hold <= kMaxLeaf primitives of ONE kind.
+// boxes: lo/hi per primitive (3 floats each); kinds: 0 triangle / 1 curve.
+void build_bvh(const std::vector<float>& lo, const std::vector<float>& hi, const std::vector<uint8_t>& kinds,
+               FlatBvh* out);
+
+}  // namespace pb

@@ -1,0 +1,62 @@
+// kernels.h -- path-state layout in HBM and the kernel launch interface (host <-> kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dscene.h"
+
+namespace pb {
+
+// Per-path state, SoA, float4-packed so that a wave reads/writes 1 KiB per instruction.
+// N = paths of one chunk (pixels of this rank's tiles x passes in the chunk); slot = pass_local*npix + pixel.
+//   ray_o (org.xyz, tmin) | ray_d (dir.xyz, tmax) | thr (throughput.rgb, bsdf pdf) | L (contribution.rgb, -)
+//   hit (t, u, v, slot bits) | rng (PCG32 state, u64) | flags (u32)                                = 92 B
+//   random-walk state, touched only by paths inside a medium:                                       96 B
+//     sss_sigt (sigma_t.rgb, step index) | sss_sigs (sigma_s.rgb, entry instance id) | sss_thr (walk throughput)
+//     sss_pdf (channel pdf of the pending step) | sss_ez (entry frame normal) | sss_A (resolved first NEE)
+//   queues: q_in/q_out (ping-pong), q_principled, q_hair, q_sss (u32 each) and the shadow queue
+//     sh_o (org, tmin) | sh_d (dir, tmax) | sh_c (contribution if visible, path slot) | sh_e (if occluded, mode)
+struct PathState {
+  float4 *ray_o, *ray_d, *thr, *L, *hit;
+  uint64_t* rng;
+  uint32_t* flags;
+  float4 *sss_sigt, *sss_sigs, *sss_thr, *sss_pdf, *sss_ez, *sss_A;
+  uint32_t *q_in, *q_out, *q_principled, *q_hair, *q_sss;
+  float4 *sh_o, *sh_d, *sh_c, *sh_e;
+  uint32_t* counts;              // kCnt*
+  unsigned long long* stats;     // kStat*
+};
+
+enum : uint32_t { kFlagNotFirst = 1u, kFlagSss = 2u };
+enum : uint32_t { kShNormal = 0u, kShSssEntry = 1u, kShSssExit = 2u };
+enum : uint32_t { kCntIn = 0, kCntOut, kCntPrincipled, kCntHair, kCntSss, kCntShadow, kCntOverflow, kCntNum = 8 };
+enum : uint32_t {
+  kStatClosestRays = 0, kStatClosestNodes, kStatClosestTris, kStatClosestCurves,
+  kStatShadowRays, kStatShadowNodes, kStatShadowTris, kStatShadowCurves, kStatNum
+};
+
+constexpr uint32_t kTraceGridCap = 256 * 16;  // blocks: 256 CUs x (<=4 resident + queued)
+constexpr uint32_t kShadeGridCap = 256 * 8;
+
+struct HookHit {  // == pbrhip_hit == TraceResult (raytracer.h:9-17)
+  float ng[3];
+  float t, u, v;
+  uint32_t instance_id, geom_id, prim_id;
+};
+
+void launch_generate(hipStream_t s, const PathState& P, const Camera& cam, const uint32_t* pix_index, uint32_t npix,
+                     uint32_t npaths, uint32_t width, uint32_t first_pass, uint64_t seed_seq);
+void launch_trace_closest(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, bool stats);
+void launch_trace_shadow(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, bool stats);
+void launch_surface(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc);
+void launch_shade_principled(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc);
+void launch_shade_hair(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc);
+void launch_sss_step(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc);
+void launch_accumulate(hipStream_t s, const PathState& P, const uint32_t* pix_index, uint32_t npix, uint32_t npass,
+                       float* rgba, uint32_t* count);
+void launch_advance(hipStream_t s, const PathState& P);
+void launch_hook_closest(hipStream_t s, const DScene& sc, const float4* rays, uint32_t n, HookHit* out, uint32_t* flag);
+void launch_hook_any(hipStream_t s, const DScene& sc, const float4* rays, uint32_t n, uint8_t* out, uint32_t* flag);
+
+}  // namespace pb

@@ -1,0 +1,656 @@
+// kernels.hip -- the wavefront path tracer's device kernels (gfx950, wave64).
+//
+// One path = one (pixel, pass) sample.  Path state lives in HBM as float4-packed SoA indexed by the
+// path slot; stages exchange *queues of slot ids* that are compacted with wave ballots
+// (one atomicAdd per wave).  One iteration of the host loop (render.cpp) =
+//
+//   k_trace_closest   rtcIntersect1          (raytracer_impl.cc:268-278)  active paths -> hit records
+//   k_surface         GetRadiance head       (render.cc:31-68): miss / implicit light + MIS / Russian
+//                                            roulette, then routes each path to its closure queue
+//   k_shade_principled CyclesPrincipledShader (cycles-principled-shader.cc:414-484) incl. SSS entry
+//   k_shade_hair      HairShader             (hair-shader.cc:153-229)
+//   k_sss_step        RandomWalkSubsurface loop body + exit (random-walk-sss.h:287-405)
+//   k_trace_shadow    rtcOccluded1 + tail of DirectIllumination (shader-utils.h:192-208)
+//
+// and k_generate (render.cc:160-171) / k_accumulate (render.cc:175-183) bracket a chunk of passes.
+#include "dshade.h"
+#include "kernels.h"
+
+namespace pb {
+
+constexpr int kBlock = 256;
+
+// ------------------------------------------------------------------ wave-ballot stream compaction
+// Every lane of the wave must reach this call; returns the output index for lanes with pred.
+__device__ __forceinline__ uint32_t queue_append(uint32_t* counter, bool pred) {
+  unsigned long long mask = __ballot(pred);
+  if (mask == 0ull) return 0u;
+  uint32_t lane = __lane_id();
+  uint32_t prefix = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+  int leader = __ffsll((long long)mask) - 1;
+  uint32_t base = 0;
+  if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+  base = (uint32_t)__shfl((int)base, leader);
+  return base + prefix;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
+  return v;
+}
+
+__device__ __forceinline__ float4 mk4(V3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
+
+// ------------------------------------------------------------------ k_generate (render.cc:160-171)
+__global__ __launch_bounds__(kBlock) void k_generate(PathState P, Camera cam, const uint32_t* __restrict__ pix_index,
+                                                     uint32_t npix, uint32_t npaths, uint32_t width,
+                                                     uint32_t first_pass, uint64_t seed_seq) {
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < npaths; i += gridDim.x * kBlock) {
+    uint32_t pass = first_pass + i / npix;
+    uint32_t gpix = pix_index[i % npix];
+    uint32_t x = gpix % width, y = gpix / width;
+    Rng rng = rng_seed(((uint64_t)pass << 32) + (uint64_t)gpix, seed_seq);
+    float jx = draw(rng);
+    float jy = draw(rng);
+    V3 org(cam.org[0], cam.org[1], cam.org[2]);
+    V3 target(cam.x_corner + cam.dx * ((float)x + jx), cam.y_corner - cam.dy * ((float)y + jy), cam.z_corner);
+    V3 dir = normalize_raw(target - org);
+    P.ray_o[i] = mk4(org, 0.0f);
+    P.ray_d[i] = mk4(dir, kInf);
+    P.thr[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+    P.L[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    P.rng[i] = rng.state;
+    P.flags[i] = 0u;
+    P.q_in[i] = i;
+  }
+}
+
+// ------------------------------------------------------------------ k_trace_closest / k_trace_shadow
+template <bool STATS>
+__global__ __launch_bounds__(kBlock) void k_trace_closest(PathState P, DScene sc, uint32_t count_idx) {
+  __shared__ uint32_t stk[kStackDepth * kBlock];
+  const uint32_t n = P.counts[count_idx];
+  TravStats st = {0u, 0u, 0u};
+  uint32_t overflow = 0u;
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    uint32_t p = P.q_in[i];
+    float4 o4 = P.ray_o[p], d4 = P.ray_d[p];
+    Hit h;
+    traverse<false, STATS>(sc, ld3(o4), ld3(d4), o4.w, d4.w, h, stk + threadIdx.x, kBlock, st, &overflow);
+    P.hit[p] = make_float4(h.t, h.u, h.v, __uint_as_float(h.slot));
+  }
+  if (overflow) P.counts[kCntOverflow] = 1u;
+  if (STATS) {
+    uint32_t a = wave_sum(st.nodes), b = wave_sum(st.tris), c = wave_sum(st.curves);
+    if (__lane_id() == 0) {
+      atomicAdd(&P.stats[kStatClosestNodes], (unsigned long long)a);
+      atomicAdd(&P.stats[kStatClosestTris], (unsigned long long)b);
+      atomicAdd(&P.stats[kStatClosestCurves], (unsigned long long)c);
+      if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&P.stats[kStatClosestRays], (unsigned long long)n);
+    }
+  }
+}
+
+// Shadow rays + tail of DirectIllumination.  Shadow entry modes:
+//   kShNormal   L += c_vis when unoccluded
+//   kShSssEntry A  = 0 + c_vis when unoccluded (first NEE of a path that entered the medium)
+//   kShSssExit  L += unoccluded ? c_vis : c_occ
+template <bool STATS>
+__global__ __launch_bounds__(kBlock) void k_trace_shadow(PathState P, DScene sc) {
+  __shared__ uint32_t stk[kStackDepth * kBlock];
+  const uint32_t n = P.counts[kCntShadow];
+  TravStats st = {0u, 0u, 0u};
+  uint32_t overflow = 0u;
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    float4 o4 = P.sh_o[i], d4 = P.sh_d[i];
+    Hit h;
+    bool occluded = traverse<true, STATS>(sc, ld3(o4), ld3(d4), o4.w, d4.w, h, stk + threadIdx.x, kBlock, st, &overflow);
+    float4 c = P.sh_c[i], e = P.sh_e[i];
+    uint32_t p = __float_as_uint(c.w), mode = __float_as_uint(e.w);
+    if (mode == kShSssEntry) {
+      if (!occluded) P.sss_A[p] = make_float4(0.0f + c.x, 0.0f + c.y, 0.0f + c.z, 0.0f);
+    } else {
+      V3 add = occluded ? V3(e.x, e.y, e.z) : V3(c.x, c.y, c.z);
+      if (!occluded || mode == kShSssExit) {
+        float4 L = P.L[p];
+        P.L[p] = make_float4(L.x + add.x, L.y + add.y, L.z + add.z, L.w);
+      }
+    }
+  }
+  if (overflow) P.counts[kCntOverflow] = 1u;
+  if (STATS) {
+    uint32_t a = wave_sum(st.nodes), b = wave_sum(st.tris), c = wave_sum(st.curves);
+    if (__lane_id() == 0) {
+      atomicAdd(&P.stats[kStatShadowNodes], (unsigned long long)a);
+      atomicAdd(&P.stats[kStatShadowTris], (unsigned long long)b);
+      atomicAdd(&P.stats[kStatShadowCurves], (unsigned long long)c);
+      if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&P.stats[kStatShadowRays], (unsigned long long)n);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ k_surface (render.cc:31-68)
+__global__ __launch_bounds__(kBlock) void k_surface(PathState P, DScene sc, uint64_t rng_inc) {
+  const uint32_t n = P.counts[kCntIn];
+  const uint32_t n_round = (n + kBlock - 1) / kBlock * kBlock;
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_round; i += gridDim.x * kBlock) {
+    bool active = i < n;
+    uint32_t p = active ? P.q_in[i] : 0u;
+    bool to_sss = false, to_pr = false, to_hair = false;
+    if (active) {
+      uint32_t flags = P.flags[p];
+      if (flags & kFlagSss) {
+        to_sss = true;
+      } else {
+        float4 h4 = P.hit[p];
+        Hit h = {h4.x, h4.y, h4.z, __float_as_uint(h4.w)};
+        if (h.slot != kNone) {  // render.cc:34 (miss: no environment light)
+          float4 o4 = P.ray_o[p], d4 = P.ray_d[p];
+          V3 dir = ld3(d4);
+          Surface s = make_surface(sc, ld3(o4), dir, h);
+          float4 t4 = P.thr[p];
+          V3 thr = ld3(t4);
+          if (s.face == kFront && s.lightrec != kNone) {  // render.cc:43-62, LightManager::ImplicitAreaLight
+            const float4* lr = reinterpret_cast<const float4*>(sc.lrecs + s.lightrec);
+            float pdf_area = lr[0].w;
+            V3 emission = ld3(lr[4]);
+            float a2s = fabsf((h.t * h.t) / dot(s.n_s, dir));
+            float w = (flags & kFlagNotFirst) ? power_heuristic(t4.w, pdf_area * a2s) : 1.0f;
+            float4 L4 = P.L[p];
+            V3 L = ld3(L4) + w * emission * thr;
+            P.L[p] = mk4(L, L4.w);
+          }
+          Rng rng = {P.rng[p], rng_inc};
+          float rr = spectrum_norm(thr);  // render.cc:66-68 (Q1)
+          float u = draw(rng);
+          if (!(rr < u)) {
+            thr = thr * V3(1.0f / rr);
+            P.thr[p] = mk4(thr, t4.w);
+            P.rng[p] = rng.state;
+            P.flags[p] = flags | kFlagNotFirst;
+            if (s.material != kNone) {  // shader.cc:11-17: no material -> throughput 0 -> path ends
+              uint32_t kind = sc.materials[s.material].kind;
+              to_pr = (kind == kMatPrincipled);
+              to_hair = (kind == kMatHair);
+            }
+          }
+        }
+      }
+    }
+    uint32_t k;
+    k = queue_append(&P.counts[kCntSss], to_sss);
+    if (to_sss) P.q_sss[k] = p;
+    k = queue_append(&P.counts[kCntPrincipled], to_pr);
+    if (to_pr) P.q_principled[k] = p;
+    k = queue_append(&P.counts[kCntHair], to_hair);
+    if (to_hair) P.q_hair[k] = p;
+  }
+}
+
+// writes one shadow-queue entry
+__device__ __forceinline__ void put_shadow(const PathState& P, uint32_t k, V3 pos, const Nee& n, V3 c_vis, V3 c_occ,
+                                           uint32_t p, uint32_t mode) {
+  // ShadowRay (shader-utils.h:116-129): [kEps, max(kEps, dist - kEps)]  (Q9)
+  P.sh_o[k] = mk4(pos, kEps);
+  P.sh_d[k] = mk4(n.dir, smax(kEps, n.dist - kEps));
+  P.sh_c[k] = mk4(c_vis, __uint_as_float(p));
+  P.sh_e[k] = mk4(c_occ, __uint_as_float(mode));
+}
+
+// ------------------------------------------------------------------ k_shade_principled
+// CyclesPrincipledShader (cycles-principled-shader.cc:414-484) + the tail of GetRadiance (render.cc:76-87).
+__global__ __launch_bounds__(kBlock) void k_shade_principled(PathState P, DScene sc, uint64_t rng_inc) {
+  const uint32_t n = P.counts[kCntPrincipled];
+  const uint32_t n_round = (n + kBlock - 1) / kBlock * kBlock;
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_round; i += gridDim.x * kBlock) {
+    bool active = i < n;
+    uint32_t p = active ? P.q_principled[i] : 0u;
+    bool alive = false, shadow = false;
+    V3 sh_pos(0.f), c_vis(0.f);
+    Nee nee;
+    nee.dir = V3(0.f), nee.emission = V3(0.f), nee.dist = 0.f, nee.pdf_sigma = 0.f;
+    uint32_t sh_mode = kShNormal;
+    if (active) {
+      float4 h4 = P.hit[p], o4 = P.ray_o[p], d4 = P.ray_d[p], t4 = P.thr[p];
+      Hit h = {h4.x, h4.y, h4.z, __float_as_uint(h4.w)};
+      V3 dir = ld3(d4);
+      Surface s = make_surface(sc, ld3(o4), dir, h);
+      V3 thr = ld3(t4);
+      Rng rng = {P.rng[p], rng_inc};
+      V3 new_thr(0.f), next_dir = -dir;
+      float new_pdf = 0.f;
+      if (s.face != kAmbiguous) {  // :418-424
+        V3 wo_g = -dir;
+        Frame fr;
+        fr.ez = (s.face == kFront) ? s.n_s : -s.n_s;
+        branchless_onb(fr.ez, fr.ex, fr.ey);
+        V3 wo = to_local(fr, wo_g);
+        const PrincipledBsdf& b = sc.materials[s.material].bsdf;
+        SampleWeight w = closure_sample_weight(wo, b);
+        // DirectIllumination (shader-utils.h:166-212)
+        V3 d1(0.f);
+        shadow = nee_sample(sc, rng, s.pos, fr.ez, true, nee);
+        if (shadow) {
+          V3 f;
+          float pdf;
+          eval_bsdf(to_local(fr, nee.dir), wo, b, w, f, pdf);
+          d1 = nee_contribution(nee, f, pdf);
+          sh_pos = s.pos;
+        }
+        // SampleBsdf (:169-242)
+        float select = draw(rng);
+        int pick = pick_closure(select, w);
+        V3 wi(0.f);
+        bool sampled = true;
+        if (pick == 0) {
+          float u0 = draw(rng);
+          float u1 = draw(rng);
+          float pdf;
+          lambert_sample(u0, u1, wi, pdf);
+        } else if (pick == 2) {
+          float u0 = draw(rng);
+          float u1 = draw(rng);
+          ggx_sample(wo, b.alpha_x, b.alpha_y, u0, u1, wi);
+        } else if (pick == 3) {
+          float u0 = draw(rng);
+          float u1 = draw(rng);
+          ggx_sample(wo, b.clearcoat_alpha_x, b.clearcoat_alpha_y, u0, u1, wi);
+        } else {
+          // RandomWalkSubsurface entry (random-walk-sss.h:236-287)
+          sampled = false;
+          bool ok = (s.face == kFront);
+          if (ok) {
+            float u0 = draw(rng);
+            float u1 = draw(rng);
+            V3 tmp;
+            float pdf;
+            lambert_sample(u0, u1, tmp, pdf);
+            tmp = -tmp;
+            V3 gdir = to_global(fr, tmp);
+            ok = !(dot(-s.n_g, gdir) <= 0.0f);
+            if (ok) {
+              V3 sigt, sigs;
+              scattering_from_albedo(b.subsurface_albedo.x, b.subsurface_radius.x, sigt.x, sigs.x);
+              scattering_from_albedo(b.subsurface_albedo.y, b.subsurface_radius.y, sigt.y, sigs.y);
+              scattering_from_albedo(b.subsurface_albedo.z, b.subsurface_radius.z, sigt.z, sigs.z);
+              V3 wthr = safe_divide_spectrum(b.subsurface_weight, b.subsurface_albedo);
+              float e0 = draw(rng);
+              float e1 = draw(rng);
+              V3 chpdf;
+              float t_scatter = sample_scatter_distance(wthr, sigs, sigt, e0, e1, chpdf);
+              P.ray_o[p] = mk4(s.pos, 1e-3f);
+              P.ray_d[p] = mk4(gdir, t_scatter);
+              P.sss_sigt[p] = mk4(sigt, __uint_as_float(0u));                      // .w = bounce index
+              P.sss_sigs[p] = mk4(sigs, __uint_as_float(sc.slot_ids[h.slot].x));   // .w = entry instance id
+              P.sss_thr[p] = mk4(wthr, 0.f);
+              P.sss_pdf[p] = mk4(chpdf, 0.f);
+              P.sss_ez[p] = mk4(fr.ez, 0.f);
+              P.sss_A[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+              P.flags[p] = P.flags[p] | kFlagSss;
+              P.rng[p] = rng.state;
+              alive = true;
+              sh_mode = kShSssEntry;
+              c_vis = d1;  // raw: resolved into A by k_trace_shadow
+            }
+          }
+          // failed entry: omega_in = f = pdf = 0 -> 0*0/0 = NaN -> throughput 0 (:217-220, :474-483)
+        }
+        if (sampled) {
+          V3 f;
+          float pdf;
+          eval_bsdf(wi, wo, b, w, f, pdf);
+          next_dir = to_global(fr, wi);
+          float cos_i = fabsf(wi.z);
+          new_thr = f * cos_i / pdf;
+          new_pdf = pdf;
+          if (!is_finite(new_thr) || !isfinite(new_pdf)) {
+            new_thr = V3(0.f);
+            new_pdf = 0.f;
+          }
+        }
+        if (sh_mode == kShNormal) c_vis = thr * ((V3(0.f) + d1) + V3(0.f));  // render.cc:79
+        if (!alive) {
+          // render.cc:80-86
+          V3 t2 = new_thr * thr;
+          if (!is_black(t2)) {
+            alive = true;
+            P.ray_o[p] = mk4(s.pos, 1e-3f);
+            P.ray_d[p] = mk4(next_dir, kInf);
+            P.thr[p] = mk4(t2, new_pdf);
+            P.rng[p] = rng.state;
+          }
+        }
+      }
+    }
+    uint32_t k = queue_append(&P.counts[kCntShadow], shadow);
+    if (shadow) put_shadow(P, k, sh_pos, nee, c_vis, V3(0.f), p, sh_mode);
+    k = queue_append(&P.counts[kCntOut], alive);
+    if (alive) P.q_out[k] = p;
+  }
+}
+
+// ------------------------------------------------------------------ k_shade_hair (hair-shader.cc:153-229)
+__global__ __launch_bounds__(kBlock) void k_shade_hair(PathState P, DScene sc, uint64_t rng_inc) {
+  const uint32_t n = P.counts[kCntHair];
+  const uint32_t n_round = (n + kBlock - 1) / kBlock * kBlock;
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_round; i += gridDim.x * kBlock) {
+    bool active = i < n;
+    uint32_t p = active ? P.q_hair[i] : 0u;
+    bool alive = false, shadow = false;
+    V3 sh_pos(0.f), c_vis(0.f);
+    Nee nee;
+    nee.dir = V3(0.f), nee.emission = V3(0.f), nee.dist = 0.f, nee.pdf_sigma = 0.f;
+    if (active) {
+      float4 h4 = P.hit[p], o4 = P.ray_o[p], d4 = P.ray_d[p], t4 = P.thr[p];
+      Hit h = {h4.x, h4.y, h4.z, __float_as_uint(h4.w)};
+      V3 dir = ld3(d4);
+      Surface s = make_surface(sc, ld3(o4), dir, h);
+      V3 thr = ld3(t4);
+      Rng rng = {P.rng[p], rng_inc};
+      if (s.face != kAmbiguous) {
+        V3 wo_g = -dir;
+        Frame fr;
+        fr.ex = s.n_s;  // curve tangent
+        fr.ey = vnormalize(cross(cross(wo_g, fr.ex), fr.ex));
+        fr.ez = cross(fr.ex, fr.ey);
+        V3 wo = to_local(fr, wo_g);
+        HairBsdf hb = sc.materials[s.material].hair;
+        hb.h = h.v;  // :183 (Q12)
+        HairSetup S;
+        hair_prepare(wo, hb, S);
+        V3 d1(0.f);
+        shadow = nee_sample(sc, rng, s.pos, fr.ex, false, nee);
+        if (shadow) {
+          V3 wl = to_local(fr, nee.dir);
+          float pdf;
+          V3 fcos = hair_eval(S, wl, hb, pdf);
+          d1 = nee_contribution(nee, fcos / fabsf(wl.x), pdf);
+          sh_pos = s.pos;
+        }
+        float us[4];
+        us[0] = draw(rng), us[1] = draw(rng), us[2] = draw(rng), us[3] = draw(rng);
+        V3 wi(0.f);
+        float pdf = 0.f;
+        V3 fcos = hair_sample(S, hb, us, wi, pdf);
+        V3 next_dir = to_global(fr, wi);
+        V3 new_thr = fcos / pdf;
+        if (!is_finite(new_thr) || !isfinite(pdf)) {
+          new_thr = V3(0.f);
+          pdf = 0.f;
+        }
+        c_vis = thr * ((V3(0.f) + d1) + V3(0.f));
+        V3 t2 = new_thr * thr;
+        if (!is_black(t2)) {
+          alive = true;
+          P.ray_o[p] = mk4(s.pos, 1e-3f);
+          P.ray_d[p] = mk4(next_dir, kInf);
+          P.thr[p] = mk4(t2, pdf);
+          P.rng[p] = rng.state;
+        }
+      }
+    }
+    uint32_t k = queue_append(&P.counts[kCntShadow], shadow);
+    if (shadow) put_shadow(P, k, sh_pos, nee, c_vis, V3(0.f), p, kShNormal);
+    k = queue_append(&P.counts[kCntOut], alive);
+    if (alive) P.q_out[k] = p;
+  }
+}
+
+// ------------------------------------------------------------------ k_sss_step
+// One iteration of RandomWalkSubsurface's loop after its TraceFirstHit1 (random-walk-sss.h:314-405),
+// then either the next step's direction/distance sampling (:287-311) or the exit: second NEE + diffuse
+// re-sample (cycles-principled-shader.cc:197-216) and the tail of CyclesPrincipledShader (:467-483).
+__global__ __launch_bounds__(kBlock) void k_sss_step(PathState P, DScene sc, uint64_t rng_inc) {
+  const uint32_t n = P.counts[kCntSss];
+  const uint32_t n_round = (n + kBlock - 1) / kBlock * kBlock;
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_round; i += gridDim.x * kBlock) {
+    bool active = i < n;
+    uint32_t p = active ? P.q_sss[i] : 0u;
+    bool alive = false, shadow = false;
+    V3 sh_pos(0.f), c_vis(0.f), c_occ(0.f);
+    Nee nee;
+    nee.dir = V3(0.f), nee.emission = V3(0.f), nee.dist = 0.f, nee.pdf_sigma = 0.f;
+    if (active) {
+      float4 h4 = P.hit[p], o4 = P.ray_o[p], d4 = P.ray_d[p];
+      float4 st4 = P.sss_sigt[p], ss4 = P.sss_sigs[p], wt4 = P.sss_thr[p], cp4 = P.sss_pdf[p];
+      Hit h = {h4.x, h4.y, h4.z, __float_as_uint(h4.w)};
+      V3 org = ld3(o4), dir = ld3(d4), sigt = ld3(st4), sigs = ld3(ss4), wthr = ld3(wt4), chpdf = ld3(cp4);
+      uint32_t bounce = __float_as_uint(st4.w), entry_inst = __float_as_uint(ss4.w);
+      Rng rng = {P.rng[p], rng_inc};
+      bool hit = (h.slot != kNone);
+      float t = hit ? h.t : d4.w;  // d4.w = t_scatter
+      V3 trans = attenuate_transmission(sigt, t);
+      bool fail = false, exited = false;
+      if (hit) {
+        float pdf = dot(chpdf, trans);
+        wthr = wthr * trans / pdf;
+        exited = true;
+      } else {
+        float pdf = dot(chpdf, sigt * trans);
+        wthr = wthr * (sigs * trans) / pdf;
+        float pr = saturate(spectrum_norm(wthr));
+        float q = draw(rng);
+        if (q >= pr) {
+          fail = true;
+        } else {
+          wthr = wthr / pr;
+          org = org + t * dir;
+          bounce++;
+          if (bounce > 8192u) fail = true;  // loop bound :287
+        }
+      }
+      V3 thr = ld3(P.thr[p]);
+      V3 A = ld3(P.sss_A[p]);
+      if (!fail && !exited) {
+        // next step: isotropic direction; g++ evaluates UniformSampleSphere(Draw(), Draw()) right-to-left,
+        // so the FIRST draw is u2 (:296)
+        float first = draw(rng);
+        float second = draw(rng);
+        V3 wi = vnormalize(uniform_sample_sphere(second, first));
+        float e0 = draw(rng);
+        float e1 = draw(rng);
+        float t_scatter = sample_scatter_distance(wthr, sigs, sigt, e0, e1, chpdf);
+        P.ray_o[p] = mk4(org, 0.f);
+        P.ray_d[p] = mk4(wi, t_scatter);
+        P.sss_sigt[p] = mk4(sigt, __uint_as_float(bounce));
+        P.sss_thr[p] = mk4(wthr, 0.f);
+        P.sss_pdf[p] = mk4(chpdf, 0.f);
+        P.rng[p] = rng.state;
+        alive = true;
+      } else if (exited) {
+        Surface s = make_surface(sc, org, dir, h);  // :369
+        if (sc.slot_ids[h.slot].x != entry_inst) fail = true;  // :372 (Q6)
+        if (s.face != kBack) fail = true;                      // :376
+        if (!fail) {
+          Frame fx;  // exit frame :382-394
+          fx.ez = s.n_s;
+          branchless_onb(fx.ez, fx.ex, fx.ey);
+          V3 wo = to_local(fx, dir);
+          PrincipledBsdf nb = default_bsdf();  // cycles-principled-shader.cc:198-200
+          nb.enable_diffuse = 1;
+          nb.diffuse_weight = wthr;
+          SampleWeight w = closure_sample_weight(wo, nb);
+          V3 d2(0.f);
+          shadow = nee_sample(sc, rng, s.pos, s.n_s, true, nee);  // :202-212 (Q5)
+          if (shadow) {
+            V3 f;
+            float pdf;
+            eval_bsdf(to_local(fx, nee.dir), wo, nb, w, f, pdf);
+            d2 = nee_contribution(nee, f, pdf);
+            sh_pos = s.pos;
+          }
+          float select = draw(rng);
+          int pick = pick_closure(select, w);
+          V3 wi(0.f);
+          float u0 = draw(rng);
+          float u1 = draw(rng);
+          if (pick == 0) {
+            float pdf;
+            lambert_sample(u0, u1, wi, pdf);
+          } else {
+            // diffuse weight 0 (NaN -> 0) falls through to the clearcoat branch with alpha (1,1) (Q7)
+            ggx_sample(wo, nb.clearcoat_alpha_x, nb.clearcoat_alpha_y, u0, u1, wi);
+          }
+          V3 f;
+          float pdf;
+          eval_bsdf(wi, wo, nb, w, f, pdf);
+          // local -> global with the ENTRY frame (cycles-principled-shader.cc:467-469)
+          Frame fe;
+          fe.ez = ld3(P.sss_ez[p]);
+          branchless_onb(fe.ez, fe.ex, fe.ey);
+          V3 next_dir = to_global(fe, wi);
+          V3 new_thr = f * fabsf(wi.z) / pdf;
+          if (!is_finite(new_thr) || !isfinite(pdf)) {
+            new_thr = V3(0.f);
+            pdf = 0.f;
+          }
+          c_vis = thr * (A + d2);
+          c_occ = thr * (A + V3(0.f));
+          if (!shadow) {
+            float4 L4 = P.L[p];
+            P.L[p] = mk4(ld3(L4) + c_occ, L4.w);
+          }
+          V3 t2 = new_thr * thr;
+          P.flags[p] = P.flags[p] & ~kFlagSss;
+          if (!is_black(t2)) {
+            alive = true;
+            P.ray_o[p] = mk4(s.pos, 1e-3f);
+            P.ray_d[p] = mk4(next_dir, kInf);
+            P.thr[p] = mk4(t2, pdf);
+            P.rng[p] = rng.state;
+          }
+        }
+      }
+      if (fail) {
+        // walk failed: path ends, the first NEE's contribution still counts (render.cc:79)
+        float4 L4 = P.L[p];
+        P.L[p] = mk4(ld3(L4) + thr * (A + V3(0.f)), L4.w);
+        P.flags[p] = P.flags[p] & ~kFlagSss;
+      }
+    }
+    uint32_t k = queue_append(&P.counts[kCntShadow], shadow);
+    if (shadow) put_shadow(P, k, sh_pos, nee, c_vis, c_occ, p, kShSssExit);
+    k = queue_append(&P.counts[kCntOut], alive);
+    if (alive) P.q_out[k] = p;
+  }
+}
+
+// ------------------------------------------------------------------ k_accumulate (render.cc:175-183, Q13)
+// One thread per pixel of this rank's tiles; passes of the chunk are added in ascending order.
+__global__ __launch_bounds__(kBlock) void k_accumulate(PathState P, const uint32_t* __restrict__ pix_index, uint32_t npix,
+                                                       uint32_t npass, float* __restrict__ rgba,
+                                                       uint32_t* __restrict__ count) {
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < npix; i += gridDim.x * kBlock) {
+    uint32_t g = pix_index[i];
+    float4 acc = reinterpret_cast<float4*>(rgba)[g];
+    uint32_t c = count[g];
+    for (uint32_t k = 0; k < npass; k++) {
+      float4 L = P.L[(size_t)k * npix + i];
+      acc.x += L.x, acc.y += L.y, acc.z += L.z, acc.w += 1.0f;
+      c++;
+    }
+    reinterpret_cast<float4*>(rgba)[g] = acc;
+    count[g] = c;
+  }
+}
+
+// ------------------------------------------------------------------ test hooks: Raytracer::FirstHitTrace1 / AnyHit1
+__global__ __launch_bounds__(kBlock) void k_hook_closest(DScene sc, const float4* __restrict__ rays, uint32_t n,
+                                                         HookHit* __restrict__ out, uint32_t* overflow_flag) {
+  __shared__ uint32_t stk[kStackDepth * kBlock];
+  TravStats st = {0u, 0u, 0u};
+  uint32_t overflow = 0u;
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    float4 o4 = rays[2 * i], d4 = rays[2 * i + 1];
+    Hit h;
+    traverse<false, false>(sc, ld3(o4), ld3(d4), o4.w, fminf(d4.w, INFINITY), h, stk + threadIdx.x, kBlock, st, &overflow);
+    HookHit r;  // TraceResult defaults (raytracer.h:9-17)
+    r.ng[0] = 1.f, r.ng[1] = 0.f, r.ng[2] = 0.f, r.t = 1.f, r.u = 0.f, r.v = 0.f;
+    r.instance_id = r.geom_id = r.prim_id = kNone;
+    if (h.slot != kNone) {
+      Surface s = make_surface(sc, ld3(o4), ld3(d4), h);
+      uint4 ids = sc.slot_ids[h.slot];
+      r.ng[0] = s.n_g.x, r.ng[1] = s.n_g.y, r.ng[2] = s.n_g.z;
+      r.t = h.t, r.u = h.u, r.v = h.v;
+      r.instance_id = ids.x, r.geom_id = ids.y, r.prim_id = ids.z;
+    }
+    out[i] = r;
+  }
+  if (overflow) *overflow_flag = 1u;
+}
+__global__ __launch_bounds__(kBlock) void k_hook_any(DScene sc, const float4* __restrict__ rays, uint32_t n,
+                                                     uint8_t* __restrict__ out, uint32_t* overflow_flag) {
+  __shared__ uint32_t stk[kStackDepth * kBlock];
+  TravStats st = {0u, 0u, 0u};
+  uint32_t overflow = 0u;
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    float4 o4 = rays[2 * i], d4 = rays[2 * i + 1];
+    Hit h;
+    out[i] = traverse<true, false>(sc, ld3(o4), ld3(d4), o4.w, fminf(d4.w, INFINITY), h, stk + threadIdx.x, kBlock, st,
+                                   &overflow)
+                 ? 1
+                 : 0;
+  }
+  if (overflow) *overflow_flag = 1u;
+}
+
+// queue flip between iterations: counts[In] = counts[Out]; the per-iteration counters restart at 0
+__global__ void k_advance(uint32_t* counts) {
+  if (threadIdx.x == 0) {
+    counts[kCntIn] = counts[kCntOut];
+    counts[kCntOut] = 0, counts[kCntPrincipled] = 0, counts[kCntHair] = 0, counts[kCntSss] = 0, counts[kCntShadow] = 0;
+  }
+}
+
+// ------------------------------------------------------------------ launchers
+static inline uint32_t grid_for(uint32_t n, uint32_t cap) {
+  uint32_t g = (n + kBlock - 1) / kBlock;
+  if (g < 1) g = 1;
+  return g < cap ? g : cap;
+}
+
+void launch_generate(hipStream_t s, const PathState& P, const Camera& cam, const uint32_t* pix_index, uint32_t npix,
+                     uint32_t npaths, uint32_t width, uint32_t first_pass, uint64_t seed_seq) {
+  hipLaunchKernelGGL(k_generate, dim3(grid_for(npaths, 8192)), dim3(kBlock), 0, s, P, cam, pix_index, npix, npaths, width,
+                     first_pass, seed_seq);
+}
+void launch_trace_closest(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, bool stats) {
+  dim3 g(grid_for(n_upper, kTraceGridCap));
+  if (stats)
+    hipLaunchKernelGGL(k_trace_closest<true>, g, dim3(kBlock), 0, s, P, sc, (uint32_t)kCntIn);
+  else
+    hipLaunchKernelGGL(k_trace_closest<false>, g, dim3(kBlock), 0, s, P, sc, (uint32_t)kCntIn);
+}
+void launch_trace_shadow(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, bool stats) {
+  dim3 g(grid_for(n_upper, kTraceGridCap));
+  if (stats)
+    hipLaunchKernelGGL(k_trace_shadow<true>, g, dim3(kBlock), 0, s, P, sc);
+  else
+    hipLaunchKernelGGL(k_trace_shadow<false>, g, dim3(kBlock), 0, s, P, sc);
+}
+void launch_surface(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc) {
+  hipLaunchKernelGGL(k_surface, dim3(grid_for(n_upper, kShadeGridCap)), dim3(kBlock), 0, s, P, sc, rng_inc);
+}
+void launch_shade_principled(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc) {
+  hipLaunchKernelGGL(k_shade_principled, dim3(grid_for(n_upper, kShadeGridCap)), dim3(kBlock), 0, s, P, sc, rng_inc);
+}
+void launch_shade_hair(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc) {
+  hipLaunchKernelGGL(k_shade_hair, dim3(grid_for(n_upper, kShadeGridCap)), dim3(kBlock), 0, s, P, sc, rng_inc);
+}
+void launch_sss_step(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc) {
+  hipLaunchKernelGGL(k_sss_step, dim3(grid_for(n_upper, kShadeGridCap)), dim3(kBlock), 0, s, P, sc, rng_inc);
+}
+void launch_accumulate(hipStream_t s, const PathState& P, const uint32_t* pix_index, uint32_t npix, uint32_t npass,
+                       float* rgba, uint32_t* count) {
+  hipLaunchKernelGGL(k_accumulate, dim3(grid_for(npix, 8192)), dim3(kBlock), 0, s, P, pix_index, npix, npass, rgba, count);
+}
+void launch_advance(hipStream_t s, const PathState& P) { hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, s, P.counts); }
+void launch_hook_closest(hipStream_t s, const DScene& sc, const float4* rays, uint32_t n, HookHit* out, uint32_t* flag) {
+  hipLaunchKernelGGL(k_hook_closest, dim3(grid_for(n, kTraceGridCap)), dim3(kBlock), 0, s, sc, rays, n, out, flag);
+}
+void launch_hook_any(hipStream_t s, const DScene& sc, const float4* rays, uint32_t n, uint8_t* out, uint32_t* flag) {
+  hipLaunchKernelGGL(k_hook_any, dim3(grid_for(n, kTraceGridCap)), dim3(kBlock), 0, s, sc, rays, n, out, flag);
+}
+
+}  // namespace pb

@@ -1,0 +1,881 @@
+// pbrhip.cpp -- C ABI (include/pbrhip.h): host scene store, commit (light tables, BVH, upload) and the
+// wavefront render loop that drives kernels.hip.  Host C++ only; device code lives in kernels.hip.
+#include "../../include/pbrhip.h"
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+#include <memory>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "host_scene.h"
+#include "kernels.h"
+
+using namespace pb;
+
+static_assert(sizeof(pbrhip_principled_param) == sizeof(PrincipledParam), "param layout");
+static_assert(sizeof(pbrhip_hair_param) == sizeof(HairParam), "param layout");
+static_assert(sizeof(pbrhip_hit) == sizeof(HookHit), "hit layout");
+static_assert(sizeof(pbrhip_ray) == 32, "ray layout");
+static_assert(sizeof(LightRec) == 80, "light record layout");
+
+// ------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+static int g_device = 0;
+
+static int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIPCHK(expr)                                                                                      \
+  do {                                                                                                    \
+    hipError_t e_ = (expr);                                                                               \
+    if (e_ != hipSuccess) return fail(PBRHIP_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                                      __FILE__, __LINE__);                                                \
+  } while (0)
+
+extern "C" const char* pbrhip_last_error(void) { return g_err.c_str(); }
+
+extern "C" int pbrhip_device_count(int* count) {
+  if (!count) return fail(PBRHIP_EINVAL, "count is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(PBRHIP_ENODEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  }
+  *count = n;
+  return PBRHIP_OK;
+}
+extern "C" int pbrhip_set_device(int device) {
+  int n = 0;
+  int rc = pbrhip_device_count(&n);
+  if (rc) return rc;
+  if (device < 0 || device >= n) return fail(PBRHIP_EINVAL, "device %d out of range (%d devices)", device, n);
+  g_device = device;
+  return PBRHIP_OK;
+}
+
+// ------------------------------------------------------------------ device buffers
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr, n = 0;
+  }
+  hipError_t reserve(size_t count) {
+    if (count <= n) return hipSuccess;
+    release();
+    hipError_t e = hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T));
+    if (e == hipSuccess) n = count;
+    return e;
+  }
+  hipError_t upload(const std::vector<T>& h, hipStream_t s) {
+    hipError_t e = reserve(h.size());
+    if (e != hipSuccess || h.empty()) return e;
+    return hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s);
+  }
+};
+
+struct pbrhip_scene {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  // host model
+  std::vector<HostMesh> meshes;
+  std::vector<std::vector<uint32_t>> locals;
+  std::vector<HostInstance> instances;
+  std::vector<HostMaterial> materials;
+  std::vector<V3> light_params;
+  std::vector<HostLight> lights;
+  std::vector<float> light_cdf;
+  bool committed = false;
+  float bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0};
+  uint32_t bvh_depth = 0;
+  // device scene
+  DevBuf<BvhNode> d_nodes;
+  DevBuf<float4> d_slots, d_nrm;
+  DevBuf<uint4> d_meta, d_ids;
+  DevBuf<Material> d_materials;
+  DevBuf<float> d_light_cdf, d_lprim_cdf;
+  DevBuf<LightHead> d_heads;
+  DevBuf<LightRec> d_lrecs;
+  DScene dscene;
+  // render working set (grown on demand, reused across calls)
+  DevBuf<float4> ray_o, ray_d, thr, L, hit, sss[6], sh[4];
+  DevBuf<uint64_t> rng;
+  DevBuf<uint32_t> flags, q[5], counts, pix_index;
+  DevBuf<unsigned long long> stats;
+  DevBuf<float> own_rgba;
+  DevBuf<uint32_t> own_count;
+  DevBuf<float4> hook_rays;
+  DevBuf<HookHit> hook_hits;
+  DevBuf<uint8_t> hook_occ;
+  uint32_t* h_counts = nullptr;  // pinned
+  // pixel list cache key
+  uint32_t pk_w = 0, pk_h = 0, pk_rank = 0, pk_world = 0, pk_npix = 0;
+  std::vector<hipEvent_t> events;
+
+  size_t device_bytes() const {
+    return d_nodes.n * sizeof(BvhNode) + d_slots.n * 16 + d_nrm.n * 16 + d_meta.n * 16 + d_ids.n * 16 +
+           d_materials.n * sizeof(Material) + d_lrecs.n * sizeof(LightRec);
+  }
+};
+
+// ------------------------------------------------------------------ scene construction
+extern "C" int pbrhip_scene_create(pbrhip_scene** out) {
+  if (!out) return fail(PBRHIP_EINVAL, "out is NULL");
+  int n = 0;
+  int rc = pbrhip_device_count(&n);
+  if (rc) return rc;
+  if (n <= 0) return fail(PBRHIP_ENODEVICE, "no HIP device available: libpbrhip has no CPU fallback");
+  HIPCHK(hipSetDevice(g_device));
+  std::unique_ptr<pbrhip_scene> s(new pbrhip_scene());
+  s->device = g_device;
+  HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  HIPCHK(hipHostMalloc((void**)&s->h_counts, sizeof(uint32_t) * kCntNum, hipHostMallocDefault));
+  memset(&s->dscene, 0, sizeof(s->dscene));
+  *out = s.release();
+  return PBRHIP_OK;
+}
+
+extern "C" int pbrhip_scene_destroy(pbrhip_scene* s) {
+  if (!s) return PBRHIP_OK;
+  (void)hipSetDevice(s->device);
+  if (s->stream) (void)hipStreamSynchronize(s->stream);
+  for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
+  if (s->h_counts) (void)hipHostFree(s->h_counts);
+  hipStream_t st = s->stream;
+  delete s;
+  if (st) (void)hipStreamDestroy(st);
+  return PBRHIP_OK;
+}
+
+extern "C" int pbrhip_scene_add_triangle_mesh(pbrhip_scene* s, const float* vertices_xyzw, uint32_t num_vertices,
+                                              const float* normals_xyzw, uint32_t num_normals,
+                                              const float* texcoords_uv, uint32_t num_texcoords,
+                                              const uint32_t* vertex_ids, const uint32_t* normal_ids,
+                                              const uint32_t* texcoord_ids, const uint32_t* material_ids,
+                                              uint32_t num_faces, uint32_t* mesh_id) {
+  if (!s || !mesh_id || (!vertices_xyzw && num_vertices) || (!vertex_ids && num_faces))
+    return fail(PBRHIP_EINVAL, "add_triangle_mesh: NULL argument");
+  if (s->committed) return fail(PBRHIP_ESTATE, "scene already committed");
+  for (size_t i = 0; i < (size_t)num_faces * 3; i++)
+    if (vertex_ids[i] >= num_vertices) return fail(PBRHIP_EINVAL, "vertex id %u out of range", vertex_ids[i]);
+  if (normal_ids)
+    for (size_t i = 0; i < (size_t)num_faces * 3; i++)
+      if (normal_ids[i] != kNone && normal_ids[i] >= num_normals)
+        return fail(PBRHIP_EINVAL, "normal id %u out of range", normal_ids[i]);
+  HostMesh m;
+  m.kind = 0;
+  m.nfaces = num_faces;
+  m.vertices.assign(vertices_xyzw, vertices_xyzw + (size_t)num_vertices * 4);
+  if (num_normals) m.normals.assign(normals_xyzw, normals_xyzw + (size_t)num_normals * 4);
+  if (num_texcoords) m.texcoords.assign(texcoords_uv, texcoords_uv + (size_t)num_texcoords * 2);
+  m.vid.assign(vertex_ids, vertex_ids + (size_t)num_faces * 3);
+  // mesh/triangle-mesh.cc:33-55: missing id arrays become all -1
+  if (normal_ids) m.nid.assign(normal_ids, normal_ids + (size_t)num_faces * 3);
+  else m.nid.assign((size_t)num_faces * 3, kNone);
+  if (texcoord_ids) m.tid.assign(texcoord_ids, texcoord_ids + (size_t)num_faces * 3);
+  else m.tid.assign((size_t)num_faces * 3, kNone);
+  if (material_ids) m.mat.assign(material_ids, material_ids + num_faces);
+  else m.mat.assign(num_faces, kNone);
+  *mesh_id = (uint32_t)s->meshes.size();
+  s->meshes.push_back(std::move(m));
+  return PBRHIP_OK;
+}
+
+extern "C" int pbrhip_scene_add_curve_mesh(pbrhip_scene* s, const float* vertices_xyzr, uint32_t num_vertices,
+                                           const uint32_t* indices, const uint32_t* material_ids,
+                                           uint32_t num_segments, uint32_t* mesh_id) {
+  if (!s || !mesh_id || (!vertices_xyzr && num_vertices) || (!indices && num_segments))
+    return fail(PBRHIP_EINVAL, "add_curve_mesh: NULL argument");
+  if (s->committed) return fail(PBRHIP_ESTATE, "scene already committed");
+  for (uint32_t i = 0; i < num_segments; i++)
+    if ((uint64_t)indices[i] + 4 > num_vertices) return fail(PBRHIP_EINVAL, "curve index %u out of range", indices[i]);
+  HostMesh m;
+  m.kind = 1;
+  m.cverts.assign(vertices_xyzr, vertices_xyzr + (size_t)num_vertices * 4);
+  m.cidx.assign(indices, indices + num_segments);
+  if (material_ids) m.cmat.assign(material_ids, material_ids + num_segments);
+  else m.cmat.assign(num_segments, kNone);
+  *mesh_id = (uint32_t)s->meshes.size();
+  s->meshes.push_back(std::move(m));
+  return PBRHIP_OK;
+}
+
+static int check_tex(const pbrhip_principled_param* p) {
+  if (p->base_color_tex_id != kNone || p->subsurface_color_tex_id != kNone)
+    return fail(PBRHIP_EUNSUPPORTED, "textured materials (map_base_color / map_subsurface_color) are not supported yet");
+  return PBRHIP_OK;
+}
+extern "C" int pbrhip_scene_add_principled_material(pbrhip_scene* s, const pbrhip_principled_param* p, uint32_t* id) {
+  if (!s || !p || !id) return fail(PBRHIP_EINVAL, "add_principled_material: NULL argument");
+  if (int rc = check_tex(p)) return rc;
+  HostMaterial m;
+  m.kind = kMatPrincipled;
+  memcpy(&m.pr, p, sizeof(m.pr));
+  memset(&m.hr, 0, sizeof(m.hr));
+  *id = (uint32_t)s->materials.size();
+  s->materials.push_back(m);
+  return PBRHIP_OK;
+}
+extern "C" int pbrhip_scene_add_hair_material(pbrhip_scene* s, const pbrhip_hair_param* p, uint32_t* id) {
+  if (!s || !p || !id) return fail(PBRHIP_EINVAL, "add_hair_material: NULL argument");
+  HostMaterial m;
+  m.kind = kMatHair;
+  memset(&m.pr, 0, sizeof(m.pr));
+  memcpy(&m.hr, p, sizeof(m.hr));
+  *id = (uint32_t)s->materials.size();
+  s->materials.push_back(m);
+  return PBRHIP_OK;
+}
+extern "C" int pbrhip_scene_add_area_light(pbrhip_scene* s, const float emission[3], uint32_t* id) {
+  if (!s || !emission || !id) return fail(PBRHIP_EINVAL, "add_area_light: NULL argument");
+  *id = (uint32_t)s->light_params.size();
+  s->light_params.push_back(V3(emission[0], emission[1], emission[2]));
+  return PBRHIP_OK;
+}
+extern "C" int pbrhip_scene_create_local_scene(pbrhip_scene* s, uint32_t* id) {
+  if (!s || !id) return fail(PBRHIP_EINVAL, "create_local_scene: NULL argument");
+  *id = (uint32_t)s->locals.size();
+  s->locals.emplace_back();
+  return PBRHIP_OK;
+}
+extern "C" int pbrhip_scene_add_mesh_to_local_scene(pbrhip_scene* s, uint32_t local_scene_id, uint32_t mesh_id,
+                                                    uint32_t* geom_id) {
+  if (!s || !geom_id) return fail(PBRHIP_EINVAL, "add_mesh_to_local_scene: NULL argument");
+  if (local_scene_id >= s->locals.size() || mesh_id >= s->meshes.size())
+    return fail(PBRHIP_EINVAL, "local scene %u / mesh %u out of range", local_scene_id, mesh_id);
+  *geom_id = (uint32_t)s->locals[local_scene_id].size();
+  s->locals[local_scene_id].push_back(mesh_id);
+  return PBRHIP_OK;
+}
+extern "C" int pbrhip_scene_create_instance(pbrhip_scene* s, uint32_t local_scene_id, const float* transform,
+                                            uint32_t* instance_id) {
+  if (!s || !instance_id) return fail(PBRHIP_EINVAL, "create_instance: NULL argument");
+  if (local_scene_id >= s->locals.size()) return fail(PBRHIP_EINVAL, "local scene %u out of range", local_scene_id);
+  static const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  HostInstance in;
+  in.local_scene = local_scene_id;
+  memcpy(in.xf, transform ? transform : ident, sizeof(ident));
+  if (memcmp(in.xf, ident, sizeof(ident)) != 0)
+    return fail(PBRHIP_EUNSUPPORTED, "instance transforms other than the identity are not supported yet");
+  // scene.cc:119-143: material ids are copied from the meshes when the instance is created
+  for (uint32_t mid : s->locals[local_scene_id]) {
+    const HostMesh& m = s->meshes[mid];
+    in.material_ids.push_back(m.kind == 0 ? m.mat : m.cmat);
+    in.light_ids.emplace_back();
+  }
+  *instance_id = (uint32_t)s->instances.size();
+  s->instances.push_back(std::move(in));
+  return PBRHIP_OK;
+}
+static const HostMesh* inst_mesh(const pbrhip_scene* s, uint32_t instance_id, uint32_t geom_id) {
+  const HostInstance& in = s->instances[instance_id];
+  return &s->meshes[s->locals[in.local_scene][geom_id]];
+}
+extern "C" int pbrhip_scene_attach_light_ids(pbrhip_scene* s, uint32_t instance_id, uint32_t geom_id,
+                                             const uint32_t* ids, uint32_t n) {
+  if (!s || (!ids && n)) return fail(PBRHIP_EINVAL, "attach_light_ids: NULL argument");
+  if (instance_id >= s->instances.size() || geom_id >= s->instances[instance_id].light_ids.size())
+    return fail(PBRHIP_EINVAL, "instance %u / geom %u out of range", instance_id, geom_id);
+  if (n != 0 && n != inst_mesh(s, instance_id, geom_id)->num_prims()) return fail(PBRHIP_ESIZE, "light param error");
+  for (uint32_t i = 0; i < n; i++)
+    if (ids[i] != kNone && ids[i] >= s->light_params.size()) return fail(PBRHIP_EINVAL, "light id %u out of range", ids[i]);
+  s->instances[instance_id].light_ids[geom_id].assign(ids, ids + n);
+  return PBRHIP_OK;
+}
+extern "C" int pbrhip_scene_attach_material_ids(pbrhip_scene* s, uint32_t instance_id, uint32_t geom_id,
+                                                const uint32_t* ids, uint32_t n) {
+  if (!s || (!ids && n)) return fail(PBRHIP_EINVAL, "attach_material_ids: NULL argument");
+  if (instance_id >= s->instances.size() || geom_id >= s->instances[instance_id].material_ids.size())
+    return fail(PBRHIP_EINVAL, "instance %u / geom %u out of range", instance_id, geom_id);
+  if (n != inst_mesh(s, instance_id, geom_id)->num_prims()) return fail(PBRHIP_ESIZE, "material param error");
+  s->instances[instance_id].material_ids[geom_id].assign(ids, ids + n);
+  return PBRHIP_OK;
+}
+
+// ------------------------------------------------------------------ commit
+static V3 mesh_vertex(const HostMesh& m, uint32_t prim, int k) {
+  const float* p = m.vertices.data() + (size_t)m.vid[prim * 3 + k] * 4;
+  return V3(p[0], p[1], p[2]);
+}
+// TriangleMesh::FetchFaceArea (mesh/triangle-mesh.cc:113-124)
+static float face_area(const HostMesh& m, uint32_t prim) {
+  V3 p0 = mesh_vertex(m, prim, 0), p1 = mesh_vertex(m, prim, 1), p2 = mesh_vertex(m, prim, 2);
+  return length(cross(p1 - p0, p2 - p0)) * 0.5f;
+}
+
+// LightManager::RegisterInstanceMesh (light-manager.cc:79-184)
+static void register_lights(pbrhip_scene* s, uint32_t instance_id) {
+  HostInstance& in = s->instances[instance_id];
+  size_t ng = in.light_ids.size();
+  in.has_area_light.assign(ng, 0);
+  in.area_lights.assign(ng, HostAreaLight());
+  for (size_t g = 0; g < ng; g++) {
+    const std::vector<uint32_t>& ids = in.light_ids[g];
+    if (ids.empty()) continue;
+    const HostMesh& m = *inst_mesh(s, instance_id, (uint32_t)g);
+    if (m.kind != 0) continue;
+    uint32_t nf = m.nfaces;
+    bool have = false;
+    for (uint32_t f = 0; f < nf; f++) have = have || ids[f] != kNone;
+    if (!have) continue;
+    HostAreaLight& a = in.area_lights[g];
+    in.has_area_light[g] = 1;
+    a.light_param_ids = ids;
+    a.choose_prob.assign(nf, 0.f);
+    for (uint32_t f = 0; f < nf; f++) {
+      float intensity = 0.0f;
+      if (ids[f] != kNone) intensity = spectrum_norm(s->light_params[ids[f]]);
+      a.choose_prob[f] = intensity * face_area(m, f);
+    }
+    a.intensity_sum = std::accumulate(a.choose_prob.begin(), a.choose_prob.end(), 0.0f);
+    const float sum = a.intensity_sum;
+    for (float& v : a.choose_prob) v = v / sum;
+    a.cdf = a.choose_prob;
+    for (uint32_t f = 0; nf > 0 && f < nf - 1u; f++) a.cdf[f + 1u] += a.cdf[f];
+    a.area_pdf.assign(nf, 0.f);
+    for (uint32_t f = 0; f < nf; f++)
+      if (ids[f] != kNone) a.area_pdf[f] = 1.0f / face_area(m, f);
+  }
+}
+// LightManager::Commit (light-manager.cc:29-77)
+static void commit_lights(pbrhip_scene* s) {
+  s->lights.clear();
+  double intensity_sum = 0.0;
+  for (uint32_t i = 0; i < s->instances.size(); i++) {
+    HostInstance& in = s->instances[i];
+    for (uint32_t g = 0; g < in.area_lights.size(); g++) {
+      if (!in.has_area_light[g]) continue;
+      in.area_lights[g].global_id = (uint32_t)s->lights.size();
+      HostLight L;
+      L.choose_prob = in.area_lights[g].intensity_sum;
+      L.instance_id = i, L.geom_id = g;
+      intensity_sum += (double)L.choose_prob;
+      s->lights.push_back(L);
+    }
+  }
+  for (HostLight& L : s->lights) L.choose_prob = (float)((double)L.choose_prob / intensity_sum);
+  s->light_cdf.resize(s->lights.size());
+  for (size_t l = 0; l < s->lights.size(); l++) s->light_cdf[l] = s->lights[l].choose_prob;
+  for (size_t l = 0; !s->light_cdf.empty() && l < s->light_cdf.size() - 1u; l++) s->light_cdf[l + 1u] += s->light_cdf[l];
+}
+
+static Material make_material(const HostMaterial& hm) {
+  Material m;
+  memset(&m, 0, sizeof(m));
+  m.kind = hm.kind;
+  m.bsdf = default_bsdf();
+  if (hm.kind == kMatPrincipled) m.bsdf = param_to_bsdf(hm.pr);
+  else m.hair = hair_param_to_bsdf(hm.hr);
+  return m;
+}
+
+extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
+  if (!s) return fail(PBRHIP_EINVAL, "scene is NULL");
+  HIPCHK(hipSetDevice(s->device));
+  for (uint32_t i = 0; i < s->instances.size(); i++) register_lights(s, i);
+  commit_lights(s);
+
+  // flatten primitives in canonical (instance, geom, prim) order = gid
+  std::vector<PrimRef> prims;
+  for (uint32_t i = 0; i < s->instances.size(); i++)
+    for (uint32_t g = 0; g < s->instances[i].material_ids.size(); g++) {
+      const HostMesh& m = *inst_mesh(s, i, g);
+      if (s->instances[i].material_ids[g].size() != m.num_prims())
+        return fail(PBRHIP_ESIZE, "material param error (instance %u geom %u)", i, g);
+      for (uint32_t p = 0; p < m.num_prims(); p++) prims.push_back({i, g, p, (uint32_t)m.kind});
+    }
+  uint32_t np = (uint32_t)prims.size();
+  if (np >= (1u << 27)) return fail(PBRHIP_EUNSUPPORTED, "too many primitives (%u)", np);
+  std::vector<float> lo(3 * (size_t)np), hi(3 * (size_t)np);
+  std::vector<uint8_t> kinds(np);
+  const float inf = std::numeric_limits<float>::infinity();
+  float bmin[3] = {inf, inf, inf}, bmax[3] = {-inf, -inf, -inf};
+  for (uint32_t g = 0; g < np; g++) {
+    const PrimRef& pr = prims[g];
+    const HostMesh& m = *inst_mesh(s, pr.instance_id, pr.geom_id);
+    float l[3] = {inf, inf, inf}, h[3] = {-inf, -inf, -inf};
+    kinds[g] = (uint8_t)pr.kind;
+    if (pr.kind == 0) {
+      for (int c = 0; c < 3; c++) {
+        V3 v = mesh_vertex(m, pr.prim_id, c);
+        float a[3] = {v.x, v.y, v.z};
+        for (int k = 0; k < 3; k++) l[k] = std::min(l[k], a[k]), h[k] = std::max(h[k], a[k]);
+      }
+    } else {
+      // convex hull of the control points widened by the largest control radius
+      float r = 0.f;
+      for (int c = 0; c < 4; c++) {
+        const float* cp = m.cverts.data() + ((size_t)m.cidx[pr.prim_id] + c) * 4;
+        r = std::max(r, fabsf(cp[3]));
+        for (int k = 0; k < 3; k++) l[k] = std::min(l[k], cp[k]), h[k] = std::max(h[k], cp[k]);
+      }
+      for (int k = 0; k < 3; k++) l[k] -= r, h[k] += r;
+    }
+    for (int k = 0; k < 3; k++) {
+      lo[3 * g + k] = l[k], hi[3 * g + k] = h[k];
+      bmin[k] = std::min(bmin[k], l[k]), bmax[k] = std::max(bmax[k], h[k]);
+    }
+  }
+  memcpy(s->bmin, bmin, sizeof(bmin));
+  memcpy(s->bmax, bmax, sizeof(bmax));
+
+  FlatBvh bvh;
+  build_bvh(lo, hi, kinds, &bvh);
+  if (bvh.depth > (uint32_t)kStackDepth)
+    return fail(PBRHIP_EOVERFLOW, "BVH depth %u exceeds the traversal stack (%d)", bvh.depth, kStackDepth);
+  s->bvh_depth = bvh.depth;
+
+  // light records: one per (light, prim), concatenated
+  std::vector<LightHead> heads(s->lights.size());
+  std::vector<LightRec> lrecs;
+  std::vector<float> lprim_cdf;
+  for (size_t l = 0; l < s->lights.size(); l++) {
+    const HostLight& L = s->lights[l];
+    const HostAreaLight& a = s->instances[L.instance_id].area_lights[L.geom_id];
+    const HostMesh& m = *inst_mesh(s, L.instance_id, L.geom_id);
+    heads[l].first = (uint32_t)lrecs.size();
+    heads[l].count = m.nfaces;
+    for (uint32_t f = 0; f < m.nfaces; f++) {
+      LightRec r;
+      memset(&r, 0, sizeof(r));
+      V3 p0 = mesh_vertex(m, f, 0), p1 = mesh_vertex(m, f, 1), p2 = mesh_vertex(m, f, 2);
+      V3 n = vnormalize(cross(p1 - p0, p2 - p1));  // CalcGeometryNormal (triangle-mesh.cc:181-184)
+      r.p0[0] = p0.x, r.p0[1] = p0.y, r.p0[2] = p0.z;
+      r.p1[0] = p1.x, r.p1[1] = p1.y, r.p1[2] = p1.z;
+      r.p2[0] = p2.x, r.p2[1] = p2.y, r.p2[2] = p2.z;
+      r.normal[0] = n.x, r.normal[1] = n.y, r.normal[2] = n.z;
+      // light-manager.h:68-70,149-150: choose_light * choose_prim * prim_area_pdf, in that order
+      r.pdf = L.choose_prob * a.choose_prob[f] * a.area_pdf[f];
+      if (a.light_param_ids[f] != kNone) {
+        V3 e = s->light_params[a.light_param_ids[f]];
+        r.emission[0] = e.x, r.emission[1] = e.y, r.emission[2] = e.z;
+      }
+      lrecs.push_back(r);
+      lprim_cdf.push_back(a.cdf[f]);
+    }
+  }
+
+  // leaf-ordered slots
+  uint32_t ns = (uint32_t)bvh.slot_gid.size();
+  std::vector<float4> slots(4 * (size_t)ns), nrm(3 * (size_t)ns);
+  std::vector<uint4> meta(ns), ids(ns);
+  for (uint32_t k = 0; k < ns; k++) {
+    uint32_t g = bvh.slot_gid[k];
+    const PrimRef& pr = prims[g];
+    const HostInstance& in = s->instances[pr.instance_id];
+    const HostMesh& m = *inst_mesh(s, pr.instance_id, pr.geom_id);
+    uint32_t mat = in.material_ids[pr.geom_id][pr.prim_id];
+    if (mat != kNone && mat >= s->materials.size()) return fail(PBRHIP_EINVAL, "material id %u out of range", mat);
+    uint32_t flags = 0, lightrec = kNone;
+    float4* sl = &slots[4 * (size_t)k];
+    float4* nr = &nrm[3 * (size_t)k];
+    for (int c = 0; c < 4; c++) sl[c] = make_float4(0, 0, 0, 0);
+    for (int c = 0; c < 3; c++) nr[c] = make_float4(0, 0, 0, 0);
+    if (pr.kind == 0) {
+      for (int c = 0; c < 3; c++) {
+        V3 v = mesh_vertex(m, pr.prim_id, c);
+        sl[c] = make_float4(v.x, v.y, v.z, 0.f);
+      }
+      uint32_t a = m.nid[pr.prim_id * 3 + 0], b = m.nid[pr.prim_id * 3 + 1], c = m.nid[pr.prim_id * 3 + 2];
+      if (a != kNone && b != kNone && c != kNone) {  // triangle-mesh.cc:81-84
+        flags |= kSlotHasNormals;
+        const uint32_t idx[3] = {a, b, c};
+        for (int q = 0; q < 3; q++) {
+          const float* n = m.normals.data() + (size_t)idx[q] * 4;
+          nr[q] = make_float4(n[0], n[1], n[2], 0.f);
+        }
+      }
+      if (in.has_area_light[pr.geom_id]) {
+        const HostAreaLight& al = in.area_lights[pr.geom_id];
+        if (al.light_param_ids[pr.prim_id] != kNone) lightrec = heads[al.global_id].first + pr.prim_id;
+      }
+    } else {
+      flags |= kSlotIsCurve;
+      for (int c = 0; c < 4; c++) {
+        const float* cp = m.cverts.data() + ((size_t)m.cidx[pr.prim_id] + c) * 4;
+        sl[c] = make_float4(cp[0], cp[1], cp[2], cp[3]);
+      }
+    }
+    meta[k] = make_uint4(g, mat, lightrec, flags);
+    ids[k] = make_uint4(pr.instance_id, pr.geom_id, pr.prim_id, pr.kind);
+  }
+  std::vector<Material> mats(s->materials.size());
+  for (size_t i = 0; i < mats.size(); i++) mats[i] = make_material(s->materials[i]);
+
+  hipStream_t st = s->stream;
+  HIPCHK(s->d_nodes.upload(bvh.nodes, st));
+  HIPCHK(s->d_slots.upload(slots, st));
+  HIPCHK(s->d_nrm.upload(nrm, st));
+  HIPCHK(s->d_meta.upload(meta, st));
+  HIPCHK(s->d_ids.upload(ids, st));
+  HIPCHK(s->d_materials.upload(mats, st));
+  HIPCHK(s->d_light_cdf.upload(s->light_cdf, st));
+  HIPCHK(s->d_heads.upload(heads, st));
+  HIPCHK(s->d_lprim_cdf.upload(lprim_cdf, st));
+  HIPCHK(s->d_lrecs.upload(lrecs, st));
+  HIPCHK(hipStreamSynchronize(st));
+  DScene& d = s->dscene;
+  d.nodes = s->d_nodes.p, d.slots = s->d_slots.p, d.slot_meta = s->d_meta.p, d.slot_ids = s->d_ids.p;
+  d.slot_nrm = s->d_nrm.p, d.materials = s->d_materials.p, d.light_cdf = s->d_light_cdf.p;
+  d.light_heads = s->d_heads.p, d.lprim_cdf = s->d_lprim_cdf.p, d.lrecs = s->d_lrecs.p;
+  d.num_nodes = (uint32_t)bvh.nodes.size(), d.num_slots = ns, d.num_lights = (uint32_t)s->lights.size();
+  d.num_materials = (uint32_t)mats.size();
+  s->committed = true;
+  return PBRHIP_OK;
+}
+
+extern "C" int pbrhip_scene_aabb(const pbrhip_scene* s, float bmin[3], float bmax[3]) {
+  if (!s || !bmin || !bmax) return fail(PBRHIP_EINVAL, "scene_aabb: NULL argument");
+  if (!s->committed) return fail(PBRHIP_ESTATE, "scene not committed");
+  memcpy(bmin, s->bmin, 12), memcpy(bmax, s->bmax, 12);
+  return PBRHIP_OK;
+}
+extern "C" int pbrhip_scene_info(const pbrhip_scene* s, uint64_t* num_nodes, uint64_t* num_slots, uint32_t* depth,
+                                 uint64_t* device_bytes) {
+  if (!s) return fail(PBRHIP_EINVAL, "scene is NULL");
+  if (num_nodes) *num_nodes = s->dscene.num_nodes;
+  if (num_slots) *num_slots = s->dscene.num_slots;
+  if (depth) *depth = s->bvh_depth;
+  if (device_bytes) *device_bytes = s->device_bytes();
+  return PBRHIP_OK;
+}
+
+static int update_material(pbrhip_scene* s, uint32_t id, const HostMaterial& hm) {
+  if (id >= s->materials.size()) return fail(PBRHIP_EINVAL, "material id %u out of range", id);
+  if (s->materials[id].kind != hm.kind) return fail(PBRHIP_EINVAL, "material %u is of the other kind", id);
+  s->materials[id] = hm;
+  if (s->committed) {
+    HIPCHK(hipSetDevice(s->device));
+    Material m = make_material(hm);
+    HIPCHK(hipMemcpyAsync(s->d_materials.p + id, &m, sizeof(m), hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+  }
+  return PBRHIP_OK;
+}
+extern "C" int pbrhip_scene_update_principled_material(pbrhip_scene* s, uint32_t id, const pbrhip_principled_param* p) {
+  if (!s || !p) return fail(PBRHIP_EINVAL, "update_material: NULL argument");
+  if (int rc = check_tex(p)) return rc;
+  HostMaterial m;
+  m.kind = kMatPrincipled;
+  memcpy(&m.pr, p, sizeof(m.pr));
+  memset(&m.hr, 0, sizeof(m.hr));
+  return update_material(s, id, m);
+}
+extern "C" int pbrhip_scene_update_hair_material(pbrhip_scene* s, uint32_t id, const pbrhip_hair_param* p) {
+  if (!s || !p) return fail(PBRHIP_EINVAL, "update_material: NULL argument");
+  HostMaterial m;
+  m.kind = kMatHair;
+  memset(&m.pr, 0, sizeof(m.pr));
+  memcpy(&m.hr, p, sizeof(m.hr));
+  return update_material(s, id, m);
+}
+
+// ------------------------------------------------------------------ tiles (render-tile.cc:29-41)
+extern "C" int pbrhip_create_tiles(uint32_t width, uint32_t height, uint32_t* out, uint32_t* num_tiles) {
+  if (!num_tiles) return fail(PBRHIP_EINVAL, "num_tiles is NULL");
+  const uint32_t kTile = 64;
+  uint32_t n = 0;
+  for (uint32_t i = 0; i < height; i += kTile)
+    for (uint32_t j = 0; j < width; j += kTile) {
+      if (out) {
+        out[4 * n + 0] = j, out[4 * n + 1] = std::min(j + kTile, width);
+        out[4 * n + 2] = i, out[4 * n + 3] = std::min(i + kTile, height);
+      }
+      n++;
+    }
+  *num_tiles = n;
+  return PBRHIP_OK;
+}
+
+// camera of RenderingTile (render.cc:132-158)
+static Camera make_camera(const pbrhip_scene* s, uint32_t width, uint32_t height) {
+  const float *bmin = s->bmin, *bmax = s->bmax;
+  float hs, vs;
+  if (bmax[0] - bmin[0] > bmax[1] - bmin[1]) {
+    hs = bmax[0] - bmin[0];
+    vs = hs * float(height) / float(width);
+  } else {
+    vs = bmax[1] - bmin[1];
+    hs = vs * float(width) / float(height);
+  }
+  Camera c;
+  c.org[0] = (bmax[0] + bmin[0]) * 0.5f;
+  c.org[1] = (bmax[1] + bmin[1]) * 0.5f;
+  c.org[2] = bmax[2] + hs * 0.5f * sqrtf(3.f);
+  c.x_corner = (bmax[0] + bmin[0]) * 0.5f - hs * 0.5f;
+  c.y_corner = (bmax[1] + bmin[1]) * 0.5f + vs * 0.5f;
+  c.z_corner = bmax[2];
+  c.dx = hs / float(width);
+  c.dy = vs / float(height);
+  return c;
+}
+
+// ------------------------------------------------------------------ render
+namespace {
+struct Timer {
+  pbrhip_scene* s;
+  bool on;
+  size_t used = 0;
+  struct Rec {
+    size_t ev;
+    double* acc;
+  };
+  std::vector<Rec> recs;
+  hipError_t begin(double* acc) {
+    if (!on) return hipSuccess;
+    while (s->events.size() < used + 2) {
+      hipEvent_t e;
+      hipError_t rc = hipEventCreate(&e);
+      if (rc != hipSuccess) return rc;
+      s->events.push_back(e);
+    }
+    recs.push_back({used, acc});
+    return hipEventRecord(s->events[used], s->stream);
+  }
+  hipError_t end() {
+    if (!on) return hipSuccess;
+    hipError_t rc = hipEventRecord(s->events[used + 1], s->stream);
+    used += 2;
+    return rc;
+  }
+  // call after a stream sync
+  hipError_t collect() {
+    if (!on) return hipSuccess;
+    for (const Rec& r : recs) {
+      float ms = 0.f;
+      hipError_t rc = hipEventElapsedTime(&ms, s->events[r.ev], s->events[r.ev + 1]);
+      if (rc != hipSuccess) return rc;
+      *r.acc += (double)ms;
+    }
+    recs.clear();
+    used = 0;
+    return hipSuccess;
+  }
+};
+}  // namespace
+
+static int ensure_pixels(pbrhip_scene* s, uint32_t w, uint32_t h, uint32_t rank, uint32_t world) {
+  if (s->pk_w == w && s->pk_h == h && s->pk_rank == rank && s->pk_world == world && s->pix_index.p) return PBRHIP_OK;
+  uint32_t nt = 0;
+  pbrhip_create_tiles(w, h, nullptr, &nt);
+  std::vector<uint32_t> tiles(4 * (size_t)nt);
+  pbrhip_create_tiles(w, h, tiles.data(), &nt);
+  std::vector<uint32_t> pix;
+  for (uint32_t t = 0; t < nt; t++) {
+    if (t % world != rank) continue;  // interleaved tile -> GPU map
+    for (uint32_t y = tiles[4 * t + 2]; y < tiles[4 * t + 3]; y++)
+      for (uint32_t x = tiles[4 * t + 0]; x < tiles[4 * t + 1]; x++) pix.push_back(y * w + x);
+  }
+  HIPCHK(s->pix_index.upload(pix, s->stream));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  s->pk_w = w, s->pk_h = h, s->pk_rank = rank, s->pk_world = world, s->pk_npix = (uint32_t)pix.size();
+  return PBRHIP_OK;
+}
+
+static int ensure_paths(pbrhip_scene* s, size_t n) {
+  HIPCHK(s->ray_o.reserve(n));
+  HIPCHK(s->ray_d.reserve(n));
+  HIPCHK(s->thr.reserve(n));
+  HIPCHK(s->L.reserve(n));
+  HIPCHK(s->hit.reserve(n));
+  for (auto& b : s->sss) HIPCHK(b.reserve(n));
+  for (auto& b : s->sh) HIPCHK(b.reserve(n));
+  HIPCHK(s->rng.reserve(n));
+  HIPCHK(s->flags.reserve(n));
+  for (auto& b : s->q) HIPCHK(b.reserve(n));
+  HIPCHK(s->counts.reserve(kCntNum));
+  HIPCHK(s->stats.reserve(kStatNum));
+  return PBRHIP_OK;
+}
+
+static int render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile int* cancel, float* d_rgba,
+                       uint32_t* d_count, size_t* finish_pass, pbrhip_render_stats* stats) {
+  auto t_begin = std::chrono::steady_clock::now();
+  if (!s->committed) return fail(PBRHIP_ESTATE, "scene not committed");
+  if (d->width == 0 || d->height == 0) return fail(PBRHIP_EINVAL, "empty image");
+  if ((uint64_t)d->width * d->height >= (1ull << 32)) return fail(PBRHIP_EINVAL, "image too large");
+  uint32_t world = d->tile_world ? d->tile_world : 1;
+  if (d->tile_rank >= world) return fail(PBRHIP_EINVAL, "tile_rank %u >= tile_world %u", d->tile_rank, world);
+  HIPCHK(hipSetDevice(s->device));
+  hipStream_t st = s->stream;
+  const size_t npx_img = (size_t)d->width * d->height;
+  if (!(d->flags & PBRHIP_RENDER_NO_CLEAR)) {  // PrepareRendering: layer->Resize + Clear (render.cc:99-100)
+    HIPCHK(hipMemsetAsync(d_rgba, 0, npx_img * 4 * sizeof(float), st));
+    HIPCHK(hipMemsetAsync(d_count, 0, npx_img * sizeof(uint32_t), st));
+  }
+  if (finish_pass) *finish_pass = 0;
+  pbrhip_render_stats S;
+  memset(&S, 0, sizeof(S));
+  if (int rc = ensure_pixels(s, d->width, d->height, d->tile_rank, world)) return rc;
+  const uint32_t npix = s->pk_npix;
+  const bool want_stats = (d->flags & PBRHIP_RENDER_STATS) != 0;
+  Timer tm{s, (d->flags & PBRHIP_RENDER_TIMING) != 0};
+  if (npix > 0 && d->num_sample > 0) {
+    uint64_t max_paths = d->max_paths_in_flight ? d->max_paths_in_flight : (32ull << 20);
+    uint32_t chunk_passes = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(d->num_sample, max_paths / npix));
+    if ((uint64_t)chunk_passes * npix >= (1ull << 32)) chunk_passes = (uint32_t)(((1ull << 32) - 1) / npix);
+    if (int rc = ensure_paths(s, (size_t)chunk_passes * npix)) return rc;
+    PathState P;
+    P.ray_o = s->ray_o.p, P.ray_d = s->ray_d.p, P.thr = s->thr.p, P.L = s->L.p, P.hit = s->hit.p;
+    P.rng = s->rng.p, P.flags = s->flags.p;
+    P.sss_sigt = s->sss[0].p, P.sss_sigs = s->sss[1].p, P.sss_thr = s->sss[2].p, P.sss_pdf = s->sss[3].p;
+    P.sss_ez = s->sss[4].p, P.sss_A = s->sss[5].p;
+    P.q_in = s->q[0].p, P.q_out = s->q[1].p, P.q_principled = s->q[2].p, P.q_hair = s->q[3].p, P.q_sss = s->q[4].p;
+    P.sh_o = s->sh[0].p, P.sh_d = s->sh[1].p, P.sh_c = s->sh[2].p, P.sh_e = s->sh[3].p;
+    P.counts = s->counts.p, P.stats = s->stats.p;
+    HIPCHK(hipMemsetAsync(P.stats, 0, sizeof(unsigned long long) * kStatNum, st));
+    const Camera cam = make_camera(s, d->width, d->height);
+    const uint64_t rng_inc = (d->seed_seq << 1u) | 1u;  // pcg32_srandom (rng.h:30-36)
+    const DScene& sc = s->dscene;
+
+    for (uint32_t done = 0; done < d->num_sample;) {
+      if (cancel && *cancel) break;  // render.cc:217 (cooperative, chunk granularity)
+      uint32_t np = std::min(chunk_passes, d->num_sample - done);
+      uint32_t n = np * npix;
+      memset(s->h_counts, 0, sizeof(uint32_t) * kCntNum);
+      s->h_counts[kCntIn] = n;
+      HIPCHK(hipMemcpyAsync(P.counts, s->h_counts, sizeof(uint32_t) * kCntNum, hipMemcpyHostToDevice, st));
+      HIPCHK(tm.begin(&S.ms_generate));
+      launch_generate(st, P, cam, s->pix_index.p, npix, n, d->width, d->first_pass + done, d->seed_seq);
+      HIPCHK(tm.end());
+      while (n > 0) {
+        HIPCHK(tm.begin(&S.ms_trace_closest));
+        launch_trace_closest(st, P, sc, n, want_stats);
+        HIPCHK(tm.end());
+        HIPCHK(tm.begin(&S.ms_surface));
+        launch_surface(st, P, sc, n, rng_inc);
+        HIPCHK(tm.end());
+        HIPCHK(tm.begin(&S.ms_shade_principled));
+        launch_shade_principled(st, P, sc, n, rng_inc);
+        HIPCHK(tm.end());
+        HIPCHK(tm.begin(&S.ms_shade_hair));
+        launch_shade_hair(st, P, sc, n, rng_inc);
+        HIPCHK(tm.end());
+        HIPCHK(tm.begin(&S.ms_sss_step));
+        launch_sss_step(st, P, sc, n, rng_inc);
+        HIPCHK(tm.end());
+        HIPCHK(tm.begin(&S.ms_trace_shadow));
+        launch_trace_shadow(st, P, sc, n, want_stats);
+        HIPCHK(tm.end());
+        S.n_trace_closest++, S.n_trace_shadow++, S.n_surface++, S.n_shade_principled++, S.n_shade_hair++, S.n_sss_step++;
+        launch_advance(st, P);
+        std::swap(P.q_in, P.q_out);
+        HIPCHK(hipMemcpyAsync(s->h_counts, P.counts, sizeof(uint32_t) * kCntNum, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(tm.collect());
+        if (s->h_counts[kCntOverflow]) return fail(PBRHIP_EOVERFLOW, "BVH traversal stack overflow");
+        n = s->h_counts[kCntIn];
+        S.iterations++;
+      }
+      HIPCHK(tm.begin(&S.ms_accumulate));
+      launch_accumulate(st, P, s->pix_index.p, npix, np, d_rgba, d_count);
+      HIPCHK(tm.end());
+      HIPCHK(hipGetLastError());
+      done += np;
+      S.chunks++;
+      S.samples += (uint64_t)np * npix;
+      if (finish_pass) *finish_pass = done;  // render.cc:224-231
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(tm.collect());
+    if (want_stats) {
+      unsigned long long hs[kStatNum];
+      HIPCHK(hipMemcpy(hs, P.stats, sizeof(hs), hipMemcpyDeviceToHost));
+      S.closest_rays = hs[kStatClosestRays], S.closest_nodes = hs[kStatClosestNodes];
+      S.closest_tris = hs[kStatClosestTris], S.closest_curves = hs[kStatClosestCurves];
+      S.shadow_rays = hs[kStatShadowRays], S.shadow_nodes = hs[kStatShadowNodes];
+      S.shadow_tris = hs[kStatShadowTris], S.shadow_curves = hs[kStatShadowCurves];
+    }
+  } else {
+    HIPCHK(hipStreamSynchronize(st));
+    if (finish_pass) *finish_pass = d->num_sample;
+  }
+  S.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  if (stats) *stats = S;
+  return PBRHIP_OK;
+}
+
+extern "C" int pbrhip_render_device(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile int* cancel,
+                                    float* d_rgba, uint32_t* d_count, size_t* finish_pass, pbrhip_render_stats* stats) {
+  if (!s || !d || !d_rgba || !d_count) return fail(PBRHIP_EINVAL, "render: NULL argument");
+  return render_impl(s, d, cancel, d_rgba, d_count, finish_pass, stats);
+}
+
+extern "C" int pbrhip_render(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile int* cancel, float* rgba,
+                             uint32_t* count, size_t* finish_pass, pbrhip_render_stats* stats) {
+  if (!s || !d || !rgba || !count) return fail(PBRHIP_EINVAL, "render: NULL argument");
+  auto t_begin = std::chrono::steady_clock::now();
+  HIPCHK(hipSetDevice(s->device));
+  size_t npx = (size_t)d->width * d->height;
+  HIPCHK(s->own_rgba.reserve(npx * 4));
+  HIPCHK(s->own_count.reserve(npx));
+  if (d->flags & PBRHIP_RENDER_NO_CLEAR) {
+    HIPCHK(hipMemcpyAsync(s->own_rgba.p, rgba, npx * 4 * sizeof(float), hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(s->own_count.p, count, npx * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+  }
+  int rc = render_impl(s, d, cancel, s->own_rgba.p, s->own_count.p, finish_pass, stats);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(rgba, s->own_rgba.p, npx * 4 * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+  HIPCHK(hipMemcpyAsync(count, s->own_count.p, npx * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  if (stats) stats->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  return PBRHIP_OK;
+}
+
+// ------------------------------------------------------------------ test hooks
+extern "C" int pbrhip_trace_closest(pbrhip_scene* s, const pbrhip_ray* rays, size_t n, pbrhip_hit* hits) {
+  if (!s || (!rays && n) || (!hits && n)) return fail(PBRHIP_EINVAL, "trace_closest: NULL argument");
+  if (!s->committed) return fail(PBRHIP_ESTATE, "scene not committed");
+  if (n == 0) return PBRHIP_OK;
+  if (n >= (1ull << 31)) return fail(PBRHIP_EINVAL, "too many rays");
+  HIPCHK(hipSetDevice(s->device));
+  HIPCHK(s->hook_rays.reserve(2 * n));
+  HIPCHK(s->hook_hits.reserve(n));
+  HIPCHK(s->counts.reserve(kCntNum));
+  HIPCHK(hipMemsetAsync(s->counts.p, 0, sizeof(uint32_t) * kCntNum, s->stream));
+  HIPCHK(hipMemcpyAsync(s->hook_rays.p, rays, n * sizeof(pbrhip_ray), hipMemcpyHostToDevice, s->stream));
+  launch_hook_closest(s->stream, s->dscene, s->hook_rays.p, (uint32_t)n, s->hook_hits.p, s->counts.p + kCntOverflow);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(hits, s->hook_hits.p, n * sizeof(pbrhip_hit), hipMemcpyDeviceToHost, s->stream));
+  HIPCHK(hipMemcpyAsync(s->h_counts, s->counts.p, sizeof(uint32_t) * kCntNum, hipMemcpyDeviceToHost, s->stream));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  if (s->h_counts[kCntOverflow]) return fail(PBRHIP_EOVERFLOW, "BVH traversal stack overflow");
+  return PBRHIP_OK;
+}
+extern "C" int pbrhip_trace_any(pbrhip_scene* s, const pbrhip_ray* rays, size_t n, uint8_t* occluded) {
+  if (!s || (!rays && n) || (!occluded && n)) return fail(PBRHIP_EINVAL, "trace_any: NULL argument");
+  if (!s->committed) return fail(PBRHIP_ESTATE, "scene not committed");
+  if (n == 0) return PBRHIP_OK;
+  if (n >= (1ull << 31)) return fail(PBRHIP_EINVAL, "too many rays");
+  HIPCHK(hipSetDevice(s->device));
+  HIPCHK(s->hook_rays.reserve(2 * n));
+  HIPCHK(s->hook_occ.reserve(n));
+  HIPCHK(s->counts.reserve(kCntNum));
+  HIPCHK(hipMemsetAsync(s->counts.p, 0, sizeof(uint32_t) * kCntNum, s->stream));
+  HIPCHK(hipMemcpyAsync(s->hook_rays.p, rays, n * sizeof(pbrhip_ray), hipMemcpyHostToDevice, s->stream));
+  launch_hook_any(s->stream, s->dscene, s->hook_rays.p, (uint32_t)n, s->hook_occ.p, s->counts.p + kCntOverflow);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(occluded, s->hook_occ.p, n, hipMemcpyDeviceToHost, s->stream));
+  HIPCHK(hipMemcpyAsync(s->h_counts, s->counts.p, sizeof(uint32_t) * kCntNum, hipMemcpyDeviceToHost, s->stream));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  if (s->h_counts[kCntOverflow]) return fail(PBRHIP_EOVERFLOW, "BVH traversal stack overflow");
+  return PBRHIP_OK;
+}
