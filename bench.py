@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py -- Msamples/s of the MI355X path-tracing hot path (BASELINE.json metric).
+
+One "step" = one pbrlab::Render() of the workload: every (pixel, pass) sample of the frame goes
+through the whole hot path (camera ray -> GetRadiance bounce loop -> RenderLayer).  The scene (BVH,
+materials, light tables) is already resident in HBM when the timed region starts; the step ends with
+the framebuffer on the host of rank 0 (RenderLayer is host memory in pbrlab's API).
+
+N GPUs: one process per GPU (torch.distributed / RCCL).  64x64 tiles are interleaved over the ranks
+(tile i -> rank i % N), every rank renders its tiles into a zero-initialised full-size device
+framebuffer, and ONE RCCL reduce (sum) of rgba + count lands the frame on rank 0.  Total work is fixed
+as N grows => "scaling": "strong".
+
+  python bench.py --gpus 1 --steps 3 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # BASELINE.json configs[1..4] on the procedural stand-in scenes (assets are missing: BASELINE.md §3)
+    "c2": dict(desc="cornellbox_suzanne_lucy stand-in (S-cornell, reference .mtl, Lucy subsurface=0): "
+                    "Lambert + GGX, 1920x1080, 64 spp", scene="cornell", variant="ggx", width=1920, height=1080, spp=64),
+    "c3": dict(desc="S-cornell with Lucy subsurface=1 (random-walk SSS), 1920x1080, 256 spp", scene="cornell",
+               variant="sss", width=1920, height=1080, spp=256),
+    "c4": dict(desc="S-hair (50k curly strands) + head, PrincipledHair + curve intersection, 1920x1080, 128 spp",
+               scene="hair", variant="", width=1920, height=1080, spp=128),
+    "c1": dict(desc="S-cornell Lambert-only, 256x256, 4 spp (plumbing config)", scene="cornell", variant="lambert",
+               width=256, height=256, spp=4),
+}
+
+# algorithmic bytes of the traversal kernel: 64 B per BVH node visited, 48 B per
+# triangle tested, 64 B per curve tested, and per ray 32 B ray + 16 B hit record + 4 B queue entry
+NODE_B, TRI_B, CURVE_B, RAY_B = 64, 48, 64, 52
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def make_desc(w):
+    from pbrlab_amd import scenes
+    if w["scene"] == "cornell":
+        return scenes.cornell_scene(w["variant"], seed=1)
+    return scenes.hair_scene(seed=1)
+
+
+def cpu_baseline(desc, w, seconds_budget=20.0):
+    """Oracle (reference algorithm restated in C, oracle/) on the host cores, bounded sample of the same
+    workload: the full frame at as many spp as fit ~seconds_budget (cost per sample is spp-independent)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as O
+    so = O.oracle_scene_from_desc(desc)
+    cores = os.cpu_count() or 1
+    W, H = w["width"], w["height"]
+    t0 = time.time()                               # calibrate on 1/16 of the tiles
+    _, _, st = so.render(W, H, 1, tile_rank=0, tile_world=16, threads=cores)
+    rate = st["samples"] / max(time.time() - t0, 1e-3)
+    spp, world = 1, 1
+    if rate * seconds_budget >= W * H:
+        spp = int(max(1, min(w["spp"], rate * seconds_budget // (W * H))))
+    else:
+        world = int(min(64, max(1, round(W * H / (rate * seconds_budget)))))
+    t0 = time.time()
+    _, _, st = so.render(W, H, spp, tile_rank=0, tile_world=world, threads=cores)
+    dt = time.time() - t0
+    return {"value": st["samples"] / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (C restatement of the reference integrator, own binned-SAH BVH2; Embree is not "
+                      f"available), {W}x{H} x {spp} spp, tiles i%{world}==0: {st['samples']} samples in {dt:.1f} s "
+                      f"on {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--spp", type=int, default=0, help="override spp (invalidates the headline config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--max-paths", type=int, default=0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import pbrlab_amd as pa
+    from pbrlab_amd import api
+    from pbrlab_amd.dist import reduce_layer
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    pa.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    w = dict(WORKLOADS[args.workload])
+    if args.spp:
+        w["spp"] = args.spp
+    W, H, spp = w["width"], w["height"], w["spp"]
+    desc = make_desc(w)
+    scene = pa.scene_from_desc(desc)          # upload + BVH: outside the timed region
+    info = scene.info()
+
+    rgba = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+    count = torch.zeros((H, W), dtype=torch.int32, device=dev)
+    h_rgba = torch.zeros((H, W, 4), dtype=torch.float32).pin_memory() if rank == 0 else None
+    h_count = torch.zeros((H, W), dtype=torch.int32).pin_memory() if rank == 0 else None
+    torch.cuda.synchronize()
+    ptrs = (rgba.data_ptr(), count.data_ptr())
+
+    def step(flags=0):
+        _, st = api.Render(scene, W, H, spp, tile_rank=rank, tile_world=world, device_out=ptrs, flags=flags,
+                           max_paths_in_flight=args.max_paths)
+        if dist is not None:                   # the only exchange step: framebuffer reduce over xGMI
+            reduce_layer(rgba, count, dst=0)
+        if rank == 0:                          # RenderLayer lives on the host
+            h_rgba.copy_(rgba, non_blocking=True)
+            h_count.copy_(count, non_blocking=True)
+        torch.cuda.synchronize()
+        return st
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    agg = {}
+    for _ in range(args.steps):
+        st = step(flags=0 if args.no_roofline else api.RENDER_TIMING)
+        for k, v in st.items():
+            agg[k] = agg.get(k, 0) + v
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sanity: every pixel got spp samples
+    if rank == 0:
+        assert int(h_count.min()) == spp and int(h_count.max()) == spp, "framebuffer incomplete"
+        assert bool(torch.isfinite(h_rgba).all())
+
+    roofline = None
+    if not args.no_roofline:
+        # untimed pass with traversal counters (deterministic: identical work to the timed steps)
+        _, sst = api.Render(scene, W, H, spp, tile_rank=rank, tile_world=world, device_out=ptrs,
+                            flags=api.RENDER_STATS, max_paths_in_flight=args.max_paths)
+        torch.cuda.synchronize()
+        bytes_step = (NODE_B * sst["closest_nodes"] + TRI_B * sst["closest_tris"] + CURVE_B * sst["closest_curves"] +
+                      RAY_B * sst["closest_rays"])
+        launches = agg["n_trace_closest"] / args.steps
+        ms_step = agg["ms_trace_closest"] / args.steps
+        if ms_step > 0:
+            achieved = bytes_step / (ms_step * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": "k_trace_closest", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                        "algorithmic_bytes_per_launch": bytes_step / max(launches, 1),
+                        "avg_launch_ms": ms_step / max(launches, 1), "launches_per_step": launches,
+                        "rays_per_step": sst["closest_rays"],
+                        "kernel_ms_per_step": {k[3:]: agg[k] / args.steps for k in agg if k.startswith("ms_") and k != "ms_total"}}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(desc, w)
+
+    if rank == 0:
+        samples = W * H * spp * args.steps
+        out = {
+            "metric": "Msamples/s (paths x spp / s), 1920x1080 Cornell-box-Suzanne render", "value": samples / elapsed / 1e6,
+            "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": w["desc"], "width": W, "height": H, "spp": spp,
+                       "triangles": desc.num_triangles(), "curve_segments": desc.num_segments(),
+                       "bvh_nodes": info["num_nodes"], "scene_bytes": info["device_bytes"],
+                       "parallelism": f"tiles%{world}" if world > 1 else "1gpu",
+                       "rng": "PCG32((pass<<32)+pixel, 1234567890)"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,66 @@
+"""CPU, world_size 2 over gloo: the multi-GPU exchange step (one framebuffer reduce to rank 0) on
+per-rank tile shards.  The shards here come from the oracle (no GPU in this container); the GPU
+version of the same check is tests/test_gpu_parity.py::test_tile_sharding_matches_single."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np, torch, torch.distributed as dist
+import _oracle as O
+from pbrlab_amd import scenes
+from pbrlab_amd.dist import reduce_layer, tiles_of_rank
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+d = scenes.cornell_scene("ggx", monkey_subdiv=1, lucy_nu=32, lucy_nv=8)
+so = O.oracle_scene_from_desc(d)
+W, H, SPP = 130, 70, 2
+rgba, cnt, _ = so.render(W, H, SPP, tile_rank=rank, tile_world=world)
+mine = tiles_of_rank(W, H, rank, world)
+mask = np.zeros((H, W), bool)
+for sx, tx, sy, ty in mine: mask[sy:ty, sx:tx] = True
+assert (cnt[mask] == SPP).all() and (cnt[~mask] == 0).all() and not rgba[~mask].any()
+t_rgba, t_cnt = torch.from_numpy(rgba), torch.from_numpy(cnt.astype(np.int32))
+reduce_layer(t_rgba, t_cnt, dst=0)
+if rank == 0:
+    full, fcnt, _ = so.render(W, H, SPP)
+    assert t_rgba.numpy().tobytes() == full.tobytes(), "reduced frame differs from the single-rank frame"
+    assert np.array_equal(t_cnt.numpy(), fcnt.astype(np.int32))
+    print("DIST_OK")
+dist.destroy_process_group()
+"""
+
+
+def test_gloo_world2_reduce(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "DIST_OK" in outs[0]
+
+
+def test_tile_rank_map():
+    from pbrlab_amd.dist import tiles_of_rank
+    import pbrlab_amd as pa
+    all_tiles = pa.create_tiles(1920, 1080)
+    got = [tiles_of_rank(1920, 1080, r, 8) for r in range(8)]
+    assert sum(len(g) for g in got) == len(all_tiles) == 510
+    assert np.array_equal(got[3], all_tiles[3::8])
+    assert [len(g) for g in got] == [64, 64, 64, 64, 64, 64, 63, 63]

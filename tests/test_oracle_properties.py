@@ -1,0 +1,109 @@
+"""CPU: properties of the oracle that the parity argument relies on."""
+import numpy as np
+import pytest
+
+import _oracle as O
+from pbrlab_amd import scenes
+
+
+@pytest.fixture(scope="module")
+def small():
+    d = scenes.cornell_scene("sss", monkey_subdiv=2, lucy_nu=64, lucy_nv=12)
+    return d, O.oracle_scene_from_desc(d)
+
+
+def test_bvh_equals_brute_force(small):
+    d, so = small
+    rays = scenes.random_rays(so.FetchSceneAABB(), 3000, seed=5)
+    a, b = so.trace_closest(rays), so.trace_closest(rays, brute_force=True)
+    assert a.tobytes() == b.tobytes()
+    sr = rays.copy()
+    sr["tmax"] = 0.5
+    assert np.array_equal(so.trace_any(sr), so.trace_any(sr, brute_force=True))
+    dh = scenes.hair_scene(n_strands=200, n_segments=5, head_subdiv=1)
+    sh = O.oracle_scene_from_desc(dh)
+    rays = scenes.random_rays(sh.FetchSceneAABB(), 2000, seed=6)
+    assert sh.trace_closest(rays).tobytes() == sh.trace_closest(rays, brute_force=True).tobytes()
+
+
+def test_hit_conventions(small):
+    """tmin < t <= tmax; miss = ids 0xFFFFFFFF with TraceResult defaults (raytracer.h:9-17)."""
+    d, so = small
+    r = np.zeros(3, O.RAY_DT)
+    r["org"] = [0, 0, 0.9]
+    r["dir"] = [0, 0, -1]          # hits the back wall z = -1 at t = 1.9
+    r["tmin"] = [0, 0, 1.9]
+    r["tmax"] = [1.844e18, 1.9, 1.844e18]
+    h = so.trace_closest(r)
+    assert h["instance_id"][0] == 2 and abs(h["t"][0] - 1.9) < 1e-6    # 'back' is the third shape
+    assert h["instance_id"][1] == 2                                     # t == tmax is accepted
+    assert h["instance_id"][2] == 0xFFFFFFFF and h["t"][2] == 1.0 and tuple(h["normal_g"][2]) == (1, 0, 0)
+    up = np.zeros(1, O.RAY_DT)
+    up["org"], up["dir"], up["tmax"] = [0, 0, 3], [0, 0, 1], 1.844e18
+    assert so.trace_closest(up)["prim_id"][0] == 0xFFFFFFFF
+
+
+def test_tile_sharding_is_exact(small):
+    """disjoint tiles + zeros: the sum of per-rank framebuffers equals the single-rank frame bit for bit
+     and does not depend on thread count."""
+    d, so = small
+    full, cnt, _ = so.render(130, 70, 3, threads=3)
+    acc, cacc = np.zeros_like(full), np.zeros_like(cnt)
+    for r in range(3):
+        a, c, _ = so.render(130, 70, 3, tile_rank=r, tile_world=3, threads=2)
+        acc += a
+        cacc += c
+    assert acc.tobytes() == full.tobytes() and np.array_equal(cacc, cnt) and (cnt == 3).all()
+    one, _, _ = so.render(130, 70, 3, threads=1)
+    assert one.tobytes() == full.tobytes()
+
+
+def test_progressive_passes_add_up(small):
+    d, so = small
+    full, _, _ = so.render(64, 64, 4)
+    a, _, _ = so.render(64, 64, 2, first_pass=0)
+    b, _, _ = so.render(64, 64, 2, first_pass=2)
+    # ascending-pass accumulation: (p0+p1)+(p2+p3) differs from ((p0+p1)+p2)+p3 only by float association
+    assert np.allclose(a + b, full, rtol=1e-6, atol=1e-7)
+    assert full[..., 3].min() == 4 == full[..., 3].max()
+
+
+def test_light_tables(small):
+    """LightManager::Commit on the single 2-triangle `light` quad (light-manager.cc:29-184)."""
+    import ctypes as C
+    d, so = small
+    L = O.lib()
+    inst, geom, npr = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    p, cdf = C.c_float(), C.c_float()
+    assert L.orc_light_table(so.h, 0, C.byref(inst), C.byref(geom), C.byref(p), C.byref(cdf), C.byref(npr)) == 1
+    assert (inst.value, geom.value, npr.value, p.value, cdf.value) == (5, 0, 2, 1.0, 1.0)
+    pp, pc, pa = (np.zeros(2, np.float32) for _ in range(3))
+    L.orc_light_prims(so.h, 0, O._ptr(pp), O._ptr(pc), O._ptr(pa))
+    assert np.allclose(pp, [0.5, 0.5]) and np.allclose(pc, [0.5, 1.0]) and np.allclose(pa, 1 / 0.18)
+
+
+def test_demo_material_closures():
+    """ParamToBsdf on the demo .mtl: which closures each material enables."""
+    L = O.lib()
+    want = {"Floor": (1, 0, 0, 0), "Light": (0, 0, 0, 0), "Monkey": (1, 0, 1, 0), "Lucy": (0, 1, 1, 0),
+            "Reflective": (1, 0, 0, 0), "Wall_Green": (1, 0, 0, 0), "Wall_Red": (1, 0, 0, 0), "Wall_White": (1, 0, 0, 0)}
+    for m in scenes.demo_materials("sss"):
+        out = np.zeros(34, np.float32)
+        L.orc_kat_param_to_bsdf(O.make_principled(m), O._ptr(out))
+        assert (out[0], out[4], out[14], out[24]) == want[m["name"]], m["name"]
+        if m["name"] == "Monkey":
+            assert abs(out[20] - (2 / (1 - np.sqrt(0.08)) - 1)) < 1e-6 and abs(out[18] - 1e-4) < 1e-9
+        if m["name"] == "Lucy":
+            assert abs(out[18] - 0.04) < 1e-8 and np.allclose(out[8:11], [1, .8, .8])
+
+
+def test_empty_and_lightless_scenes():
+    so = O.OracleScene()
+    so.CommitScene()
+    rgba, cnt, st = so.render(8, 8, 2)
+    assert not rgba[..., :3].any() and (cnt == 2).all() and st["closest_rays"] == 128
+    d = scenes.cornell_scene("lambert", monkey_subdiv=1, lucy_nu=16, lucy_nv=6)
+    d.shapes = [s for s in d.shapes if s.name != "light"]
+    so = O.oracle_scene_from_desc(d)
+    rgba, cnt, st = so.render(16, 16, 2)
+    assert not rgba[..., :3].any() and st["shadow_rays"] == 0
