@@ -193,7 +193,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": w["desc"], "width": W, "height": H, "spp": spp,
                        "triangles": desc.num_triangles(), "curve_segments": desc.num_segments(),
-                       "bvh_nodes": info["num_nodes"], "scene_bytes": info["device_bytes"],
+                       "bvh_nodes": info["num_nodes"], "bvh_depth": info["depth"], "scene_bytes": info["device_bytes"],
                        "parallelism": f"tiles%{world}" if world > 1 else "1gpu",
                        "rng": "PCG32((pass<<32)+pixel, 1234567890)"},
             "roofline": roofline, "cpu_baseline": cpu,

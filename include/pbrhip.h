@@ -76,7 +76,7 @@ typedef struct {
   uint32_t first_pass;                /* passes [first_pass, first_pass+num_sample) (progressive resume) */
   uint64_t seed_seq;                  /* PCG32 initseq; the reference uses 1234567890 (render.cc:215) */
   uint32_t tile_rank, tile_world;     /* 64x64 tiles (render.cc:107-108) with index % world == rank */
-  uint32_t max_paths_in_flight;       /* 0 = default (32 Mi): passes are rendered in chunks of this many paths */
+  uint32_t max_paths_in_flight;       /* 0 = default (half of the free HBM, <= 256 Mi): passes are rendered in chunks of this many paths */
   uint32_t flags;                     /* PBRHIP_RENDER_* */
 } pbrhip_render_desc;
 

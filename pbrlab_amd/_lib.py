@@ -6,7 +6,7 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libpbrhip.so")
+LIB_PATH = os.environ.get("PBRHIP_LIB") or os.path.join(HERE, "libpbrhip.so")  # PBRHIP_LIB: A/B builds
 CSRC = os.path.join(HERE, "csrc")
 
 # every symbol include/pbrhip.h declares

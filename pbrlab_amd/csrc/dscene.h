@@ -21,7 +21,10 @@ constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kCurveBit = 0x40000000u;
 constexpr uint32_t kEmptyChild = 0xFFFFFFFFu;  // (a leaf reference that can never be produced)
 constexpr int kMaxLeaf = 4;
-constexpr int kStackDepth = 40;
+#ifndef PB_STACK_DEPTH
+#define PB_STACK_DEPTH 40
+#endif
+constexpr int kStackDepth = PB_STACK_DEPTH;
 
 struct alignas(16) BvhNode {
   float lo0[3], hi0[3];
@@ -92,7 +95,7 @@ struct DScene {
   const LightHead* light_heads;
   const float* lprim_cdf;
   const LightRec* lrecs;
-  uint32_t num_nodes, num_slots, num_lights, num_materials;
+  uint32_t num_nodes, num_slots, num_lights, num_materials, num_curves;
 };
 
 // camera of RenderingTile (render.cc:132-158), derived on the host from the scene AABB

@@ -20,6 +20,8 @@ struct Hit {
 
 struct TravStats {
   uint32_t nodes, tris, curves;
+  // phase-voting traversal, lane 0 of each wave: iterations and participating lanes per phase
+  uint32_t it_node, it_tri, it_curve, it_refill, ln_node, ln_tri, ln_curve;
 };
 
 __device__ __forceinline__ V3 ld3(const float4& a) { return V3(a.x, a.y, a.z); }
@@ -112,7 +114,7 @@ __device__ __forceinline__ bool box_test(const float* lo, const float* hi, V3 o,
 }
 
 // Leaf processing.  ANY: returns true on the first accepted hit.
-template <bool ANY, bool STATS>
+template <bool ANY, bool STATS, bool CURVES>
 __device__ __forceinline__ bool leaf_test(const DScene& sc, uint32_t leaf, V3 o, V3 d, float tmin, float& best_t,
                                           Hit& hit, TravStats& st) {
   uint32_t first = (leaf & 0x3FFFFFFFu) >> 3, count = (leaf & 7u) + 1u;
@@ -121,7 +123,7 @@ __device__ __forceinline__ bool leaf_test(const DScene& sc, uint32_t leaf, V3 o,
     const float4* g = sc.slots + (size_t)s * 4;
     float t, u, v;
     bool ok;
-    if (!is_curve) {
+    if (!CURVES || !is_curve) {
       float4 a = g[0], b = g[1], c = g[2];
       if (STATS) st.tris++;
       ok = tri_test(ld3(a), ld3(b), ld3(c), o, d, tmin, t, u, v) && (t <= best_t);
@@ -142,7 +144,7 @@ __device__ __forceinline__ bool leaf_test(const DScene& sc, uint32_t leaf, V3 o,
 }
 
 // BVH2 traversal, near child first, far child on a per-lane stack (stack[i * stride]).
-template <bool ANY, bool STATS>
+template <bool ANY, bool STATS, bool CURVES>
 __device__ __forceinline__ bool traverse(const DScene& sc, V3 o, V3 d, float tmin, float tmax, Hit& hit,
                                          uint32_t* stack, uint32_t stride, TravStats& st, uint32_t* overflow) {
   hit.slot = kNone;
@@ -186,7 +188,7 @@ __device__ __forceinline__ bool traverse(const DScene& sc, V3 o, V3 d, float tmi
         next = stack[(uint32_t)sp * stride];
       }
       if (!(next & kLeafBit)) break;
-      if (leaf_test<ANY, STATS>(sc, next, o, d, tmin, best_t, hit, st)) return true;
+      if (leaf_test<ANY, STATS, CURVES>(sc, next, o, d, tmin, best_t, hit, st)) return true;
       next = kEmptyChild;
     }
     cur = next;

@@ -1,0 +1,194 @@
+// dtrace_pv.h -- persistent, phase-voting BVH traversal for wave64 (device).
+//
+// Why: a one-ray-per-lane while/if traversal on gfx950 measured 9.6 active lanes per VALU instruction (15 %)
+// -- lanes at a leaf idle while others walk nodes, and finished rays idle until the slowest lane of the wave
+// ends (profiles/README.md, round 1a).  Here every lane owns a small state machine
+//     IDLE -> NODE(internal node) <-> TRI(one triangle of a leaf) [<-> CURVE]
+// whose next work item (a 64-byte node or a 64-byte primitive slot -- same footprint) is prefetched into
+// registers as soon as it is known.  Each iteration the WAVE votes (ballot + popcount) for the phase with the
+// most lanes and executes only that phase's code, so at least half of the busy lanes advance per iteration and
+// the two code paths never serialise.  When enough lanes are idle they are refilled from the ray queue
+// (persistent threads): the wave grabs rays in batches with one atomicAdd and deals them out by ballot rank.
+//
+// The intersection contract is dtrace.h's (same tests, same tie rule), so results are bit-identical to the
+// simple traversal used by the test hooks.
+#pragma once
+
+#include "dtrace.h"
+
+namespace pb {
+
+constexpr uint32_t kPvBatch = 512;        // rays grabbed per atomicAdd
+constexpr int kPvRefillIdle = 24;         // refill when at least this many lanes are idle
+
+enum : uint32_t { kStIdle = 0, kStNode = 1, kStTri = 2, kStCurve = 3 };
+
+// Sink: what to do with a finished ray.  closest: store the hit record; shadow: resolve the contribution.
+//   void load(uint32_t idx, uint32_t& tag, V3& o, V3& d, float& tmin, float& tmax)
+//   void done(uint32_t tag, const Hit& h, bool occluded)
+template <bool ANY, bool STATS, bool CURVES, typename Sink>
+__device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t* head, Sink& sink, uint32_t* stk_base,
+                                         uint32_t stride, TravStats& st, uint32_t* overflow) {
+  const uint32_t lane = __lane_id();
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  // wave-uniform batch cursor
+  uint32_t batch_cur = 0, batch_end = 0;
+  bool exhausted = (n == 0) || (sc.num_nodes == 0);
+  if (sc.num_nodes == 0 && n != 0) {
+    // empty scene: every ray misses
+    for (;;) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(head, 64u);
+      base = (uint32_t)__shfl((int)base, 0);
+      if (base >= n) break;
+      uint32_t idx = base + lane;
+      if (idx < n) {
+        uint32_t tag;
+        V3 o, d;
+        float tmin, tmax;
+        sink.load(idx, tag, o, d, tmin, tmax);
+        Hit h = {tmax, 0.f, 0.f, kNone};
+        sink.done(tag, h, false);
+      }
+    }
+    return;
+  }
+
+  // per-lane state
+  uint32_t state = kStIdle, tag = 0;
+  V3 o(0.f), d(0.f), inv(0.f);
+  float tmin = 0.f, best_t = 0.f;
+  Hit hit = {0.f, 0.f, 0.f, kNone};
+  int sp = 0;
+  uint32_t cur = 0, end = 0;  // TRI/CURVE: slot cursor and end of the leaf
+  float4 D0 = make_float4(0, 0, 0, 0), D1 = D0, D2 = D0, D3 = D0;  // prefetched node / primitive slot
+
+  for (;;) {
+    unsigned long long idle_mask = __ballot(state == kStIdle);
+    int n_idle = __popcll(idle_mask);
+    // `advance`: the lane needs a new item; `next` is its reference when have_next, else it is popped
+    bool advance = false, have_next = false, need_load = false;
+    uint32_t next = 0;
+    if (!exhausted && (n_idle >= kPvRefillIdle)) {
+      // ---- refill idle lanes from the queue
+      if (batch_cur == batch_end) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(head, kPvBatch);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)base, 0));
+        batch_cur = base < n ? base : n;
+        batch_end = (base + kPvBatch) < n ? (base + kPvBatch) : n;
+        if (batch_cur >= n) exhausted = true;
+      }
+      uint32_t avail = batch_end - batch_cur;
+      uint32_t take = (uint32_t)n_idle < avail ? (uint32_t)n_idle : avail;
+      uint32_t rank = (uint32_t)__popcll(idle_mask & lt_mask);
+      if (state == kStIdle && rank < take) {
+        float tmax;
+        sink.load(batch_cur + rank, tag, o, d, tmin, tmax);
+        inv = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        best_t = tmax;
+        hit.t = tmax, hit.u = 0.f, hit.v = 0.f, hit.slot = kNone;
+        sp = 0;
+        advance = true, have_next = true, next = 0u;  // root is always an internal node
+      }
+      batch_cur += take;
+      if (STATS && lane == 0) st.it_refill++;
+    } else {
+      if (n_idle == 64) break;  // queue exhausted and every lane done
+      unsigned long long node_mask = __ballot(state == kStNode);
+      unsigned long long tri_mask = __ballot(state == kStTri);
+      int n_node = __popcll(node_mask), n_tri = __popcll(tri_mask);
+      int n_curve = CURVES ? (64 - n_idle - n_node - n_tri) : 0;
+      const int phase = (n_node >= n_tri && n_node >= n_curve) ? 0 : ((!CURVES || n_tri >= n_curve) ? 1 : 2);
+      if (STATS && lane == 0) {
+        if (phase == 0) st.it_node++, st.ln_node += n_node;
+        else if (phase == 1) st.it_tri++, st.ln_tri += n_tri;
+        else st.it_curve++, st.ln_curve += n_curve;
+      }
+      if (phase == 0) {
+        // ---- NODE phase
+        if (state == kStNode) {
+          if (STATS) st.nodes++;
+          float lo0[3] = {D0.x, D0.y, D0.z}, hi0[3] = {D0.w, D1.x, D1.y};
+          float lo1[3] = {D1.z, D1.w, D2.x}, hi1[3] = {D2.y, D2.z, D2.w};
+          uint32_t c0 = __float_as_uint(D3.x), c1 = __float_as_uint(D3.y);
+          float t0, t1;
+          bool h0 = box_test(lo0, hi0, o, inv, tmin, best_t, t0);
+          bool h1 = box_test(lo1, hi1, o, inv, tmin, best_t, t1);
+          bool swap = h1 && (!h0 || t1 < t0);
+          uint32_t nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
+          advance = true;
+          have_next = h0 || h1;
+          next = nearc;
+          if (h0 && h1) {
+            if (sp < kStackDepth) {
+              stk_base[(uint32_t)sp * stride] = farc;
+              sp++;
+            } else {
+              *overflow = 1u;
+            }
+          }
+        }
+      } else {
+        // ---- TRI / CURVE phase: one primitive per lane
+        const bool mine = (phase == 1) ? (state == kStTri) : (CURVES && state == kStCurve);
+        if (mine) {
+          float t, u, v;
+          bool ok;
+          if (!CURVES || phase == 1) {
+            if (STATS) st.tris++;
+            ok = tri_test(ld3(D0), ld3(D1), ld3(D2), o, d, tmin, t, u, v) && (t <= best_t);
+          } else {
+            if (STATS) st.curves++;
+            float4 cp[4] = {D0, D1, D2, D3};
+            ok = curve_test(cp, o, d, tmin, best_t, t, u, v);
+          }
+          if (ok && !ANY && t == best_t && hit.slot != kNone) ok = sc.slot_meta[cur].x < sc.slot_meta[hit.slot].x;
+          if (ok) {
+            best_t = t;
+            hit.t = t, hit.u = u, hit.v = v, hit.slot = cur;
+          }
+          if (ANY && ok) {
+            sink.done(tag, hit, true);
+            state = kStIdle;
+          } else {
+            cur++;
+            if (cur < end) need_load = true;  // next primitive of the same leaf
+            else advance = true;              // leaf done: pop
+          }
+        }
+      }
+    }
+    // ---- common tail: pop / finish / decode the next item, then ONE load site for every lane that moved
+    if (advance) {
+      if (!have_next) {
+        if (sp == 0) {
+          sink.done(tag, hit, false);
+          state = kStIdle;
+          advance = false;
+        } else {
+          sp--;
+          next = stk_base[(uint32_t)sp * stride];
+        }
+      }
+      if (advance) {
+        need_load = true;
+        if (next & kLeafBit) {
+          cur = (next & 0x3FFFFFFFu) >> 3;
+          end = cur + (next & 7u) + 1u;
+          state = (CURVES && (next & kCurveBit)) ? kStCurve : kStTri;
+        } else {
+          cur = next;
+          state = kStNode;
+        }
+      }
+    }
+    if (need_load) {
+      const float4* g = (state == kStNode) ? reinterpret_cast<const float4*>(sc.nodes + cur) : (sc.slots + (size_t)cur * 4);
+      D0 = g[0], D1 = g[1], D2 = g[2];
+      if (state != kStTri) D3 = g[3];
+    }
+  }
+}
+
+}  // namespace pb

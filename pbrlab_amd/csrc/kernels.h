@@ -30,13 +30,18 @@ struct PathState {
 
 enum : uint32_t { kFlagNotFirst = 1u, kFlagSss = 2u };
 enum : uint32_t { kShNormal = 0u, kShSssEntry = 1u, kShSssExit = 2u };
-enum : uint32_t { kCntIn = 0, kCntOut, kCntPrincipled, kCntHair, kCntSss, kCntShadow, kCntOverflow, kCntNum = 8 };
+enum : uint32_t {
+  kCntIn = 0, kCntOut, kCntPrincipled, kCntHair, kCntSss, kCntShadow, kCntOverflow, kCntHeadClosest, kCntHeadShadow,
+  kCntNum = 12
+};
 enum : uint32_t {
   kStatClosestRays = 0, kStatClosestNodes, kStatClosestTris, kStatClosestCurves,
-  kStatShadowRays, kStatShadowNodes, kStatShadowTris, kStatShadowCurves, kStatNum
+  kStatShadowRays, kStatShadowNodes, kStatShadowTris, kStatShadowCurves,
+  kStatPvItNode, kStatPvItTri, kStatPvItCurve, kStatPvItRefill, kStatPvLnNode, kStatPvLnTri, kStatPvLnCurve, kStatNum
 };
 
-constexpr uint32_t kTraceGridCap = 256 * 16;  // blocks: 256 CUs x (<=4 resident + queued)
+constexpr uint32_t kTraceBlocksPerCU = (160 / kStackDepth) < 8 ? (160 / kStackDepth) : 8;  // LDS: kStackDepth KiB per block
+constexpr uint32_t kTraceGridCap = 256 * kTraceBlocksPerCU;        // persistent traversal: exactly the resident blocks
 constexpr uint32_t kShadeGridCap = 256 * 8;
 
 struct HookHit {  // == pbrhip_hit == TraceResult (raytracer.h:9-17)

@@ -14,6 +14,7 @@
 //
 // and k_generate (render.cc:160-171) / k_accumulate (render.cc:175-183) bracket a chunk of passes.
 #include "dshade.h"
+#include "dtrace_pv.h"
 #include "kernels.h"
 
 namespace pb {
@@ -67,19 +68,28 @@ __global__ __launch_bounds__(kBlock) void k_generate(PathState P, Camera cam, co
 }
 
 // ------------------------------------------------------------------ k_trace_closest / k_trace_shadow
-template <bool STATS>
-__global__ __launch_bounds__(kBlock) void k_trace_closest(PathState P, DScene sc, uint32_t count_idx) {
-  __shared__ uint32_t stk[kStackDepth * kBlock];
-  const uint32_t n = P.counts[count_idx];
-  TravStats st = {0u, 0u, 0u};
-  uint32_t overflow = 0u;
-  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-    uint32_t p = P.q_in[i];
-    float4 o4 = P.ray_o[p], d4 = P.ray_d[p];
-    Hit h;
-    traverse<false, STATS>(sc, ld3(o4), ld3(d4), o4.w, d4.w, h, stk + threadIdx.x, kBlock, st, &overflow);
-    P.hit[p] = make_float4(h.t, h.u, h.v, __uint_as_float(h.slot));
+// Persistent phase-voting traversal (dtrace_pv.h).  The grid is sized to the chip, not to the ray count;
+// rays are dealt from the queue through P.counts[kCntHeadClosest / kCntHeadShadow].
+struct ClosestSink {
+  const PathState& P;
+  __device__ __forceinline__ void load(uint32_t idx, uint32_t& tag, V3& o, V3& d, float& tmin, float& tmax) const {
+    tag = P.q_in[idx];
+    float4 o4 = P.ray_o[tag], d4 = P.ray_d[tag];
+    o = ld3(o4), d = ld3(d4), tmin = o4.w, tmax = d4.w;
   }
+  __device__ __forceinline__ void done(uint32_t tag, const Hit& h, bool) const {
+    P.hit[tag] = make_float4(h.t, h.u, h.v, __uint_as_float(h.slot));
+  }
+};
+
+template <bool STATS, bool CURVES>
+__global__ __launch_bounds__(kBlock) void k_trace_closest(PathState P, DScene sc) {
+  __shared__ uint32_t stk[kStackDepth * kBlock];
+  const uint32_t n = P.counts[kCntIn];
+  TravStats st = {};
+  uint32_t overflow = 0u;
+  ClosestSink sink = {P};
+  trace_pv<false, STATS, CURVES>(sc, n, &P.counts[kCntHeadClosest], sink, stk + threadIdx.x, kBlock, st, &overflow);
   if (overflow) P.counts[kCntOverflow] = 1u;
   if (STATS) {
     uint32_t a = wave_sum(st.nodes), b = wave_sum(st.tris), c = wave_sum(st.curves);
@@ -88,6 +98,13 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(PathState P, DScene sc
       atomicAdd(&P.stats[kStatClosestTris], (unsigned long long)b);
       atomicAdd(&P.stats[kStatClosestCurves], (unsigned long long)c);
       if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&P.stats[kStatClosestRays], (unsigned long long)n);
+      atomicAdd(&P.stats[kStatPvItNode], (unsigned long long)st.it_node);
+      atomicAdd(&P.stats[kStatPvItTri], (unsigned long long)st.it_tri);
+      atomicAdd(&P.stats[kStatPvItCurve], (unsigned long long)st.it_curve);
+      atomicAdd(&P.stats[kStatPvItRefill], (unsigned long long)st.it_refill);
+      atomicAdd(&P.stats[kStatPvLnNode], (unsigned long long)st.ln_node);
+      atomicAdd(&P.stats[kStatPvLnTri], (unsigned long long)st.ln_tri);
+      atomicAdd(&P.stats[kStatPvLnCurve], (unsigned long long)st.ln_curve);
     }
   }
 }
@@ -96,28 +113,34 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(PathState P, DScene sc
 //   kShNormal   L += c_vis when unoccluded
 //   kShSssEntry A  = 0 + c_vis when unoccluded (first NEE of a path that entered the medium)
 //   kShSssExit  L += unoccluded ? c_vis : c_occ
-template <bool STATS>
-__global__ __launch_bounds__(kBlock) void k_trace_shadow(PathState P, DScene sc) {
-  __shared__ uint32_t stk[kStackDepth * kBlock];
-  const uint32_t n = P.counts[kCntShadow];
-  TravStats st = {0u, 0u, 0u};
-  uint32_t overflow = 0u;
-  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-    float4 o4 = P.sh_o[i], d4 = P.sh_d[i];
-    Hit h;
-    bool occluded = traverse<true, STATS>(sc, ld3(o4), ld3(d4), o4.w, d4.w, h, stk + threadIdx.x, kBlock, st, &overflow);
+struct ShadowSink {
+  const PathState& P;
+  __device__ __forceinline__ void load(uint32_t idx, uint32_t& tag, V3& o, V3& d, float& tmin, float& tmax) const {
+    tag = idx;
+    float4 o4 = P.sh_o[idx], d4 = P.sh_d[idx];
+    o = ld3(o4), d = ld3(d4), tmin = o4.w, tmax = d4.w;
+  }
+  __device__ __forceinline__ void done(uint32_t i, const Hit&, bool occluded) const {
     float4 c = P.sh_c[i], e = P.sh_e[i];
     uint32_t p = __float_as_uint(c.w), mode = __float_as_uint(e.w);
     if (mode == kShSssEntry) {
       if (!occluded) P.sss_A[p] = make_float4(0.0f + c.x, 0.0f + c.y, 0.0f + c.z, 0.0f);
-    } else {
+    } else if (!occluded || mode == kShSssExit) {
       V3 add = occluded ? V3(e.x, e.y, e.z) : V3(c.x, c.y, c.z);
-      if (!occluded || mode == kShSssExit) {
-        float4 L = P.L[p];
-        P.L[p] = make_float4(L.x + add.x, L.y + add.y, L.z + add.z, L.w);
-      }
+      float4 L = P.L[p];
+      P.L[p] = make_float4(L.x + add.x, L.y + add.y, L.z + add.z, L.w);
     }
   }
+};
+
+template <bool STATS, bool CURVES>
+__global__ __launch_bounds__(kBlock) void k_trace_shadow(PathState P, DScene sc) {
+  __shared__ uint32_t stk[kStackDepth * kBlock];
+  const uint32_t n = P.counts[kCntShadow];
+  TravStats st = {};
+  uint32_t overflow = 0u;
+  ShadowSink sink = {P};
+  trace_pv<true, STATS, CURVES>(sc, n, &P.counts[kCntHeadShadow], sink, stk + threadIdx.x, kBlock, st, &overflow);
   if (overflow) P.counts[kCntOverflow] = 1u;
   if (STATS) {
     uint32_t a = wave_sum(st.nodes), b = wave_sum(st.tris), c = wave_sum(st.curves);
@@ -559,12 +582,12 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(PathState P, const uint32
 __global__ __launch_bounds__(kBlock) void k_hook_closest(DScene sc, const float4* __restrict__ rays, uint32_t n,
                                                          HookHit* __restrict__ out, uint32_t* overflow_flag) {
   __shared__ uint32_t stk[kStackDepth * kBlock];
-  TravStats st = {0u, 0u, 0u};
+  TravStats st = {};
   uint32_t overflow = 0u;
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
     float4 o4 = rays[2 * i], d4 = rays[2 * i + 1];
     Hit h;
-    traverse<false, false>(sc, ld3(o4), ld3(d4), o4.w, fminf(d4.w, INFINITY), h, stk + threadIdx.x, kBlock, st, &overflow);
+    traverse<false, false, true>(sc, ld3(o4), ld3(d4), o4.w, fminf(d4.w, INFINITY), h, stk + threadIdx.x, kBlock, st, &overflow);
     HookHit r;  // TraceResult defaults (raytracer.h:9-17)
     r.ng[0] = 1.f, r.ng[1] = 0.f, r.ng[2] = 0.f, r.t = 1.f, r.u = 0.f, r.v = 0.f;
     r.instance_id = r.geom_id = r.prim_id = kNone;
@@ -582,12 +605,12 @@ __global__ __launch_bounds__(kBlock) void k_hook_closest(DScene sc, const float4
 __global__ __launch_bounds__(kBlock) void k_hook_any(DScene sc, const float4* __restrict__ rays, uint32_t n,
                                                      uint8_t* __restrict__ out, uint32_t* overflow_flag) {
   __shared__ uint32_t stk[kStackDepth * kBlock];
-  TravStats st = {0u, 0u, 0u};
+  TravStats st = {};
   uint32_t overflow = 0u;
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
     float4 o4 = rays[2 * i], d4 = rays[2 * i + 1];
     Hit h;
-    out[i] = traverse<true, false>(sc, ld3(o4), ld3(d4), o4.w, fminf(d4.w, INFINITY), h, stk + threadIdx.x, kBlock, st,
+    out[i] = traverse<true, false, true>(sc, ld3(o4), ld3(d4), o4.w, fminf(d4.w, INFINITY), h, stk + threadIdx.x, kBlock, st,
                                    &overflow)
                  ? 1
                  : 0;
@@ -600,6 +623,7 @@ __global__ void k_advance(uint32_t* counts) {
   if (threadIdx.x == 0) {
     counts[kCntIn] = counts[kCntOut];
     counts[kCntOut] = 0, counts[kCntPrincipled] = 0, counts[kCntHair] = 0, counts[kCntSss] = 0, counts[kCntShadow] = 0;
+    counts[kCntHeadClosest] = 0, counts[kCntHeadShadow] = 0;
   }
 }
 
@@ -617,17 +641,19 @@ void launch_generate(hipStream_t s, const PathState& P, const Camera& cam, const
 }
 void launch_trace_closest(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, bool stats) {
   dim3 g(grid_for(n_upper, kTraceGridCap));
-  if (stats)
-    hipLaunchKernelGGL(k_trace_closest<true>, g, dim3(kBlock), 0, s, P, sc, (uint32_t)kCntIn);
-  else
-    hipLaunchKernelGGL(k_trace_closest<false>, g, dim3(kBlock), 0, s, P, sc, (uint32_t)kCntIn);
+  const bool curves = sc.num_curves != 0;
+  if (stats && curves) hipLaunchKernelGGL((k_trace_closest<true, true>), g, dim3(kBlock), 0, s, P, sc);
+  else if (stats) hipLaunchKernelGGL((k_trace_closest<true, false>), g, dim3(kBlock), 0, s, P, sc);
+  else if (curves) hipLaunchKernelGGL((k_trace_closest<false, true>), g, dim3(kBlock), 0, s, P, sc);
+  else hipLaunchKernelGGL((k_trace_closest<false, false>), g, dim3(kBlock), 0, s, P, sc);
 }
 void launch_trace_shadow(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, bool stats) {
   dim3 g(grid_for(n_upper, kTraceGridCap));
-  if (stats)
-    hipLaunchKernelGGL(k_trace_shadow<true>, g, dim3(kBlock), 0, s, P, sc);
-  else
-    hipLaunchKernelGGL(k_trace_shadow<false>, g, dim3(kBlock), 0, s, P, sc);
+  const bool curves = sc.num_curves != 0;
+  if (stats && curves) hipLaunchKernelGGL((k_trace_shadow<true, true>), g, dim3(kBlock), 0, s, P, sc);
+  else if (stats) hipLaunchKernelGGL((k_trace_shadow<true, false>), g, dim3(kBlock), 0, s, P, sc);
+  else if (curves) hipLaunchKernelGGL((k_trace_shadow<false, true>), g, dim3(kBlock), 0, s, P, sc);
+  else hipLaunchKernelGGL((k_trace_shadow<false, false>), g, dim3(kBlock), 0, s, P, sc);
 }
 void launch_surface(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc) {
   hipLaunchKernelGGL(k_surface, dim3(grid_for(n_upper, kShadeGridCap)), dim3(kBlock), 0, s, P, sc, rng_inc);

@@ -6,6 +6,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -538,6 +539,8 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
   d.light_heads = s->d_heads.p, d.lprim_cdf = s->d_lprim_cdf.p, d.lrecs = s->d_lrecs.p;
   d.num_nodes = (uint32_t)bvh.nodes.size(), d.num_slots = ns, d.num_lights = (uint32_t)s->lights.size();
   d.num_materials = (uint32_t)mats.size();
+  d.num_curves = 0;
+  for (uint8_t kd : kinds) d.num_curves += kd ? 1u : 0u;
   s->committed = true;
   return PBRHIP_OK;
 }
@@ -629,6 +632,7 @@ static Camera make_camera(const pbrhip_scene* s, uint32_t width, uint32_t height
 }
 
 // ------------------------------------------------------------------ render
+static constexpr uint64_t kBytesPerPath = 5 * 16 + 8 + 4 + 6 * 16 + 5 * 4 + 4 * 16;  // ensure_paths()
 namespace {
 struct Timer {
   pbrhip_scene* s;
@@ -729,7 +733,16 @@ static int render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volat
   const bool want_stats = (d->flags & PBRHIP_RENDER_STATS) != 0;
   Timer tm{s, (d->flags & PBRHIP_RENDER_TIMING) != 0};
   if (npix > 0 && d->num_sample > 0) {
-    uint64_t max_paths = d->max_paths_in_flight ? d->max_paths_in_flight : (32ull << 20);
+    // default: as many paths in flight as half of the free HBM holds (288 GB: a whole 1080p x 64 spp frame,
+    // 132.7 M paths x ~272 B, is one chunk) -- fewer, larger launches and one tail instead of many
+    uint64_t max_paths = d->max_paths_in_flight;
+    if (!max_paths) {
+      size_t free_b = 0, total_b = 0;
+      HIPCHK(hipMemGetInfo(&free_b, &total_b));
+      size_t have = 0;
+      for (auto* b : {&s->ray_o, &s->ray_d, &s->thr, &s->L, &s->hit}) have += b->n * 16;
+      max_paths = std::min<uint64_t>(256ull << 20, std::max<uint64_t>(1ull << 20, (free_b / 2 + have * 3) / kBytesPerPath));
+    }
     uint32_t chunk_passes = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(d->num_sample, max_paths / npix));
     if ((uint64_t)chunk_passes * npix >= (1ull << 32)) chunk_passes = (uint32_t)(((1ull << 32) - 1) / npix);
     if (int rc = ensure_paths(s, (size_t)chunk_passes * npix)) return rc;
@@ -803,6 +816,12 @@ static int render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volat
       S.closest_tris = hs[kStatClosestTris], S.closest_curves = hs[kStatClosestCurves];
       S.shadow_rays = hs[kStatShadowRays], S.shadow_nodes = hs[kStatShadowNodes];
       S.shadow_tris = hs[kStatShadowTris], S.shadow_curves = hs[kStatShadowCurves];
+      if (getenv("PBRHIP_PV_STATS"))
+        fprintf(stderr, "pv closest: it node %llu tri %llu curve %llu refill %llu | lanes/iter node %.1f tri %.1f curve %.1f\n",
+                hs[kStatPvItNode], hs[kStatPvItTri], hs[kStatPvItCurve], hs[kStatPvItRefill],
+                hs[kStatPvLnNode] / (double)std::max<unsigned long long>(1, hs[kStatPvItNode]),
+                hs[kStatPvLnTri] / (double)std::max<unsigned long long>(1, hs[kStatPvItTri]),
+                hs[kStatPvLnCurve] / (double)std::max<unsigned long long>(1, hs[kStatPvItCurve]));
     }
   } else {
     HIPCHK(hipStreamSynchronize(st));

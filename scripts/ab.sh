@@ -1,0 +1,13 @@
+#!/bin/bash
+# A/B bench of library variants on the GPU box: scripts/ab.sh <bench args> -- lib1.so lib2.so ...
+args=()
+while [ "$1" != "--" ] && [ $# -gt 0 ]; do args+=("$1"); shift; done
+shift
+for lib in "$@"; do
+  PBRHIP_LIB=$(realpath $lib) python bench.py --no-cpu-baseline "${args[@]}" 2>&1 | tail -1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.read())
+r = d['roofline']
+print('$lib', 'Msamples/s %.1f' % d['value'], 'ms/step %.1f' % d['ms_per_step'], 'frac %.3f' % r['frac'], 'launches %d' % r['launches_per_step'], 'depth', d['config'].get('bvh_depth'), {k: round(v,1) for k,v in r['kernel_ms_per_step'].items()})
+"
+done
