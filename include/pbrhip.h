@@ -90,8 +90,8 @@ typedef struct {
   uint64_t closest_rays, closest_nodes, closest_tris, closest_curves; /* PBRHIP_RENDER_STATS */
   uint64_t shadow_rays, shadow_nodes, shadow_tris, shadow_curves;
   /* PBRHIP_RENDER_TIMING: total ms and launch count per kernel */
-  double ms_generate, ms_trace_closest, ms_surface, ms_shade_principled, ms_shade_hair, ms_sss_step, ms_trace_shadow,
-      ms_accumulate;
+  double ms_generate, ms_trace_closest, ms_surface /* = k_classify */, ms_shade_principled, ms_shade_hair, ms_sss_step,
+      ms_trace_shadow, ms_accumulate, ms_compact;
   uint64_t n_trace_closest, n_trace_shadow, n_surface, n_shade_principled, n_shade_hair, n_sss_step;
   double ms_total; /* wall time of the call measured on the host */
 } pbrhip_render_stats;

@@ -50,7 +50,7 @@ class RenderStats(C.Structure):
                                            "closest_tris", "closest_curves", "shadow_rays", "shadow_nodes",
                                            "shadow_tris", "shadow_curves")] +
                 [(n, C.c_double) for n in ("ms_generate", "ms_trace_closest", "ms_surface", "ms_shade_principled",
-                                           "ms_shade_hair", "ms_sss_step", "ms_trace_shadow", "ms_accumulate")] +
+                                           "ms_shade_hair", "ms_sss_step", "ms_trace_shadow", "ms_accumulate", "ms_compact")] +
                 [(n, C.c_uint64) for n in ("n_trace_closest", "n_trace_shadow", "n_surface", "n_shade_principled",
                                            "n_shade_hair", "n_sss_step")] + [("ms_total", C.c_double)])
 

@@ -5,9 +5,8 @@
 //   slots      leaf-ordered primitives, 64 B per slot (4 x float4):
 //                triangle: v0.xyz,_ | v1.xyz,_ | v2.xyz,_ | unused     (world space)
 //                curve   : 4 cubic Bezier control points xyz + radius  (world space)
-//   slot_meta  uint4 per slot: canonical primitive id (gid), material id, light record, flags
-//   slot_ids   uint4 per slot: instance_id, geom_id, prim_id, kind     (TraceResult ids)
-//   slot_nrm   3 x float4 per slot: per-corner shading normals (triangles with normals only)
+//   shade      one 128-byte line per slot with everything a hit needs for shading: triangle corners,
+//              corner normals, canonical primitive id (gid), material id, light record, flags, TraceResult ids
 //   materials  one closure record per material (ParamToBsdf hoisted to commit time)
 //   lights     per-light and per-light-primitive sampling tables (LightManager::Commit)
 #pragma once
@@ -36,6 +35,21 @@ static_assert(sizeof(BvhNode) == 64, "node must be 64 B");
 
 constexpr uint32_t kSlotHasNormals = 1u;
 constexpr uint32_t kSlotIsCurve = 2u;
+constexpr uint32_t kSlotMatHair = 4u;   // material kind, denormalised here so a hit can be routed without
+constexpr uint32_t kSlotMatNone = 8u;   // touching the material table (shader.cc:11-17 for "none")
+
+struct alignas(128) ShadeRec {
+  float v[9];   // triangle corners xyz (world); unused for curves (their control points live in `slots`)
+  float n[9];   // corner shading normals xyz (kSlotHasNormals)
+  uint32_t gid, material, lightrec, flags;
+  uint32_t instance_id, geom_id, prim_id;
+  uint32_t pad[7];
+};
+static_assert(sizeof(ShadeRec) == 128, "one cache line per primitive");
+
+// hit record code (P.hit[].w): slot | kind << 28 ; kNone = miss
+constexpr uint32_t kHitSlotMask = 0x0FFFFFFFu;
+constexpr uint32_t kHitKindPrincipled = 0u, kHitKindHair = 1u, kHitKindNoMaterial = 2u;
 
 // closure set of one material == struct CyclesPrincipledBsdf (cycles-principled-shader.cc:20-45)
 struct PrincipledBsdf {
@@ -87,9 +101,7 @@ struct LightHead {
 struct DScene {
   const BvhNode* nodes;
   const float4* slots;
-  const uint4* slot_meta;
-  const uint4* slot_ids;
-  const float4* slot_nrm;
+  const ShadeRec* shade;
   const Material* materials;
   const float* light_cdf;
   const LightHead* light_heads;

@@ -16,22 +16,26 @@ struct Surface {
 };
 
 // TraceResultToSufaceInfo (shader-utils.h:131-164) + Scene::FetchMeshShadingNormal (scene.cc:210-228,
-// mesh/triangle-mesh.cc:62-101) + EmbreeRayToTraceResult's normalisation (raytracer_impl.cc:221-240)
-__device__ __forceinline__ Surface make_surface(const DScene& sc, V3 org, V3 dir, const Hit& h) {
+// mesh/triangle-mesh.cc:62-101) + EmbreeRayToTraceResult's normalisation (raytracer_impl.cc:221-240).
+// Reads ONE 128-byte ShadeRec line (plus the 64-byte control-point slot for curves).
+__device__ __forceinline__ Surface make_surface(const DScene& sc, V3 org, V3 dir, const Hit& h, uint32_t* instance_id = nullptr) {
   Surface s;
-  uint4 meta = sc.slot_meta[h.slot];
-  s.material = meta.y, s.lightrec = meta.z, s.flags = meta.w;
-  const float4* g = sc.slots + (size_t)h.slot * 4;
-  if (meta.w & kSlotIsCurve) {
+  const float4* r = reinterpret_cast<const float4*>(sc.shade + h.slot);
+  float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5];
+  // words: v[0..8] n[9..17] gid(18) material(19) lightrec(20) flags(21) instance(22) geom(23) prim(24)
+  s.material = __float_as_uint(r4.w), s.lightrec = __float_as_uint(r5.x), s.flags = __float_as_uint(r5.y);
+  if (instance_id) *instance_id = __float_as_uint(r5.z);
+  if (s.flags & kSlotIsCurve) {
+    const float4* g = sc.slots + (size_t)h.slot * 4;
     float4 cp[4] = {g[0], g[1], g[2], g[3]};
     s.n_g = normalize_raw(bezier_tangent(cp, h.u));
     s.n_s = s.n_g;  // scene.cc:222-223
   } else {
-    V3 v0 = ld3(g[0]), v1 = ld3(g[1]), v2 = ld3(g[2]);
+    V3 v0(r0.x, r0.y, r0.z), v1(r0.w, r1.x, r1.y), v2(r1.z, r1.w, r2.x);
     s.n_g = normalize_raw(cross(v1 - v0, v2 - v0));
-    if (meta.w & kSlotHasNormals) {
-      const float4* n = sc.slot_nrm + (size_t)h.slot * 3;
-      s.n_s = vnormalize(lerp3(ld3(n[0]), ld3(n[1]), ld3(n[2]), h.u, h.v));
+    if (s.flags & kSlotHasNormals) {
+      V3 n0(r2.y, r2.z, r2.w), n1(r3.x, r3.y, r3.z), n2(r3.w, r4.x, r4.y);
+      s.n_s = vnormalize(lerp3(n0, n1, n2, h.u, h.v));
     } else {
       s.n_s = vnormalize(cross(v1 - v0, v2 - v1));  // CalcGeometryNormal, triangle-mesh.cc:181-184
     }

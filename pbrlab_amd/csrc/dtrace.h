@@ -135,7 +135,7 @@ __device__ __forceinline__ bool leaf_test(const DScene& sc, uint32_t leaf, V3 o,
     if (!ok) continue;
     if (ANY) return true;
     if (t == best_t && hit.slot != kNone) {  // tie: the smaller canonical primitive id wins
-      if (!(sc.slot_meta[s].x < sc.slot_meta[hit.slot].x)) continue;
+      if (!(sc.shade[s].gid < sc.shade[hit.slot].gid)) continue;
     }
     best_t = t;
     hit.t = t, hit.u = u, hit.v = v, hit.slot = s;

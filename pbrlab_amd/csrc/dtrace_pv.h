@@ -19,7 +19,10 @@
 namespace pb {
 
 constexpr uint32_t kPvBatch = 512;        // rays grabbed per atomicAdd
-constexpr int kPvRefillIdle = 24;         // refill when at least this many lanes are idle
+#ifndef PB_REFILL
+#define PB_REFILL 24
+#endif
+constexpr int kPvRefillIdle = PB_REFILL;         // refill when at least this many lanes are idle
 
 enum : uint32_t { kStIdle = 0, kStNode = 1, kStTri = 2, kStCurve = 3 };
 
@@ -143,7 +146,7 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
             float4 cp[4] = {D0, D1, D2, D3};
             ok = curve_test(cp, o, d, tmin, best_t, t, u, v);
           }
-          if (ok && !ANY && t == best_t && hit.slot != kNone) ok = sc.slot_meta[cur].x < sc.slot_meta[hit.slot].x;
+          if (ok && !ANY && t == best_t && hit.slot != kNone) ok = sc.shade[cur].gid < sc.shade[hit.slot].gid;
           if (ok) {
             best_t = t;
             hit.t = t, hit.u = u, hit.v = v, hit.slot = cur;

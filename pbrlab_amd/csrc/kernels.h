@@ -15,20 +15,24 @@ namespace pb {
 //   random-walk state, touched only by paths inside a medium:                                       96 B
 //     sss_sigt (sigma_t.rgb, step index) | sss_sigs (sigma_s.rgb, entry instance id) | sss_thr (walk throughput)
 //     sss_pdf (channel pdf of the pending step) | sss_ez (entry frame normal) | sss_A (resolved first NEE)
-//   queues: q_in/q_out (ping-pong), q_principled, q_hair, q_sss (u32 each) and the shadow queue
-//     sh_o (org, tmin) | sh_d (dir, tmax) | sh_c (contribution if visible, path slot) | sh_e (if occluded, mode)
+//   queues (u32 path slots): q_in/q_out (ping-pong), q_principled, q_hair, q_sss, q_shadow; the shadow-ray payload
+//     sits at the path's own slot: sh_o (org, tmin) | sh_d (dir, tmax) | sh_c (contribution if visible) | sh_e (if occluded, mode)
 struct PathState {
   float4 *ray_o, *ray_d, *thr, *L, *hit;
   uint64_t* rng;
   uint32_t* flags;
   float4 *sss_sigt, *sss_sigs, *sss_thr, *sss_pdf, *sss_ez, *sss_A;
-  uint32_t *q_in, *q_out, *q_principled, *q_hair, *q_sss;
+  uint32_t *q_in, *q_out, *q_principled, *q_hair, *q_sss, *q_shadow;
   float4 *sh_o, *sh_d, *sh_c, *sh_e;
   uint32_t* counts;              // kCnt*
   unsigned long long* stats;     // kStat*
 };
 
-enum : uint32_t { kFlagNotFirst = 1u, kFlagSss = 2u };
+enum : uint32_t { kFlagNotFirst = 1u };
+constexpr uint32_t kQSssBit = 0x80000000u, kQPathMask = 0x7FFFFFFFu;  // queue entry = path slot | in-medium bit
+// shade-kernel result word (written over the kernel's own queue entry): path slot (28 bits) | flags
+constexpr uint32_t kRPathMask = 0x0FFFFFFFu, kRShadow = 1u << 28, kRAlive = 1u << 29;
+constexpr uint64_t kMaxPathsInFlight = (1ull << 28) - 1;
 enum : uint32_t { kShNormal = 0u, kShSssEntry = 1u, kShSssExit = 2u };
 enum : uint32_t {
   kCntIn = 0, kCntOut, kCntPrincipled, kCntHair, kCntSss, kCntShadow, kCntOverflow, kCntHeadClosest, kCntHeadShadow,
@@ -54,7 +58,8 @@ void launch_generate(hipStream_t s, const PathState& P, const Camera& cam, const
                      uint32_t npaths, uint32_t width, uint32_t first_pass, uint64_t seed_seq);
 void launch_trace_closest(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, bool stats);
 void launch_trace_shadow(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, bool stats);
-void launch_surface(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc);
+void launch_classify(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper);
+void launch_compact(hipStream_t s, const PathState& P, uint32_t n_upper);
 void launch_shade_principled(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc);
 void launch_shade_hair(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc);
 void launch_sss_step(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc);

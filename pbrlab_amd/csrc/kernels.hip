@@ -5,9 +5,9 @@
 // (one atomicAdd per wave).  One iteration of the host loop (render.cpp) =
 //
 //   k_trace_closest   rtcIntersect1          (raytracer_impl.cc:268-278)  active paths -> hit records
-//   k_surface         GetRadiance head       (render.cc:31-68): miss / implicit light + MIS / Russian
-//                                            roulette, then routes each path to its closure queue
-//   k_shade_principled CyclesPrincipledShader (cycles-principled-shader.cc:414-484) incl. SSS entry
+//   k_classify        routes each path to its closure queue by the material kind stored in the hit code
+//   k_shade_principled GetRadiance head (render.cc:31-68: implicit light + MIS, Russian roulette) +
+//                     CyclesPrincipledShader (cycles-principled-shader.cc:414-484) incl. SSS entry
 //   k_shade_hair      HairShader             (hair-shader.cc:153-229)
 //   k_sss_step        RandomWalkSubsurface loop body + exit (random-walk-sss.h:287-405)
 //   k_trace_shadow    rtcOccluded1 + tail of DirectIllumination (shader-utils.h:192-208)
@@ -72,8 +72,9 @@ __global__ __launch_bounds__(kBlock) void k_generate(PathState P, Camera cam, co
 // rays are dealt from the queue through P.counts[kCntHeadClosest / kCntHeadShadow].
 struct ClosestSink {
   const PathState& P;
+  const DScene& sc;
   __device__ __forceinline__ void load(uint32_t idx, uint32_t& tag, V3& o, V3& d, float& tmin, float& tmax) const {
-    tag = P.q_in[idx];
+    tag = P.q_in[idx] & kQPathMask;
     float4 o4 = P.ray_o[tag], d4 = P.ray_d[tag];
     o = ld3(o4), d = ld3(d4), tmin = o4.w, tmax = d4.w;
   }
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(PathState P, DScene sc
   const uint32_t n = P.counts[kCntIn];
   TravStats st = {};
   uint32_t overflow = 0u;
-  ClosestSink sink = {P};
+  ClosestSink sink = {P, sc};
   trace_pv<false, STATS, CURVES>(sc, n, &P.counts[kCntHeadClosest], sink, stk + threadIdx.x, kBlock, st, &overflow);
   if (overflow) P.counts[kCntOverflow] = 1u;
   if (STATS) {
@@ -116,13 +117,13 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(PathState P, DScene sc
 struct ShadowSink {
   const PathState& P;
   __device__ __forceinline__ void load(uint32_t idx, uint32_t& tag, V3& o, V3& d, float& tmin, float& tmax) const {
-    tag = idx;
-    float4 o4 = P.sh_o[idx], d4 = P.sh_d[idx];
+    tag = P.q_shadow[idx];
+    float4 o4 = P.sh_o[tag], d4 = P.sh_d[tag];
     o = ld3(o4), d = ld3(d4), tmin = o4.w, tmax = d4.w;
   }
-  __device__ __forceinline__ void done(uint32_t i, const Hit&, bool occluded) const {
-    float4 c = P.sh_c[i], e = P.sh_e[i];
-    uint32_t p = __float_as_uint(c.w), mode = __float_as_uint(e.w);
+  __device__ __forceinline__ void done(uint32_t p, const Hit&, bool occluded) const {
+    float4 c = P.sh_c[p], e = P.sh_e[p];
+    uint32_t mode = __float_as_uint(e.w);
     if (mode == kShSssEntry) {
       if (!occluded) P.sss_A[p] = make_float4(0.0f + c.x, 0.0f + c.y, 0.0f + c.z, 0.0f);
     } else if (!occluded || mode == kShSssExit) {
@@ -153,72 +154,179 @@ __global__ __launch_bounds__(kBlock) void k_trace_shadow(PathState P, DScene sc)
   }
 }
 
-// ------------------------------------------------------------------ k_surface (render.cc:31-68)
-__global__ __launch_bounds__(kBlock) void k_surface(PathState P, DScene sc, uint64_t rng_inc) {
-  const uint32_t n = P.counts[kCntIn];
-  const uint32_t n_round = (n + kBlock - 1) / kBlock * kBlock;
-  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_round; i += gridDim.x * kBlock) {
-    bool active = i < n;
-    uint32_t p = active ? P.q_in[i] : 0u;
-    bool to_sss = false, to_pr = false, to_hair = false;
-    if (active) {
-      uint32_t flags = P.flags[p];
-      if (flags & kFlagSss) {
-        to_sss = true;
-      } else {
-        float4 h4 = P.hit[p];
-        Hit h = {h4.x, h4.y, h4.z, __float_as_uint(h4.w)};
-        if (h.slot != kNone) {  // render.cc:34 (miss: no environment light)
-          float4 o4 = P.ray_o[p], d4 = P.ray_d[p];
-          V3 dir = ld3(d4);
-          Surface s = make_surface(sc, ld3(o4), dir, h);
-          float4 t4 = P.thr[p];
-          V3 thr = ld3(t4);
-          if (s.face == kFront && s.lightrec != kNone) {  // render.cc:43-62, LightManager::ImplicitAreaLight
-            const float4* lr = reinterpret_cast<const float4*>(sc.lrecs + s.lightrec);
-            float pdf_area = lr[0].w;
-            V3 emission = ld3(lr[4]);
-            float a2s = fabsf((h.t * h.t) / dot(s.n_s, dir));
-            float w = (flags & kFlagNotFirst) ? power_heuristic(t4.w, pdf_area * a2s) : 1.0f;
-            float4 L4 = P.L[p];
-            V3 L = ld3(L4) + w * emission * thr;
-            P.L[p] = mk4(L, L4.w);
-          }
-          Rng rng = {P.rng[p], rng_inc};
-          float rr = spectrum_norm(thr);  // render.cc:66-68 (Q1)
-          float u = draw(rng);
-          if (!(rr < u)) {
-            thr = thr * V3(1.0f / rr);
-            P.thr[p] = mk4(thr, t4.w);
-            P.rng[p] = rng.state;
-            P.flags[p] = flags | kFlagNotFirst;
-            if (s.material != kNone) {  // shader.cc:11-17: no material -> throughput 0 -> path ends
-              uint32_t kind = sc.materials[s.material].kind;
-              to_pr = (kind == kMatPrincipled);
-              to_hair = (kind == kMatHair);
-            }
-          }
-        }
+// ------------------------------------------------------------------ ordered stream compaction, few atomics
+// One global atomicAdd per output queue per TILE of kTileItems entries (one queue word saturates at ~88
+// atomics/us on this chip: a per-wave atomicAdd per append cost ~45 ms per kernel at 289 M entries).
+// A block reads kItemsPerThread strided entries per thread, ranks them with wave ballots, reduces the
+// per-(item row, wave) counts in LDS, reserves the tile's output range once, and scatters in input order.
+constexpr int kItemsPerThread = 8;
+constexpr int kTileItems = kItemsPerThread * kBlock;
+constexpr int kWavesPerBlock = kBlock / 64;
+
+template <int NQ>
+struct TileCompactor {
+  uint32_t (*wcount)[kItemsPerThread][kWavesPerBlock];  // [NQ] in LDS
+  uint32_t* base;                                        // [NQ] in LDS
+  uint32_t rank[kItemsPerThread];
+  // dest[j] in 0..NQ (0 = drop).  Call from all threads of the block.
+  __device__ __forceinline__ void run(const uint32_t dest[kItemsPerThread], uint32_t* const counters[NQ]) {
+    const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int j = 0; j < kItemsPerThread; j++) {
+      rank[j] = 0;
+#pragma unroll
+      for (int q = 0; q < NQ; q++) {
+        unsigned long long m = __ballot(dest[j] == (uint32_t)(q + 1));
+        if (lane == 0) wcount[q][j][wave] = (uint32_t)__popcll(m);
+        if (dest[j] == (uint32_t)(q + 1)) rank[j] = (uint32_t)__popcll(m & lt);
       }
     }
-    uint32_t k;
-    k = queue_append(&P.counts[kCntSss], to_sss);
-    if (to_sss) P.q_sss[k] = p;
-    k = queue_append(&P.counts[kCntPrincipled], to_pr);
-    if (to_pr) P.q_principled[k] = p;
-    k = queue_append(&P.counts[kCntHair], to_hair);
-    if (to_hair) P.q_hair[k] = p;
+    __syncthreads();
+    if (threadIdx.x < NQ) {
+      const int q = threadIdx.x;
+      uint32_t total = 0;
+      for (int j = 0; j < kItemsPerThread; j++)
+        for (int w = 0; w < kWavesPerBlock; w++) {
+          uint32_t c = wcount[q][j][w];
+          wcount[q][j][w] = total;  // exclusive prefix in input order
+          total += c;
+        }
+      base[q] = total ? atomicAdd(counters[q], total) : 0u;
+    }
+    __syncthreads();
+  }
+  __device__ __forceinline__ uint32_t slot(int j, uint32_t dest_j) const {
+    return base[dest_j - 1] + wcount[dest_j - 1][j][threadIdx.x >> 6] + rank[j];
+  }
+};
+
+// ------------------------------------------------------------------ k_classify
+// Queue entries are path slots; bit 31 marks a path that is inside a medium (random-walk SSS).
+// Routes every traced path: in-medium -> q_sss; miss -> dropped (render.cc:34, no environment light);
+// hit -> q_hair / q_principled by the material kind denormalised into ShadeRec.flags.
+__global__ __launch_bounds__(kBlock) void k_classify(PathState P, DScene sc) {
+  __shared__ uint32_t wcount[3][kItemsPerThread][kWavesPerBlock];
+  __shared__ uint32_t base[3];
+  const uint32_t n = P.counts[kCntIn];
+  const uint32_t ntiles = (n + kTileItems - 1) / kTileItems;
+  uint32_t* const counters[3] = {&P.counts[kCntSss], &P.counts[kCntPrincipled], &P.counts[kCntHair]};
+  uint32_t* const queues[3] = {P.q_sss, P.q_principled, P.q_hair};
+  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    uint32_t p[kItemsPerThread], dest[kItemsPerThread];
+#pragma unroll
+    for (int j = 0; j < kItemsPerThread; j++) {
+      uint32_t i = tile * kTileItems + j * kBlock + threadIdx.x;
+      dest[j] = 0, p[j] = 0;
+      if (i < n) {
+        uint32_t e = P.q_in[i];
+        p[j] = e & kQPathMask;
+        dest[j] = (e & kQSssBit) ? 1u : 0xFFu;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kItemsPerThread; j++)
+      if (dest[j] == 0xFFu) {
+        uint32_t slot = __float_as_uint(P.hit[p[j]].w);
+        dest[j] = (slot == kNone) ? 0u : ((sc.shade[slot].flags & kSlotMatHair) ? 3u : 2u);
+      }
+    TileCompactor<3> tc = {wcount, base, {}};
+    tc.run(dest, counters);
+#pragma unroll
+    for (int j = 0; j < kItemsPerThread; j++)
+      if (dest[j]) queues[dest[j] - 1][tc.slot(j, dest[j])] = p[j];
+    __syncthreads();
   }
 }
 
+// ------------------------------------------------------------------ k_compact
+// The shade kernels overwrite their queue entry with  path | kRShadow | kRAlive | kQSssBit  instead of
+// appending; this pass turns the three result lists into the next trace queue and the shadow-ray queue.
+__global__ __launch_bounds__(kBlock) void k_compact(PathState P) {
+  __shared__ uint32_t wcount[2][kItemsPerThread][kWavesPerBlock];
+  __shared__ uint32_t base[2];
+  const uint32_t n0 = P.counts[kCntPrincipled], n1 = P.counts[kCntHair], n2 = P.counts[kCntSss];
+  const uint32_t n = n0 + n1 + n2;
+  const uint32_t ntiles = (n + kTileItems - 1) / kTileItems;
+  uint32_t* const counters[2] = {&P.counts[kCntOut], &P.counts[kCntShadow]};
+  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    uint32_t e[kItemsPerThread], d_out[kItemsPerThread], d_sh[kItemsPerThread];
+#pragma unroll
+    for (int j = 0; j < kItemsPerThread; j++) {
+      uint32_t i = tile * kTileItems + j * kBlock + threadIdx.x;
+      e[j] = 0;
+      if (i < n) e[j] = (i < n0) ? P.q_principled[i] : ((i < n0 + n1) ? P.q_hair[i - n0] : P.q_sss[i - n0 - n1]);
+      d_out[j] = (e[j] & kRAlive) ? 1u : 0u;
+      d_sh[j] = (e[j] & kRShadow) ? 2u : 0u;
+    }
+    // two independent streams share one pass: run the compactor once per stream
+    TileCompactor<2> ta = {wcount, base, {}};
+    {
+      uint32_t dest[kItemsPerThread];
+#pragma unroll
+      for (int j = 0; j < kItemsPerThread; j++) dest[j] = d_out[j];
+      ta.run(dest, counters);
+#pragma unroll
+      for (int j = 0; j < kItemsPerThread; j++)
+        if (dest[j]) P.q_out[ta.slot(j, 1u)] = e[j] & (kRPathMask | kQSssBit);
+      __syncthreads();
+    }
+    {
+      uint32_t dest[kItemsPerThread];
+#pragma unroll
+      for (int j = 0; j < kItemsPerThread; j++) dest[j] = d_sh[j];
+      ta.run(dest, counters);
+#pragma unroll
+      for (int j = 0; j < kItemsPerThread; j++)
+        if (dest[j]) P.q_shadow[ta.slot(j, 2u)] = e[j] & kRPathMask;
+      __syncthreads();
+    }
+  }
+}
+
+// Head of GetRadiance for one path that hit something (render.cc:39-68): surface, implicit area light with
+// MIS, Russian roulette.  Returns false when the path ends here.
+struct PathHead {
+  Hit h;
+  V3 dir, thr;
+  Surface s;
+  Rng rng;
+  uint32_t flags;
+};
+__device__ __forceinline__ bool path_head(const PathState& P, const DScene& sc, uint32_t p, uint64_t rng_inc, PathHead& c) {
+  float4 h4 = P.hit[p], o4 = P.ray_o[p], d4 = P.ray_d[p], t4 = P.thr[p];
+  c.h.t = h4.x, c.h.u = h4.y, c.h.v = h4.z, c.h.slot = __float_as_uint(h4.w);
+  c.dir = ld3(d4);
+  c.s = make_surface(sc, ld3(o4), c.dir, c.h);
+  c.thr = ld3(t4);
+  c.flags = P.flags[p];
+  if (c.s.face == kFront && c.s.lightrec != kNone) {  // render.cc:43-62, LightManager::ImplicitAreaLight
+    const float4* lr = reinterpret_cast<const float4*>(sc.lrecs + c.s.lightrec);
+    float pdf_area = lr[0].w;
+    V3 emission = ld3(lr[4]);
+    float a2s = fabsf((c.h.t * c.h.t) / dot(c.s.n_s, c.dir));
+    float w = (c.flags & kFlagNotFirst) ? power_heuristic(t4.w, pdf_area * a2s) : 1.0f;
+    float4 L4 = P.L[p];
+    P.L[p] = mk4(ld3(L4) + w * emission * c.thr, L4.w);
+  }
+  c.rng.state = P.rng[p], c.rng.inc = rng_inc;
+  float rr = spectrum_norm(c.thr);  // render.cc:66-68 (Q1)
+  float u = draw(c.rng);
+  if (rr < u) return false;
+  c.thr = c.thr * V3(1.0f / rr);
+  c.flags |= kFlagNotFirst;
+  return (c.s.flags & kSlotMatNone) == 0;  // shader.cc:11-17: no material -> throughput 0 -> path ends
+}
+
 // writes one shadow-queue entry
-__device__ __forceinline__ void put_shadow(const PathState& P, uint32_t k, V3 pos, const Nee& n, V3 c_vis, V3 c_occ,
-                                           uint32_t p, uint32_t mode) {
-  // ShadowRay (shader-utils.h:116-129): [kEps, max(kEps, dist - kEps)]  (Q9)
-  P.sh_o[k] = mk4(pos, kEps);
-  P.sh_d[k] = mk4(n.dir, smax(kEps, n.dist - kEps));
-  P.sh_c[k] = mk4(c_vis, __uint_as_float(p));
-  P.sh_e[k] = mk4(c_occ, __uint_as_float(mode));
+__device__ __forceinline__ void put_shadow(const PathState& P, V3 pos, const Nee& n, V3 c_vis, V3 c_occ, uint32_t p,
+                                           uint32_t mode) {
+  // ShadowRay (shader-utils.h:116-129): [kEps, max(kEps, dist - kEps)]  (Q9).  One shadow ray per path per
+  // iteration at most, so the payload lives at the path's own slot.
+  P.sh_o[p] = mk4(pos, kEps);
+  P.sh_d[p] = mk4(n.dir, smax(kEps, n.dist - kEps));
+  P.sh_c[p] = mk4(c_vis, 0.f);
+  P.sh_e[p] = mk4(c_occ, __uint_as_float(mode));
 }
 
 // ------------------------------------------------------------------ k_shade_principled
@@ -233,14 +341,13 @@ __global__ __launch_bounds__(kBlock) void k_shade_principled(PathState P, DScene
     V3 sh_pos(0.f), c_vis(0.f);
     Nee nee;
     nee.dir = V3(0.f), nee.emission = V3(0.f), nee.dist = 0.f, nee.pdf_sigma = 0.f;
-    uint32_t sh_mode = kShNormal;
-    if (active) {
-      float4 h4 = P.hit[p], o4 = P.ray_o[p], d4 = P.ray_d[p], t4 = P.thr[p];
-      Hit h = {h4.x, h4.y, h4.z, __float_as_uint(h4.w)};
-      V3 dir = ld3(d4);
-      Surface s = make_surface(sc, ld3(o4), dir, h);
-      V3 thr = ld3(t4);
-      Rng rng = {P.rng[p], rng_inc};
+    uint32_t sh_mode = kShNormal, qbit = 0u;
+    PathHead c;
+    if (active && path_head(P, sc, p, rng_inc, c)) {
+      const Hit& h = c.h;
+      const V3 dir = c.dir, thr = c.thr;
+      const Surface& s = c.s;
+      Rng& rng = c.rng;
       V3 new_thr(0.f), next_dir = -dir;
       float new_pdf = 0.f;
       if (s.face != kAmbiguous) {  // :418-424
@@ -305,14 +412,16 @@ __global__ __launch_bounds__(kBlock) void k_shade_principled(PathState P, DScene
               P.ray_o[p] = mk4(s.pos, 1e-3f);
               P.ray_d[p] = mk4(gdir, t_scatter);
               P.sss_sigt[p] = mk4(sigt, __uint_as_float(0u));                      // .w = bounce index
-              P.sss_sigs[p] = mk4(sigs, __uint_as_float(sc.slot_ids[h.slot].x));   // .w = entry instance id
+              P.sss_sigs[p] = mk4(sigs, __uint_as_float(sc.shade[h.slot].instance_id));  // .w = entry instance id
               P.sss_thr[p] = mk4(wthr, 0.f);
               P.sss_pdf[p] = mk4(chpdf, 0.f);
               P.sss_ez[p] = mk4(fr.ez, 0.f);
               P.sss_A[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-              P.flags[p] = P.flags[p] | kFlagSss;
+              P.thr[p] = mk4(thr, 0.f);  // Russian-roulette-scaled path throughput, used again at the exit
+              P.flags[p] = c.flags;
               P.rng[p] = rng.state;
               alive = true;
+              qbit = kQSssBit;
               sh_mode = kShSssEntry;
               c_vis = d1;  // raw: resolved into A by k_trace_shadow
             }
@@ -342,14 +451,13 @@ __global__ __launch_bounds__(kBlock) void k_shade_principled(PathState P, DScene
             P.ray_d[p] = mk4(next_dir, kInf);
             P.thr[p] = mk4(t2, new_pdf);
             P.rng[p] = rng.state;
+            P.flags[p] = c.flags;
           }
         }
       }
     }
-    uint32_t k = queue_append(&P.counts[kCntShadow], shadow);
-    if (shadow) put_shadow(P, k, sh_pos, nee, c_vis, V3(0.f), p, sh_mode);
-    k = queue_append(&P.counts[kCntOut], alive);
-    if (alive) P.q_out[k] = p;
+    if (shadow) put_shadow(P, sh_pos, nee, c_vis, V3(0.f), p, sh_mode);
+    if (active) P.q_principled[i] = p | (shadow ? kRShadow : 0u) | (alive ? kRAlive : 0u) | qbit;
   }
 }
 
@@ -364,13 +472,12 @@ __global__ __launch_bounds__(kBlock) void k_shade_hair(PathState P, DScene sc, u
     V3 sh_pos(0.f), c_vis(0.f);
     Nee nee;
     nee.dir = V3(0.f), nee.emission = V3(0.f), nee.dist = 0.f, nee.pdf_sigma = 0.f;
-    if (active) {
-      float4 h4 = P.hit[p], o4 = P.ray_o[p], d4 = P.ray_d[p], t4 = P.thr[p];
-      Hit h = {h4.x, h4.y, h4.z, __float_as_uint(h4.w)};
-      V3 dir = ld3(d4);
-      Surface s = make_surface(sc, ld3(o4), dir, h);
-      V3 thr = ld3(t4);
-      Rng rng = {P.rng[p], rng_inc};
+    PathHead c;
+    if (active && path_head(P, sc, p, rng_inc, c)) {
+      const Hit& h = c.h;
+      const V3 dir = c.dir, thr = c.thr;
+      const Surface& s = c.s;
+      Rng& rng = c.rng;
       if (s.face != kAmbiguous) {
         V3 wo_g = -dir;
         Frame fr;
@@ -410,13 +517,12 @@ __global__ __launch_bounds__(kBlock) void k_shade_hair(PathState P, DScene sc, u
           P.ray_d[p] = mk4(next_dir, kInf);
           P.thr[p] = mk4(t2, pdf);
           P.rng[p] = rng.state;
+          P.flags[p] = c.flags;
         }
       }
     }
-    uint32_t k = queue_append(&P.counts[kCntShadow], shadow);
-    if (shadow) put_shadow(P, k, sh_pos, nee, c_vis, V3(0.f), p, kShNormal);
-    k = queue_append(&P.counts[kCntOut], alive);
-    if (alive) P.q_out[k] = p;
+    if (shadow) put_shadow(P, sh_pos, nee, c_vis, V3(0.f), p, kShNormal);
+    if (active) P.q_hair[i] = p | (shadow ? kRShadow : 0u) | (alive ? kRAlive : 0u);
   }
 }
 
@@ -431,6 +537,7 @@ __global__ __launch_bounds__(kBlock) void k_sss_step(PathState P, DScene sc, uin
     bool active = i < n;
     uint32_t p = active ? P.q_sss[i] : 0u;
     bool alive = false, shadow = false;
+    uint32_t qbit = 0u;
     V3 sh_pos(0.f), c_vis(0.f), c_occ(0.f);
     Nee nee;
     nee.dir = V3(0.f), nee.emission = V3(0.f), nee.dist = 0.f, nee.pdf_sigma = 0.f;
@@ -481,9 +588,11 @@ __global__ __launch_bounds__(kBlock) void k_sss_step(PathState P, DScene sc, uin
         P.sss_pdf[p] = mk4(chpdf, 0.f);
         P.rng[p] = rng.state;
         alive = true;
+        qbit = kQSssBit;
       } else if (exited) {
-        Surface s = make_surface(sc, org, dir, h);  // :369
-        if (sc.slot_ids[h.slot].x != entry_inst) fail = true;  // :372 (Q6)
+        uint32_t exit_inst;
+        Surface s = make_surface(sc, org, dir, h, &exit_inst);  // :369
+        if (exit_inst != entry_inst) fail = true;               // :372 (Q6)
         if (s.face != kBack) fail = true;                      // :376
         if (!fail) {
           Frame fx;  // exit frame :382-394
@@ -535,7 +644,6 @@ __global__ __launch_bounds__(kBlock) void k_sss_step(PathState P, DScene sc, uin
             P.L[p] = mk4(ld3(L4) + c_occ, L4.w);
           }
           V3 t2 = new_thr * thr;
-          P.flags[p] = P.flags[p] & ~kFlagSss;
           if (!is_black(t2)) {
             alive = true;
             P.ray_o[p] = mk4(s.pos, 1e-3f);
@@ -549,13 +657,10 @@ __global__ __launch_bounds__(kBlock) void k_sss_step(PathState P, DScene sc, uin
         // walk failed: path ends, the first NEE's contribution still counts (render.cc:79)
         float4 L4 = P.L[p];
         P.L[p] = mk4(ld3(L4) + thr * (A + V3(0.f)), L4.w);
-        P.flags[p] = P.flags[p] & ~kFlagSss;
       }
     }
-    uint32_t k = queue_append(&P.counts[kCntShadow], shadow);
-    if (shadow) put_shadow(P, k, sh_pos, nee, c_vis, c_occ, p, kShSssExit);
-    k = queue_append(&P.counts[kCntOut], alive);
-    if (alive) P.q_out[k] = p;
+    if (shadow) put_shadow(P, sh_pos, nee, c_vis, c_occ, p, kShSssExit);
+    if (active) P.q_sss[i] = p | (shadow ? kRShadow : 0u) | (alive ? kRAlive : 0u) | qbit;
   }
 }
 
@@ -593,10 +698,10 @@ __global__ __launch_bounds__(kBlock) void k_hook_closest(DScene sc, const float4
     r.instance_id = r.geom_id = r.prim_id = kNone;
     if (h.slot != kNone) {
       Surface s = make_surface(sc, ld3(o4), ld3(d4), h);
-      uint4 ids = sc.slot_ids[h.slot];
+      const ShadeRec& sr = sc.shade[h.slot];
       r.ng[0] = s.n_g.x, r.ng[1] = s.n_g.y, r.ng[2] = s.n_g.z;
       r.t = h.t, r.u = h.u, r.v = h.v;
-      r.instance_id = ids.x, r.geom_id = ids.y, r.prim_id = ids.z;
+      r.instance_id = sr.instance_id, r.geom_id = sr.geom_id, r.prim_id = sr.prim_id;
     }
     out[i] = r;
   }
@@ -655,8 +760,15 @@ void launch_trace_shadow(hipStream_t s, const PathState& P, const DScene& sc, ui
   else if (curves) hipLaunchKernelGGL((k_trace_shadow<false, true>), g, dim3(kBlock), 0, s, P, sc);
   else hipLaunchKernelGGL((k_trace_shadow<false, false>), g, dim3(kBlock), 0, s, P, sc);
 }
-void launch_surface(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc) {
-  hipLaunchKernelGGL(k_surface, dim3(grid_for(n_upper, kShadeGridCap)), dim3(kBlock), 0, s, P, sc, rng_inc);
+static inline uint32_t tiles_grid(uint32_t n_upper) {
+  uint32_t g = (n_upper + kTileItems - 1) / kTileItems;
+  return g < 1 ? 1 : (g < kShadeGridCap ? g : kShadeGridCap);
+}
+void launch_classify(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper) {
+  hipLaunchKernelGGL(k_classify, dim3(tiles_grid(n_upper)), dim3(kBlock), 0, s, P, sc);
+}
+void launch_compact(hipStream_t s, const PathState& P, uint32_t n_upper) {
+  hipLaunchKernelGGL(k_compact, dim3(tiles_grid(n_upper)), dim3(kBlock), 0, s, P);
 }
 void launch_shade_principled(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc) {
   hipLaunchKernelGGL(k_shade_principled, dim3(grid_for(n_upper, kShadeGridCap)), dim3(kBlock), 0, s, P, sc, rng_inc);

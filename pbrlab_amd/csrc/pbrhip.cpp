@@ -109,8 +109,8 @@ struct pbrhip_scene {
   uint32_t bvh_depth = 0;
   // device scene
   DevBuf<BvhNode> d_nodes;
-  DevBuf<float4> d_slots, d_nrm;
-  DevBuf<uint4> d_meta, d_ids;
+  DevBuf<float4> d_slots;
+  DevBuf<ShadeRec> d_shade;
   DevBuf<Material> d_materials;
   DevBuf<float> d_light_cdf, d_lprim_cdf;
   DevBuf<LightHead> d_heads;
@@ -119,7 +119,7 @@ struct pbrhip_scene {
   // render working set (grown on demand, reused across calls)
   DevBuf<float4> ray_o, ray_d, thr, L, hit, sss[6], sh[4];
   DevBuf<uint64_t> rng;
-  DevBuf<uint32_t> flags, q[5], counts, pix_index;
+  DevBuf<uint32_t> flags, q[6], counts, pix_index;
   DevBuf<unsigned long long> stats;
   DevBuf<float> own_rgba;
   DevBuf<uint32_t> own_count;
@@ -132,7 +132,7 @@ struct pbrhip_scene {
   std::vector<hipEvent_t> events;
 
   size_t device_bytes() const {
-    return d_nodes.n * sizeof(BvhNode) + d_slots.n * 16 + d_nrm.n * 16 + d_meta.n * 16 + d_ids.n * 16 +
+    return d_nodes.n * sizeof(BvhNode) + d_slots.n * 16 + d_shade.n * sizeof(ShadeRec) +
            d_materials.n * sizeof(Material) + d_lrecs.n * sizeof(LightRec);
   }
 };
@@ -474,10 +474,10 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
     }
   }
 
-  // leaf-ordered slots
+  // leaf-ordered slots (traversal geometry) + one 128-byte ShadeRec per slot (everything shading needs)
   uint32_t ns = (uint32_t)bvh.slot_gid.size();
-  std::vector<float4> slots(4 * (size_t)ns), nrm(3 * (size_t)ns);
-  std::vector<uint4> meta(ns), ids(ns);
+  std::vector<float4> slots(4 * (size_t)ns);
+  std::vector<ShadeRec> shade(ns);
   for (uint32_t k = 0; k < ns; k++) {
     uint32_t g = bvh.slot_gid[k];
     const PrimRef& pr = prims[g];
@@ -485,15 +485,18 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
     const HostMesh& m = *inst_mesh(s, pr.instance_id, pr.geom_id);
     uint32_t mat = in.material_ids[pr.geom_id][pr.prim_id];
     if (mat != kNone && mat >= s->materials.size()) return fail(PBRHIP_EINVAL, "material id %u out of range", mat);
+    ShadeRec& sr = shade[k];
+    memset(&sr, 0, sizeof(sr));
     uint32_t flags = 0, lightrec = kNone;
+    if (mat == kNone) flags |= kSlotMatNone;
+    else if (s->materials[mat].kind == kMatHair) flags |= kSlotMatHair;
     float4* sl = &slots[4 * (size_t)k];
-    float4* nr = &nrm[3 * (size_t)k];
     for (int c = 0; c < 4; c++) sl[c] = make_float4(0, 0, 0, 0);
-    for (int c = 0; c < 3; c++) nr[c] = make_float4(0, 0, 0, 0);
     if (pr.kind == 0) {
       for (int c = 0; c < 3; c++) {
         V3 v = mesh_vertex(m, pr.prim_id, c);
         sl[c] = make_float4(v.x, v.y, v.z, 0.f);
+        sr.v[3 * c + 0] = v.x, sr.v[3 * c + 1] = v.y, sr.v[3 * c + 2] = v.z;
       }
       uint32_t a = m.nid[pr.prim_id * 3 + 0], b = m.nid[pr.prim_id * 3 + 1], c = m.nid[pr.prim_id * 3 + 2];
       if (a != kNone && b != kNone && c != kNone) {  // triangle-mesh.cc:81-84
@@ -501,7 +504,7 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
         const uint32_t idx[3] = {a, b, c};
         for (int q = 0; q < 3; q++) {
           const float* n = m.normals.data() + (size_t)idx[q] * 4;
-          nr[q] = make_float4(n[0], n[1], n[2], 0.f);
+          sr.n[3 * q + 0] = n[0], sr.n[3 * q + 1] = n[1], sr.n[3 * q + 2] = n[2];
         }
       }
       if (in.has_area_light[pr.geom_id]) {
@@ -515,8 +518,8 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
         sl[c] = make_float4(cp[0], cp[1], cp[2], cp[3]);
       }
     }
-    meta[k] = make_uint4(g, mat, lightrec, flags);
-    ids[k] = make_uint4(pr.instance_id, pr.geom_id, pr.prim_id, pr.kind);
+    sr.gid = g, sr.material = mat, sr.lightrec = lightrec, sr.flags = flags;
+    sr.instance_id = pr.instance_id, sr.geom_id = pr.geom_id, sr.prim_id = pr.prim_id;
   }
   std::vector<Material> mats(s->materials.size());
   for (size_t i = 0; i < mats.size(); i++) mats[i] = make_material(s->materials[i]);
@@ -524,9 +527,7 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
   hipStream_t st = s->stream;
   HIPCHK(s->d_nodes.upload(bvh.nodes, st));
   HIPCHK(s->d_slots.upload(slots, st));
-  HIPCHK(s->d_nrm.upload(nrm, st));
-  HIPCHK(s->d_meta.upload(meta, st));
-  HIPCHK(s->d_ids.upload(ids, st));
+  HIPCHK(s->d_shade.upload(shade, st));
   HIPCHK(s->d_materials.upload(mats, st));
   HIPCHK(s->d_light_cdf.upload(s->light_cdf, st));
   HIPCHK(s->d_heads.upload(heads, st));
@@ -534,8 +535,8 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
   HIPCHK(s->d_lrecs.upload(lrecs, st));
   HIPCHK(hipStreamSynchronize(st));
   DScene& d = s->dscene;
-  d.nodes = s->d_nodes.p, d.slots = s->d_slots.p, d.slot_meta = s->d_meta.p, d.slot_ids = s->d_ids.p;
-  d.slot_nrm = s->d_nrm.p, d.materials = s->d_materials.p, d.light_cdf = s->d_light_cdf.p;
+  d.nodes = s->d_nodes.p, d.slots = s->d_slots.p, d.shade = s->d_shade.p;
+  d.materials = s->d_materials.p, d.light_cdf = s->d_light_cdf.p;
   d.light_heads = s->d_heads.p, d.lprim_cdf = s->d_lprim_cdf.p, d.lrecs = s->d_lrecs.p;
   d.num_nodes = (uint32_t)bvh.nodes.size(), d.num_slots = ns, d.num_lights = (uint32_t)s->lights.size();
   d.num_materials = (uint32_t)mats.size();
@@ -632,7 +633,7 @@ static Camera make_camera(const pbrhip_scene* s, uint32_t width, uint32_t height
 }
 
 // ------------------------------------------------------------------ render
-static constexpr uint64_t kBytesPerPath = 5 * 16 + 8 + 4 + 6 * 16 + 5 * 4 + 4 * 16;  // ensure_paths()
+static constexpr uint64_t kBytesPerPath = 5 * 16 + 8 + 4 + 6 * 16 + 6 * 4 + 4 * 16;  // ensure_paths()
 namespace {
 struct Timer {
   pbrhip_scene* s;
@@ -741,8 +742,10 @@ static int render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volat
       HIPCHK(hipMemGetInfo(&free_b, &total_b));
       size_t have = 0;
       for (auto* b : {&s->ray_o, &s->ray_d, &s->thr, &s->L, &s->hit}) have += b->n * 16;
-      max_paths = std::min<uint64_t>(256ull << 20, std::max<uint64_t>(1ull << 20, (free_b / 2 + have * 3) / kBytesPerPath));
+      max_paths = std::min<uint64_t>(kMaxPathsInFlight, std::max<uint64_t>(1ull << 20, (free_b / 2 + have * 3) / kBytesPerPath));
     }
+    if (max_paths > kMaxPathsInFlight) max_paths = kMaxPathsInFlight;
+    if (npix > kMaxPathsInFlight) return fail(PBRHIP_EUNSUPPORTED, "more than 2^28 pixels per rank");
     uint32_t chunk_passes = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(d->num_sample, max_paths / npix));
     if ((uint64_t)chunk_passes * npix >= (1ull << 32)) chunk_passes = (uint32_t)(((1ull << 32) - 1) / npix);
     if (int rc = ensure_paths(s, (size_t)chunk_passes * npix)) return rc;
@@ -751,7 +754,7 @@ static int render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volat
     P.rng = s->rng.p, P.flags = s->flags.p;
     P.sss_sigt = s->sss[0].p, P.sss_sigs = s->sss[1].p, P.sss_thr = s->sss[2].p, P.sss_pdf = s->sss[3].p;
     P.sss_ez = s->sss[4].p, P.sss_A = s->sss[5].p;
-    P.q_in = s->q[0].p, P.q_out = s->q[1].p, P.q_principled = s->q[2].p, P.q_hair = s->q[3].p, P.q_sss = s->q[4].p;
+    P.q_in = s->q[0].p, P.q_out = s->q[1].p, P.q_principled = s->q[2].p, P.q_hair = s->q[3].p, P.q_sss = s->q[4].p, P.q_shadow = s->q[5].p;
     P.sh_o = s->sh[0].p, P.sh_d = s->sh[1].p, P.sh_c = s->sh[2].p, P.sh_e = s->sh[3].p;
     P.counts = s->counts.p, P.stats = s->stats.p;
     HIPCHK(hipMemsetAsync(P.stats, 0, sizeof(unsigned long long) * kStatNum, st));
@@ -774,7 +777,7 @@ static int render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volat
         launch_trace_closest(st, P, sc, n, want_stats);
         HIPCHK(tm.end());
         HIPCHK(tm.begin(&S.ms_surface));
-        launch_surface(st, P, sc, n, rng_inc);
+        launch_classify(st, P, sc, n);
         HIPCHK(tm.end());
         HIPCHK(tm.begin(&S.ms_shade_principled));
         launch_shade_principled(st, P, sc, n, rng_inc);
@@ -784,6 +787,9 @@ static int render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volat
         HIPCHK(tm.end());
         HIPCHK(tm.begin(&S.ms_sss_step));
         launch_sss_step(st, P, sc, n, rng_inc);
+        HIPCHK(tm.end());
+        HIPCHK(tm.begin(&S.ms_compact));
+        launch_compact(st, P, n);
         HIPCHK(tm.end());
         HIPCHK(tm.begin(&S.ms_trace_shadow));
         launch_trace_shadow(st, P, sc, n, want_stats);
