@@ -19,6 +19,10 @@
 namespace pb {
 
 constexpr uint32_t kPvBatch = 512;        // rays grabbed per atomicAdd
+#ifndef PB_LDS_STACK
+#define PB_LDS_STACK 16
+#endif
+constexpr int kPvLdsStack = PB_LDS_STACK;  // stack entries per lane kept in LDS
 #ifndef PB_REFILL
 #define PB_REFILL 24
 #endif
@@ -29,9 +33,13 @@ enum : uint32_t { kStIdle = 0, kStNode = 1, kStTri = 2, kStCurve = 3 };
 // Sink: what to do with a finished ray.  closest: store the hit record; shadow: resolve the contribution.
 //   void load(uint32_t idx, uint32_t& tag, V3& o, V3& d, float& tmin, float& tmax)
 //   void done(uint32_t tag, const Hit& h, bool occluded)
+// Traversal stack: the first kPvLdsStack entries of each lane live in LDS (stk_base[i * stride]), deeper ones
+// spill to a per-thread global area (spill[(i - kPvLdsStack) * spill_stride]); keeping the LDS part small is
+// what lets 6 blocks (24 waves) share a CU.
 template <bool ANY, bool STATS, bool CURVES, typename Sink>
 __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t* head, Sink& sink, uint32_t* stk_base,
-                                         uint32_t stride, TravStats& st, uint32_t* overflow) {
+                                         uint32_t stride, uint32_t* spill, uint32_t spill_stride, TravStats& st,
+                                         uint32_t* overflow) {
   const uint32_t lane = __lane_id();
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   // wave-uniform batch cursor
@@ -124,8 +132,11 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
           have_next = h0 || h1;
           next = nearc;
           if (h0 && h1) {
-            if (sp < kStackDepth) {
+            if (sp < kPvLdsStack) {
               stk_base[(uint32_t)sp * stride] = farc;
+              sp++;
+            } else if (sp < kStackDepth) {
+              spill[(uint32_t)(sp - kPvLdsStack) * spill_stride] = farc;
               sp++;
             } else {
               *overflow = 1u;
@@ -171,7 +182,7 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
           advance = false;
         } else {
           sp--;
-          next = stk_base[(uint32_t)sp * stride];
+          next = (sp < kPvLdsStack) ? stk_base[(uint32_t)sp * stride] : spill[(uint32_t)(sp - kPvLdsStack) * spill_stride];
         }
       }
       if (advance) {

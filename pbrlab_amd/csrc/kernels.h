@@ -24,6 +24,7 @@ struct PathState {
   float4 *sss_sigt, *sss_sigs, *sss_thr, *sss_pdf, *sss_ez, *sss_A;
   uint32_t *q_in, *q_out, *q_principled, *q_hair, *q_sss, *q_shadow;
   float4 *sh_o, *sh_d, *sh_c, *sh_e;
+  uint32_t* spill;               // traversal-stack spill area: (kStackDepth - LDS part) x resident threads
   uint32_t* counts;              // kCnt*
   unsigned long long* stats;     // kStat*
 };
@@ -44,7 +45,10 @@ enum : uint32_t {
   kStatPvItNode, kStatPvItTri, kStatPvItCurve, kStatPvItRefill, kStatPvLnNode, kStatPvLnTri, kStatPvLnCurve, kStatNum
 };
 
-constexpr uint32_t kTraceBlocksPerCU = (160 / kStackDepth) < 8 ? (160 / kStackDepth) : 8;  // LDS: kStackDepth KiB per block
+#ifndef PB_TRACE_BLOCKS
+#define PB_TRACE_BLOCKS 6
+#endif
+constexpr uint32_t kTraceBlocksPerCU = PB_TRACE_BLOCKS;  // resident 256-thread blocks per CU (VGPR/LDS budget)
 constexpr uint32_t kTraceGridCap = 256 * kTraceBlocksPerCU;        // persistent traversal: exactly the resident blocks
 constexpr uint32_t kShadeGridCap = 256 * 8;
 
@@ -66,7 +70,9 @@ void launch_sss_step(hipStream_t s, const PathState& P, const DScene& sc, uint32
 void launch_accumulate(hipStream_t s, const PathState& P, const uint32_t* pix_index, uint32_t npix, uint32_t npass,
                        float* rgba, uint32_t* count);
 void launch_advance(hipStream_t s, const PathState& P);
-void launch_hook_closest(hipStream_t s, const DScene& sc, const float4* rays, uint32_t n, HookHit* out, uint32_t* flag);
-void launch_hook_any(hipStream_t s, const DScene& sc, const float4* rays, uint32_t n, uint8_t* out, uint32_t* flag);
+void launch_hook_closest(hipStream_t s, const DScene& sc, const float4* rays, uint32_t n, HookHit* out, uint32_t* counts,
+                         uint32_t* spill, bool simple);
+void launch_hook_any(hipStream_t s, const DScene& sc, const float4* rays, uint32_t n, uint8_t* out, uint32_t* counts,
+                     uint32_t* spill, bool simple);
 
 }  // namespace pb

@@ -85,12 +85,13 @@ struct ClosestSink {
 
 template <bool STATS, bool CURVES>
 __global__ __launch_bounds__(kBlock) void k_trace_closest(PathState P, DScene sc) {
-  __shared__ uint32_t stk[kStackDepth * kBlock];
+  __shared__ uint32_t stk[kPvLdsStack * kBlock];
   const uint32_t n = P.counts[kCntIn];
   TravStats st = {};
   uint32_t overflow = 0u;
   ClosestSink sink = {P, sc};
-  trace_pv<false, STATS, CURVES>(sc, n, &P.counts[kCntHeadClosest], sink, stk + threadIdx.x, kBlock, st, &overflow);
+  trace_pv<false, STATS, CURVES>(sc, n, &P.counts[kCntHeadClosest], sink, stk + threadIdx.x, kBlock,
+                                 P.spill + blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, st, &overflow);
   if (overflow) P.counts[kCntOverflow] = 1u;
   if (STATS) {
     uint32_t a = wave_sum(st.nodes), b = wave_sum(st.tris), c = wave_sum(st.curves);
@@ -136,12 +137,13 @@ struct ShadowSink {
 
 template <bool STATS, bool CURVES>
 __global__ __launch_bounds__(kBlock) void k_trace_shadow(PathState P, DScene sc) {
-  __shared__ uint32_t stk[kStackDepth * kBlock];
+  __shared__ uint32_t stk[kPvLdsStack * kBlock];
   const uint32_t n = P.counts[kCntShadow];
   TravStats st = {};
   uint32_t overflow = 0u;
   ShadowSink sink = {P};
-  trace_pv<true, STATS, CURVES>(sc, n, &P.counts[kCntHeadShadow], sink, stk + threadIdx.x, kBlock, st, &overflow);
+  trace_pv<true, STATS, CURVES>(sc, n, &P.counts[kCntHeadShadow], sink, stk + threadIdx.x, kBlock,
+                                P.spill + blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, st, &overflow);
   if (overflow) P.counts[kCntOverflow] = 1u;
   if (STATS) {
     uint32_t a = wave_sum(st.nodes), b = wave_sum(st.tris), c = wave_sum(st.curves);
@@ -684,6 +686,48 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(PathState P, const uint32
 }
 
 // ------------------------------------------------------------------ test hooks: Raytracer::FirstHitTrace1 / AnyHit1
+// Same persistent phase-voting traversal as the render path, fed from a caller-supplied ray array.
+__device__ __forceinline__ HookHit hook_result(const DScene& sc, V3 o, V3 d, const Hit& h) {
+  HookHit r;  // TraceResult defaults (raytracer.h:9-17)
+  r.ng[0] = 1.f, r.ng[1] = 0.f, r.ng[2] = 0.f, r.t = 1.f, r.u = 0.f, r.v = 0.f;
+  r.instance_id = r.geom_id = r.prim_id = kNone;
+  if (h.slot != kNone) {
+    Surface s = make_surface(sc, o, d, h);
+    const ShadeRec& sr = sc.shade[h.slot];
+    r.ng[0] = s.n_g.x, r.ng[1] = s.n_g.y, r.ng[2] = s.n_g.z;
+    r.t = h.t, r.u = h.u, r.v = h.v;
+    r.instance_id = sr.instance_id, r.geom_id = sr.geom_id, r.prim_id = sr.prim_id;
+  }
+  return r;
+}
+struct HookSink {
+  const DScene& sc;
+  const float4* rays;
+  HookHit* hits;
+  uint8_t* occ;
+  __device__ __forceinline__ void load(uint32_t idx, uint32_t& tag, V3& o, V3& d, float& tmin, float& tmax) const {
+    tag = idx;
+    float4 o4 = rays[2 * idx], d4 = rays[2 * idx + 1];
+    o = ld3(o4), d = ld3(d4), tmin = o4.w, tmax = fminf(d4.w, INFINITY);  // raytracer_impl.cc:256
+  }
+  __device__ __forceinline__ void done(uint32_t i, const Hit& h, bool occluded) const {
+    if (occ) occ[i] = occluded ? 1 : 0;
+    else hits[i] = hook_result(sc, ld3(rays[2 * i]), ld3(rays[2 * i + 1]), h);
+  }
+};
+template <bool ANY>
+__global__ __launch_bounds__(kBlock) void k_hook_pv(DScene sc, const float4* __restrict__ rays, uint32_t n, HookHit* hits,
+                                                    uint8_t* occ, uint32_t* counts, uint32_t* spill) {
+  __shared__ uint32_t stk[kPvLdsStack * kBlock];
+  TravStats st = {};
+  uint32_t overflow = 0u;
+  HookSink sink = {sc, rays, hits, occ};
+  trace_pv<ANY, false, true>(sc, n, &counts[kCntHeadClosest], sink, stk + threadIdx.x, kBlock,
+                             spill + blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, st, &overflow);
+  if (overflow) counts[kCntOverflow] = 1u;
+}
+// One ray per thread, plain stack traversal (dtrace.h): an independent second implementation, selected with
+// PBRHIP_SIMPLE_TRAVERSAL=1, that must agree with the production traversal bit for bit.
 __global__ __launch_bounds__(kBlock) void k_hook_closest(DScene sc, const float4* __restrict__ rays, uint32_t n,
                                                          HookHit* __restrict__ out, uint32_t* overflow_flag) {
   __shared__ uint32_t stk[kStackDepth * kBlock];
@@ -693,17 +737,7 @@ __global__ __launch_bounds__(kBlock) void k_hook_closest(DScene sc, const float4
     float4 o4 = rays[2 * i], d4 = rays[2 * i + 1];
     Hit h;
     traverse<false, false, true>(sc, ld3(o4), ld3(d4), o4.w, fminf(d4.w, INFINITY), h, stk + threadIdx.x, kBlock, st, &overflow);
-    HookHit r;  // TraceResult defaults (raytracer.h:9-17)
-    r.ng[0] = 1.f, r.ng[1] = 0.f, r.ng[2] = 0.f, r.t = 1.f, r.u = 0.f, r.v = 0.f;
-    r.instance_id = r.geom_id = r.prim_id = kNone;
-    if (h.slot != kNone) {
-      Surface s = make_surface(sc, ld3(o4), ld3(d4), h);
-      const ShadeRec& sr = sc.shade[h.slot];
-      r.ng[0] = s.n_g.x, r.ng[1] = s.n_g.y, r.ng[2] = s.n_g.z;
-      r.t = h.t, r.u = h.u, r.v = h.v;
-      r.instance_id = sr.instance_id, r.geom_id = sr.geom_id, r.prim_id = sr.prim_id;
-    }
-    out[i] = r;
+    out[i] = hook_result(sc, ld3(o4), ld3(d4), h);
   }
   if (overflow) *overflow_flag = 1u;
 }
@@ -716,7 +750,7 @@ __global__ __launch_bounds__(kBlock) void k_hook_any(DScene sc, const float4* __
     float4 o4 = rays[2 * i], d4 = rays[2 * i + 1];
     Hit h;
     out[i] = traverse<true, false, true>(sc, ld3(o4), ld3(d4), o4.w, fminf(d4.w, INFINITY), h, stk + threadIdx.x, kBlock, st,
-                                   &overflow)
+                                         &overflow)
                  ? 1
                  : 0;
   }
@@ -784,11 +818,22 @@ void launch_accumulate(hipStream_t s, const PathState& P, const uint32_t* pix_in
   hipLaunchKernelGGL(k_accumulate, dim3(grid_for(npix, 8192)), dim3(kBlock), 0, s, P, pix_index, npix, npass, rgba, count);
 }
 void launch_advance(hipStream_t s, const PathState& P) { hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, s, P.counts); }
-void launch_hook_closest(hipStream_t s, const DScene& sc, const float4* rays, uint32_t n, HookHit* out, uint32_t* flag) {
-  hipLaunchKernelGGL(k_hook_closest, dim3(grid_for(n, kTraceGridCap)), dim3(kBlock), 0, s, sc, rays, n, out, flag);
+// counts: kCntNum zeroed words (queue head + overflow flag); spill: traversal-stack spill area
+void launch_hook_closest(hipStream_t s, const DScene& sc, const float4* rays, uint32_t n, HookHit* out, uint32_t* counts,
+                         uint32_t* spill, bool simple) {
+  if (simple)
+    hipLaunchKernelGGL(k_hook_closest, dim3(grid_for(n, 4096)), dim3(kBlock), 0, s, sc, rays, n, out, counts + kCntOverflow);
+  else
+    hipLaunchKernelGGL((k_hook_pv<false>), dim3(grid_for(n, kTraceGridCap)), dim3(kBlock), 0, s, sc, rays, n, out,
+                       (uint8_t*)nullptr, counts, spill);
 }
-void launch_hook_any(hipStream_t s, const DScene& sc, const float4* rays, uint32_t n, uint8_t* out, uint32_t* flag) {
-  hipLaunchKernelGGL(k_hook_any, dim3(grid_for(n, kTraceGridCap)), dim3(kBlock), 0, s, sc, rays, n, out, flag);
+void launch_hook_any(hipStream_t s, const DScene& sc, const float4* rays, uint32_t n, uint8_t* out, uint32_t* counts,
+                     uint32_t* spill, bool simple) {
+  if (simple)
+    hipLaunchKernelGGL(k_hook_any, dim3(grid_for(n, 4096)), dim3(kBlock), 0, s, sc, rays, n, out, counts + kCntOverflow);
+  else
+    hipLaunchKernelGGL((k_hook_pv<true>), dim3(grid_for(n, kTraceGridCap)), dim3(kBlock), 0, s, sc, rays, n,
+                       (HookHit*)nullptr, out, counts, spill);
 }
 
 }  // namespace pb

@@ -119,7 +119,7 @@ struct pbrhip_scene {
   // render working set (grown on demand, reused across calls)
   DevBuf<float4> ray_o, ray_d, thr, L, hit, sss[6], sh[4];
   DevBuf<uint64_t> rng;
-  DevBuf<uint32_t> flags, q[6], counts, pix_index;
+  DevBuf<uint32_t> flags, q[6], counts, pix_index, spill;
   DevBuf<unsigned long long> stats;
   DevBuf<float> own_rgba;
   DevBuf<uint32_t> own_count;
@@ -708,6 +708,7 @@ static int ensure_paths(pbrhip_scene* s, size_t n) {
   for (auto& b : s->q) HIPCHK(b.reserve(n));
   HIPCHK(s->counts.reserve(kCntNum));
   HIPCHK(s->stats.reserve(kStatNum));
+  HIPCHK(s->spill.reserve((size_t)kStackDepth * kTraceGridCap * 256));
   return PBRHIP_OK;
 }
 
@@ -756,7 +757,7 @@ static int render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volat
     P.sss_ez = s->sss[4].p, P.sss_A = s->sss[5].p;
     P.q_in = s->q[0].p, P.q_out = s->q[1].p, P.q_principled = s->q[2].p, P.q_hair = s->q[3].p, P.q_sss = s->q[4].p, P.q_shadow = s->q[5].p;
     P.sh_o = s->sh[0].p, P.sh_d = s->sh[1].p, P.sh_c = s->sh[2].p, P.sh_e = s->sh[3].p;
-    P.counts = s->counts.p, P.stats = s->stats.p;
+    P.counts = s->counts.p, P.stats = s->stats.p, P.spill = s->spill.p;
     HIPCHK(hipMemsetAsync(P.stats, 0, sizeof(unsigned long long) * kStatNum, st));
     const Camera cam = make_camera(s, d->width, d->height);
     const uint64_t rng_inc = (d->seed_seq << 1u) | 1u;  // pcg32_srandom (rng.h:30-36)
@@ -877,7 +878,9 @@ extern "C" int pbrhip_trace_closest(pbrhip_scene* s, const pbrhip_ray* rays, siz
   HIPCHK(s->counts.reserve(kCntNum));
   HIPCHK(hipMemsetAsync(s->counts.p, 0, sizeof(uint32_t) * kCntNum, s->stream));
   HIPCHK(hipMemcpyAsync(s->hook_rays.p, rays, n * sizeof(pbrhip_ray), hipMemcpyHostToDevice, s->stream));
-  launch_hook_closest(s->stream, s->dscene, s->hook_rays.p, (uint32_t)n, s->hook_hits.p, s->counts.p + kCntOverflow);
+  HIPCHK(s->spill.reserve((size_t)kStackDepth * kTraceGridCap * 256));
+  launch_hook_closest(s->stream, s->dscene, s->hook_rays.p, (uint32_t)n, s->hook_hits.p, s->counts.p, s->spill.p,
+                      getenv("PBRHIP_SIMPLE_TRAVERSAL") != nullptr);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(hits, s->hook_hits.p, n * sizeof(pbrhip_hit), hipMemcpyDeviceToHost, s->stream));
   HIPCHK(hipMemcpyAsync(s->h_counts, s->counts.p, sizeof(uint32_t) * kCntNum, hipMemcpyDeviceToHost, s->stream));
@@ -896,7 +899,9 @@ extern "C" int pbrhip_trace_any(pbrhip_scene* s, const pbrhip_ray* rays, size_t 
   HIPCHK(s->counts.reserve(kCntNum));
   HIPCHK(hipMemsetAsync(s->counts.p, 0, sizeof(uint32_t) * kCntNum, s->stream));
   HIPCHK(hipMemcpyAsync(s->hook_rays.p, rays, n * sizeof(pbrhip_ray), hipMemcpyHostToDevice, s->stream));
-  launch_hook_any(s->stream, s->dscene, s->hook_rays.p, (uint32_t)n, s->hook_occ.p, s->counts.p + kCntOverflow);
+  HIPCHK(s->spill.reserve((size_t)kStackDepth * kTraceGridCap * 256));
+  launch_hook_any(s->stream, s->dscene, s->hook_rays.p, (uint32_t)n, s->hook_occ.p, s->counts.p, s->spill.p,
+                  getenv("PBRHIP_SIMPLE_TRAVERSAL") != nullptr);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(occluded, s->hook_occ.p, n, hipMemcpyDeviceToHost, s->stream));
   HIPCHK(hipMemcpyAsync(s->h_counts, s->counts.p, sizeof(uint32_t) * kCntNum, hipMemcpyDeviceToHost, s->stream));
