@@ -19,7 +19,10 @@ namespace pb {
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kCurveBit = 0x40000000u;
 constexpr uint32_t kEmptyChild = 0xFFFFFFFFu;  // (a leaf reference that can never be produced)
-constexpr int kMaxLeaf = 4;
+#ifndef PB_MAX_LEAF
+#define PB_MAX_LEAF 2
+#endif
+constexpr int kMaxLeaf = PB_MAX_LEAF;
 #ifndef PB_STACK_DEPTH
 #define PB_STACK_DEPTH 40
 #endif

@@ -104,7 +104,7 @@ struct pbrhip_scene {
   std::vector<V3> light_params;
   std::vector<HostLight> lights;
   std::vector<float> light_cdf;
-  bool committed = false;
+  bool committed = false, has_hair = false, has_sss = false;
   float bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0};
   uint32_t bvh_depth = 0;
   // device scene
@@ -522,7 +522,12 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
     sr.instance_id = pr.instance_id, sr.geom_id = pr.geom_id, sr.prim_id = pr.prim_id;
   }
   std::vector<Material> mats(s->materials.size());
-  for (size_t i = 0; i < mats.size(); i++) mats[i] = make_material(s->materials[i]);
+  s->has_hair = s->has_sss = false;
+  for (size_t i = 0; i < mats.size(); i++) {
+    mats[i] = make_material(s->materials[i]);
+    s->has_hair = s->has_hair || mats[i].kind == kMatHair;
+    s->has_sss = s->has_sss || (mats[i].kind == kMatPrincipled && mats[i].bsdf.enable_subsurface);
+  }
 
   hipStream_t st = s->stream;
   HIPCHK(s->d_nodes.upload(bvh.nodes, st));
@@ -569,6 +574,7 @@ static int update_material(pbrhip_scene* s, uint32_t id, const HostMaterial& hm)
   if (s->committed) {
     HIPCHK(hipSetDevice(s->device));
     Material m = make_material(hm);
+    s->has_sss = s->has_sss || (m.kind == kMatPrincipled && m.bsdf.enable_subsurface);
     HIPCHK(hipMemcpyAsync(s->d_materials.p + id, &m, sizeof(m), hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
   }
@@ -741,11 +747,20 @@ static int render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volat
     if (!max_paths) {
       size_t free_b = 0, total_b = 0;
       HIPCHK(hipMemGetInfo(&free_b, &total_b));
-      size_t have = 0;
-      for (auto* b : {&s->ray_o, &s->ray_d, &s->thr, &s->L, &s->hit}) have += b->n * 16;
-      max_paths = std::min<uint64_t>(kMaxPathsInFlight, std::max<uint64_t>(1ull << 20, (free_b / 2 + have * 3) / kBytesPerPath));
+      // what this scene already holds for path state counts as available
+      size_t have = (s->ray_o.n + s->ray_d.n + s->thr.n + s->L.n + s->hit.n) * 16 + s->rng.n * 8 + s->flags.n * 4;
+      for (auto& b : s->sss) have += b.n * 16;
+      for (auto& b : s->sh) have += b.n * 16;
+      for (auto& b : s->q) have += b.n * 4;
+      max_paths = std::min<uint64_t>(kMaxPathsInFlight,
+                                     std::max<uint64_t>(1ull << 20, (uint64_t)((free_b + have) * 0.6) / kBytesPerPath));
     }
     if (max_paths > kMaxPathsInFlight) max_paths = kMaxPathsInFlight;
+    if (getenv("PBRHIP_DEBUG")) {
+      size_t fb = 0, tb = 0;
+      (void)hipMemGetInfo(&fb, &tb);
+      fprintf(stderr, "pbrhip: free %.1f GB total %.1f GB max_paths %llu npix %u\n", fb / 1e9, tb / 1e9, (unsigned long long)max_paths, npix);
+    }
     if (npix > kMaxPathsInFlight) return fail(PBRHIP_EUNSUPPORTED, "more than 2^28 pixels per rank");
     uint32_t chunk_passes = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(d->num_sample, max_paths / npix));
     if ((uint64_t)chunk_passes * npix >= (1ull << 32)) chunk_passes = (uint32_t)(((1ull << 32) - 1) / npix);
@@ -774,36 +789,47 @@ static int render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volat
       launch_generate(st, P, cam, s->pix_index.p, npix, n, d->width, d->first_pass + done, d->seed_seq);
       HIPCHK(tm.end());
       while (n > 0) {
-        HIPCHK(tm.begin(&S.ms_trace_closest));
-        launch_trace_closest(st, P, sc, n, want_stats);
-        HIPCHK(tm.end());
-        HIPCHK(tm.begin(&S.ms_surface));
-        launch_classify(st, P, sc, n);
-        HIPCHK(tm.end());
-        HIPCHK(tm.begin(&S.ms_shade_principled));
-        launch_shade_principled(st, P, sc, n, rng_inc);
-        HIPCHK(tm.end());
-        HIPCHK(tm.begin(&S.ms_shade_hair));
-        launch_shade_hair(st, P, sc, n, rng_inc);
-        HIPCHK(tm.end());
-        HIPCHK(tm.begin(&S.ms_sss_step));
-        launch_sss_step(st, P, sc, n, rng_inc);
-        HIPCHK(tm.end());
-        HIPCHK(tm.begin(&S.ms_compact));
-        launch_compact(st, P, n);
-        HIPCHK(tm.end());
-        HIPCHK(tm.begin(&S.ms_trace_shadow));
-        launch_trace_shadow(st, P, sc, n, want_stats);
-        HIPCHK(tm.end());
-        S.n_trace_closest++, S.n_trace_shadow++, S.n_surface++, S.n_shade_principled++, S.n_shade_hair++, S.n_sss_step++;
-        launch_advance(st, P);
-        std::swap(P.q_in, P.q_out);
+        // Long tails (few paths, many bounces) are latency-bound: below 256 Ki active paths several iterations
+        // are queued per host round trip (kernels read their counts on the device and fall through when empty).
+        const int burst = n < (1u << 18) ? 8 : 1;
+        for (int it = 0; it < burst; it++) {
+          HIPCHK(tm.begin(&S.ms_trace_closest));
+          launch_trace_closest(st, P, sc, n, want_stats);
+          HIPCHK(tm.end());
+          HIPCHK(tm.begin(&S.ms_surface));
+          launch_classify(st, P, sc, n);
+          HIPCHK(tm.end());
+          HIPCHK(tm.begin(&S.ms_shade_principled));
+          launch_shade_principled(st, P, sc, n, rng_inc);
+          HIPCHK(tm.end());
+          if (s->has_hair) {
+            HIPCHK(tm.begin(&S.ms_shade_hair));
+            launch_shade_hair(st, P, sc, n, rng_inc);
+            HIPCHK(tm.end());
+            S.n_shade_hair++;
+          }
+          if (s->has_sss) {
+            HIPCHK(tm.begin(&S.ms_sss_step));
+            launch_sss_step(st, P, sc, n, rng_inc);
+            HIPCHK(tm.end());
+            S.n_sss_step++;
+          }
+          HIPCHK(tm.begin(&S.ms_compact));
+          launch_compact(st, P, n);
+          HIPCHK(tm.end());
+          HIPCHK(tm.begin(&S.ms_trace_shadow));
+          launch_trace_shadow(st, P, sc, n, want_stats);
+          HIPCHK(tm.end());
+          S.n_trace_closest++, S.n_trace_shadow++, S.n_surface++, S.n_shade_principled++;
+          launch_advance(st, P);
+          std::swap(P.q_in, P.q_out);
+          S.iterations++;
+        }
         HIPCHK(hipMemcpyAsync(s->h_counts, P.counts, sizeof(uint32_t) * kCntNum, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         HIPCHK(tm.collect());
         if (s->h_counts[kCntOverflow]) return fail(PBRHIP_EOVERFLOW, "BVH traversal stack overflow");
         n = s->h_counts[kCntIn];
-        S.iterations++;
       }
       HIPCHK(tm.begin(&S.ms_accumulate));
       launch_accumulate(st, P, s->pix_index.p, npix, np, d_rgba, d_count);
