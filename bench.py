@@ -36,9 +36,10 @@ WORKLOADS = {
                width=256, height=256, spp=4),
 }
 
-# algorithmic bytes of the traversal kernel: 64 B per BVH node visited, 48 B per
-# triangle tested, 64 B per curve tested, and per ray 32 B ray + 16 B hit record + 4 B queue entry
-NODE_B, TRI_B, CURVE_B, RAY_B = 64, 48, 64, 52
+# algorithmic bytes of the traversal kernel k_trace: 64 B per BVH node visited, 48 B per
+# triangle tested, 64 B per curve tested; per closest-hit ray 32 B ray + 16 B hit record + 4 B queue entry; per
+# shadow ray 32 B ray + 4 B queue entry + 32 B pending-contribution payload
+NODE_B, TRI_B, CURVE_B, RAY_B, SHADOW_RAY_B = 64, 48, 64, 52, 68
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
@@ -167,18 +168,20 @@ def main():
         _, sst = api.Render(scene, W, H, spp, tile_rank=rank, tile_world=world, device_out=ptrs,
                             flags=api.RENDER_STATS, max_paths_in_flight=args.max_paths)
         torch.cuda.synchronize()
-        bytes_step = (NODE_B * sst["closest_nodes"] + TRI_B * sst["closest_tris"] + CURVE_B * sst["closest_curves"] +
-                      RAY_B * sst["closest_rays"])
+        bytes_step = (NODE_B * (sst["closest_nodes"] + sst["shadow_nodes"]) + TRI_B * (sst["closest_tris"] + sst["shadow_tris"]) +
+                      CURVE_B * (sst["closest_curves"] + sst["shadow_curves"]) + RAY_B * sst["closest_rays"] +
+                      SHADOW_RAY_B * sst["shadow_rays"])
         launches = agg["n_trace_closest"] / args.steps
         ms_step = agg["ms_trace_closest"] / args.steps
         if ms_step > 0:
             achieved = bytes_step / (ms_step * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": "k_trace_closest", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            roofline = {"bound": "hbm", "kernel": "k_trace (closest-hit rays of bounce k + shadow rays of bounce k-1)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                         "algorithmic_bytes_per_launch": bytes_step / max(launches, 1),
                         "avg_launch_ms": ms_step / max(launches, 1), "launches_per_step": launches,
-                        "rays_per_step": sst["closest_rays"],
-                        "kernel_ms_per_step": {k[3:]: agg[k] / args.steps for k in agg if k.startswith("ms_") and k != "ms_total"}}
+                        "rays_per_step": sst["closest_rays"] + sst["shadow_rays"],
+                        "kernel_ms_per_step": {{"trace_closest": "trace", "surface": "classify"}.get(k[3:], k[3:]): agg[k] / args.steps
+                                               for k in agg if k.startswith("ms_") and k not in ("ms_total", "ms_trace_shadow")}}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -19,7 +19,8 @@ struct Hit {
 };
 
 struct TravStats {
-  uint32_t nodes, tris, curves;
+  uint32_t nodes, tris, curves;     // closest-hit rays
+  uint32_t anodes, atris, acurves;  // any-hit (shadow) rays
   // phase-voting traversal, lane 0 of each wave: iterations and participating lanes per phase
   uint32_t it_node, it_tri, it_curve, it_refill, ln_node, ln_tri, ln_curve;
 };

@@ -31,12 +31,14 @@ constexpr int kPvRefillIdle = PB_REFILL;         // refill when at least this ma
 enum : uint32_t { kStIdle = 0, kStNode = 1, kStTri = 2, kStCurve = 3 };
 
 // Sink: what to do with a finished ray.  closest: store the hit record; shadow: resolve the contribution.
-//   void load(uint32_t idx, uint32_t& tag, V3& o, V3& d, float& tmin, float& tmax)
+//   bool load(uint32_t idx, uint32_t& tag, V3& o, V3& d, float& tmin, float& tmax)   returns "any-hit ray"
 //   void done(uint32_t tag, const Hit& h, bool occluded)
+// MODE: 0 = every ray wants its closest hit, 1 = every ray is an any-hit (shadow) ray, 2 = per ray (load()'s
+// return value): closest-hit rays of bounce k+1 and shadow rays of bounce k share one launch and one drain.
 // Traversal stack: the first kPvLdsStack entries of each lane live in LDS (stk_base[i * stride]), deeper ones
 // spill to a per-thread global area (spill[(i - kPvLdsStack) * spill_stride]); keeping the LDS part small is
 // what lets 6 blocks (24 waves) share a CU.
-template <bool ANY, bool STATS, bool CURVES, typename Sink>
+template <int MODE, bool STATS, bool CURVES, typename Sink>
 __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t* head, Sink& sink, uint32_t* stk_base,
                                          uint32_t stride, uint32_t* spill, uint32_t spill_stride, TravStats& st,
                                          uint32_t* overflow) {
@@ -72,6 +74,7 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
 
   // per-lane state
   uint32_t state = kStIdle, tag = 0;
+  bool any_ray = (MODE == 1);
   V3 o(0.f), d(0.f), inv(0.f);
   float tmin = 0.f, best_t = 0.f;
   Hit hit = {0.f, 0.f, 0.f, kNone};
@@ -100,7 +103,8 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
       uint32_t rank = (uint32_t)__popcll(idle_mask & lt_mask);
       if (state == kStIdle && rank < take) {
         float tmax;
-        sink.load(batch_cur + rank, tag, o, d, tmin, tmax);
+        bool a = sink.load(batch_cur + rank, tag, o, d, tmin, tmax);
+        any_ray = (MODE == 1) || (MODE == 2 && a);
         inv = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
         best_t = tmax;
         hit.t = tmax, hit.u = 0.f, hit.v = 0.f, hit.slot = kNone;
@@ -124,7 +128,7 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
       if (phase == 0) {
         // ---- NODE phase
         if (state == kStNode) {
-          if (STATS) st.nodes++;
+          if (STATS) (any_ray ? st.anodes : st.nodes)++;
           float lo0[3] = {D0.x, D0.y, D0.z}, hi0[3] = {D0.w, D1.x, D1.y};
           float lo1[3] = {D1.z, D1.w, D2.x}, hi1[3] = {D2.y, D2.z, D2.w};
           uint32_t c0 = __float_as_uint(D3.x), c1 = __float_as_uint(D3.y);
@@ -155,19 +159,19 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
           float t, u, v;
           bool ok;
           if (!CURVES || phase == 1) {
-            if (STATS) st.tris++;
+            if (STATS) (any_ray ? st.atris : st.tris)++;
             ok = tri_test(ld3(D0), ld3(D1), ld3(D2), o, d, tmin, t, u, v) && (t <= best_t);
           } else {
-            if (STATS) st.curves++;
+            if (STATS) (any_ray ? st.acurves : st.curves)++;
             float4 cp[4] = {D0, D1, D2, D3};
             ok = curve_test(cp, o, d, tmin, best_t, t, u, v);
           }
-          if (ok && !ANY && t == best_t && hit.slot != kNone) ok = sc.shade[cur].gid < sc.shade[hit.slot].gid;
+          if (ok && !any_ray && t == best_t && hit.slot != kNone) ok = sc.shade[cur].gid < sc.shade[hit.slot].gid;
           if (ok) {
             best_t = t;
             hit.t = t, hit.u = u, hit.v = v, hit.slot = cur;
           }
-          if (ANY && ok) {
+          if (any_ray && ok) {
             sink.done(tag, hit, true);
             state = kStIdle;
           } else {

@@ -22,7 +22,7 @@ struct PathState {
   uint64_t* rng;
   uint32_t* flags;
   float4 *sss_sigt, *sss_sigs, *sss_thr, *sss_pdf, *sss_ez, *sss_A;
-  uint32_t *q_in, *q_out, *q_principled, *q_hair, *q_sss, *q_shadow;
+  uint32_t *q_in, *q_out, *q_principled, *q_hair, *q_sss, *q_shadow, *q_shadow_in;
   float4 *sh_o, *sh_d, *sh_c, *sh_e;
   uint32_t* spill;               // traversal-stack spill area: (kStackDepth - LDS part) x resident threads
   uint32_t* counts;              // kCnt*
@@ -36,7 +36,7 @@ constexpr uint32_t kRPathMask = 0x0FFFFFFFu, kRShadow = 1u << 28, kRAlive = 1u <
 constexpr uint64_t kMaxPathsInFlight = (1ull << 28) - 1;
 enum : uint32_t { kShNormal = 0u, kShSssEntry = 1u, kShSssExit = 2u };
 enum : uint32_t {
-  kCntIn = 0, kCntOut, kCntPrincipled, kCntHair, kCntSss, kCntShadow, kCntOverflow, kCntHeadClosest, kCntHeadShadow,
+  kCntIn = 0, kCntOut, kCntPrincipled, kCntHair, kCntSss, kCntShadow, kCntOverflow, kCntHead, kCntShadowIn,
   kCntNum = 12
 };
 enum : uint32_t {
@@ -51,6 +51,7 @@ enum : uint32_t {
 constexpr uint32_t kTraceBlocksPerCU = PB_TRACE_BLOCKS;  // resident 256-thread blocks per CU (VGPR/LDS budget)
 constexpr uint32_t kTraceGridCap = 256 * kTraceBlocksPerCU;        // persistent traversal: exactly the resident blocks
 constexpr uint32_t kShadeGridCap = 256 * 8;
+constexpr int kMaxGroups = 8;  // concurrent path groups (one HIP stream each)
 
 struct HookHit {  // == pbrhip_hit == TraceResult (raytracer.h:9-17)
   float ng[3];
@@ -59,9 +60,8 @@ struct HookHit {  // == pbrhip_hit == TraceResult (raytracer.h:9-17)
 };
 
 void launch_generate(hipStream_t s, const PathState& P, const Camera& cam, const uint32_t* pix_index, uint32_t npix,
-                     uint32_t npaths, uint32_t width, uint32_t first_pass, uint64_t seed_seq);
-void launch_trace_closest(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, bool stats);
-void launch_trace_shadow(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, bool stats);
+                     uint32_t npaths, uint32_t slot0, uint32_t width, uint32_t first_pass, uint64_t seed_seq);
+void launch_trace(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, bool stats);
 void launch_classify(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper);
 void launch_compact(hipStream_t s, const PathState& P, uint32_t n_upper);
 void launch_shade_principled(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc);

@@ -45,11 +45,13 @@ __device__ __forceinline__ float4 mk4(V3 v, float w) { return make_float4(v.x, v
 
 // ------------------------------------------------------------------ k_generate (render.cc:160-171)
 __global__ __launch_bounds__(kBlock) void k_generate(PathState P, Camera cam, const uint32_t* __restrict__ pix_index,
-                                                     uint32_t npix, uint32_t npaths, uint32_t width,
+                                                     uint32_t npix, uint32_t npaths, uint32_t slot0, uint32_t width,
                                                      uint32_t first_pass, uint64_t seed_seq) {
-  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < npaths; i += gridDim.x * kBlock) {
-    uint32_t pass = first_pass + i / npix;
-    uint32_t gpix = pix_index[i % npix];
+  // path slots [slot0, slot0 + npaths) of the chunk belong to this group; its queues start at entry 0
+  for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < npaths; j += gridDim.x * kBlock) {
+    const uint32_t i = slot0 + j;
+    uint32_t pass = first_pass + j / npix;
+    uint32_t gpix = pix_index[j % npix];
     uint32_t x = gpix % width, y = gpix / width;
     Rng rng = rng_seed(((uint64_t)pass << 32) + (uint64_t)gpix, seed_seq);
     float jx = draw(rng);
@@ -63,66 +65,41 @@ __global__ __launch_bounds__(kBlock) void k_generate(PathState P, Camera cam, co
     P.L[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     P.rng[i] = rng.state;
     P.flags[i] = 0u;
-    P.q_in[i] = i;
+    P.q_in[j] = i;
   }
 }
 
-// ------------------------------------------------------------------ k_trace_closest / k_trace_shadow
-// Persistent phase-voting traversal (dtrace_pv.h).  The grid is sized to the chip, not to the ray count;
-// rays are dealt from the queue through P.counts[kCntHeadClosest / kCntHeadShadow].
-struct ClosestSink {
+// ------------------------------------------------------------------ k_trace
+// ONE persistent phase-voting traversal launch per wavefront iteration (dtrace_pv.h): it serves the closest-hit
+// rays of this bounce (rtcIntersect1, raytracer_impl.cc:268-278; queue q_in) AND the shadow rays the previous
+// bounce's shading produced (rtcOccluded1 + tail of DirectIllumination, shader-utils.h:192-208; queue q_shadow).
+// The two sets are independent -- shading of this bounce waits for both -- so they share one drain.
+//   closest ray: store the hit record
+//   shadow ray:  kShNormal   L += c_vis when unoccluded
+//                kShSssEntry A  = 0 + c_vis when unoccluded (first NEE of a path that entered the medium)
+//                kShSssExit  L += unoccluded ? c_vis : c_occ
+struct TraceSink {
   const PathState& P;
-  const DScene& sc;
-  __device__ __forceinline__ void load(uint32_t idx, uint32_t& tag, V3& o, V3& d, float& tmin, float& tmax) const {
-    tag = P.q_in[idx] & kQPathMask;
-    float4 o4 = P.ray_o[tag], d4 = P.ray_d[tag];
-    o = ld3(o4), d = ld3(d4), tmin = o4.w, tmax = d4.w;
-  }
-  __device__ __forceinline__ void done(uint32_t tag, const Hit& h, bool) const {
-    P.hit[tag] = make_float4(h.t, h.u, h.v, __uint_as_float(h.slot));
-  }
-};
-
-template <bool STATS, bool CURVES>
-__global__ __launch_bounds__(kBlock) void k_trace_closest(PathState P, DScene sc) {
-  __shared__ uint32_t stk[kPvLdsStack * kBlock];
-  const uint32_t n = P.counts[kCntIn];
-  TravStats st = {};
-  uint32_t overflow = 0u;
-  ClosestSink sink = {P, sc};
-  trace_pv<false, STATS, CURVES>(sc, n, &P.counts[kCntHeadClosest], sink, stk + threadIdx.x, kBlock,
-                                 P.spill + blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, st, &overflow);
-  if (overflow) P.counts[kCntOverflow] = 1u;
-  if (STATS) {
-    uint32_t a = wave_sum(st.nodes), b = wave_sum(st.tris), c = wave_sum(st.curves);
-    if (__lane_id() == 0) {
-      atomicAdd(&P.stats[kStatClosestNodes], (unsigned long long)a);
-      atomicAdd(&P.stats[kStatClosestTris], (unsigned long long)b);
-      atomicAdd(&P.stats[kStatClosestCurves], (unsigned long long)c);
-      if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&P.stats[kStatClosestRays], (unsigned long long)n);
-      atomicAdd(&P.stats[kStatPvItNode], (unsigned long long)st.it_node);
-      atomicAdd(&P.stats[kStatPvItTri], (unsigned long long)st.it_tri);
-      atomicAdd(&P.stats[kStatPvItCurve], (unsigned long long)st.it_curve);
-      atomicAdd(&P.stats[kStatPvItRefill], (unsigned long long)st.it_refill);
-      atomicAdd(&P.stats[kStatPvLnNode], (unsigned long long)st.ln_node);
-      atomicAdd(&P.stats[kStatPvLnTri], (unsigned long long)st.ln_tri);
-      atomicAdd(&P.stats[kStatPvLnCurve], (unsigned long long)st.ln_curve);
+  uint32_t n_closest;
+  __device__ __forceinline__ bool load(uint32_t idx, uint32_t& tag, V3& o, V3& d, float& tmin, float& tmax) const {
+    if (idx < n_closest) {
+      tag = P.q_in[idx] & kQPathMask;
+      float4 o4 = P.ray_o[tag], d4 = P.ray_d[tag];
+      o = ld3(o4), d = ld3(d4), tmin = o4.w, tmax = d4.w;
+      return false;
     }
-  }
-}
-
-// Shadow rays + tail of DirectIllumination.  Shadow entry modes:
-//   kShNormal   L += c_vis when unoccluded
-//   kShSssEntry A  = 0 + c_vis when unoccluded (first NEE of a path that entered the medium)
-//   kShSssExit  L += unoccluded ? c_vis : c_occ
-struct ShadowSink {
-  const PathState& P;
-  __device__ __forceinline__ void load(uint32_t idx, uint32_t& tag, V3& o, V3& d, float& tmin, float& tmax) const {
-    tag = P.q_shadow[idx];
+    tag = P.q_shadow_in[idx - n_closest];
     float4 o4 = P.sh_o[tag], d4 = P.sh_d[tag];
     o = ld3(o4), d = ld3(d4), tmin = o4.w, tmax = d4.w;
+    tag |= 0x80000000u;
+    return true;
   }
-  __device__ __forceinline__ void done(uint32_t p, const Hit&, bool occluded) const {
+  __device__ __forceinline__ void done(uint32_t tag, const Hit& h, bool occluded) const {
+    const uint32_t p = tag & 0x7FFFFFFFu;
+    if (!(tag & 0x80000000u)) {
+      P.hit[p] = make_float4(h.t, h.u, h.v, __uint_as_float(h.slot));
+      return;
+    }
     float4 c = P.sh_c[p], e = P.sh_e[p];
     uint32_t mode = __float_as_uint(e.w);
     if (mode == kShSssEntry) {
@@ -136,22 +113,28 @@ struct ShadowSink {
 };
 
 template <bool STATS, bool CURVES>
-__global__ __launch_bounds__(kBlock) void k_trace_shadow(PathState P, DScene sc) {
+__global__ __launch_bounds__(kBlock) void k_trace(PathState P, DScene sc) {
   __shared__ uint32_t stk[kPvLdsStack * kBlock];
-  const uint32_t n = P.counts[kCntShadow];
+  const uint32_t n_closest = P.counts[kCntIn], n_shadow = P.counts[kCntShadowIn];
   TravStats st = {};
   uint32_t overflow = 0u;
-  ShadowSink sink = {P};
-  trace_pv<true, STATS, CURVES>(sc, n, &P.counts[kCntHeadShadow], sink, stk + threadIdx.x, kBlock,
-                                P.spill + blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, st, &overflow);
+  TraceSink sink = {P, n_closest};
+  trace_pv<2, STATS, CURVES>(sc, n_closest + n_shadow, &P.counts[kCntHead], sink, stk + threadIdx.x, kBlock,
+                             P.spill + blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, st, &overflow);
   if (overflow) P.counts[kCntOverflow] = 1u;
   if (STATS) {
-    uint32_t a = wave_sum(st.nodes), b = wave_sum(st.tris), c = wave_sum(st.curves);
-    if (__lane_id() == 0) {
-      atomicAdd(&P.stats[kStatShadowNodes], (unsigned long long)a);
-      atomicAdd(&P.stats[kStatShadowTris], (unsigned long long)b);
-      atomicAdd(&P.stats[kStatShadowCurves], (unsigned long long)c);
-      if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&P.stats[kStatShadowRays], (unsigned long long)n);
+    uint32_t v[13] = {st.nodes, st.tris, st.curves, st.anodes, st.atris, st.acurves, st.it_node, st.it_tri, st.it_curve,
+                      st.it_refill, st.ln_node, st.ln_tri, st.ln_curve};
+    const uint32_t idx[13] = {kStatClosestNodes, kStatClosestTris, kStatClosestCurves, kStatShadowNodes, kStatShadowTris,
+                              kStatShadowCurves, kStatPvItNode, kStatPvItTri, kStatPvItCurve, kStatPvItRefill,
+                              kStatPvLnNode, kStatPvLnTri, kStatPvLnCurve};
+    for (int i = 0; i < 13; i++) {
+      uint32_t s = wave_sum(v[i]);
+      if (__lane_id() == 0 && s) atomicAdd(&P.stats[idx[i]], (unsigned long long)s);
+    }
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+      atomicAdd(&P.stats[kStatClosestRays], (unsigned long long)n_closest);
+      atomicAdd(&P.stats[kStatShadowRays], (unsigned long long)n_shadow);
     }
   }
 }
@@ -705,10 +688,11 @@ struct HookSink {
   const float4* rays;
   HookHit* hits;
   uint8_t* occ;
-  __device__ __forceinline__ void load(uint32_t idx, uint32_t& tag, V3& o, V3& d, float& tmin, float& tmax) const {
+  __device__ __forceinline__ bool load(uint32_t idx, uint32_t& tag, V3& o, V3& d, float& tmin, float& tmax) const {
     tag = idx;
     float4 o4 = rays[2 * idx], d4 = rays[2 * idx + 1];
     o = ld3(o4), d = ld3(d4), tmin = o4.w, tmax = fminf(d4.w, INFINITY);  // raytracer_impl.cc:256
+    return occ != nullptr;
   }
   __device__ __forceinline__ void done(uint32_t i, const Hit& h, bool occluded) const {
     if (occ) occ[i] = occluded ? 1 : 0;
@@ -722,7 +706,7 @@ __global__ __launch_bounds__(kBlock) void k_hook_pv(DScene sc, const float4* __r
   TravStats st = {};
   uint32_t overflow = 0u;
   HookSink sink = {sc, rays, hits, occ};
-  trace_pv<ANY, false, true>(sc, n, &counts[kCntHeadClosest], sink, stk + threadIdx.x, kBlock,
+  trace_pv<ANY ? 1 : 0, false, true>(sc, n, &counts[kCntHead], sink, stk + threadIdx.x, kBlock,
                              spill + blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, st, &overflow);
   if (overflow) counts[kCntOverflow] = 1u;
 }
@@ -761,8 +745,9 @@ __global__ __launch_bounds__(kBlock) void k_hook_any(DScene sc, const float4* __
 __global__ void k_advance(uint32_t* counts) {
   if (threadIdx.x == 0) {
     counts[kCntIn] = counts[kCntOut];
+    counts[kCntShadowIn] = counts[kCntShadow];
     counts[kCntOut] = 0, counts[kCntPrincipled] = 0, counts[kCntHair] = 0, counts[kCntSss] = 0, counts[kCntShadow] = 0;
-    counts[kCntHeadClosest] = 0, counts[kCntHeadShadow] = 0;
+    counts[kCntHead] = 0;
   }
 }
 
@@ -774,25 +759,17 @@ static inline uint32_t grid_for(uint32_t n, uint32_t cap) {
 }
 
 void launch_generate(hipStream_t s, const PathState& P, const Camera& cam, const uint32_t* pix_index, uint32_t npix,
-                     uint32_t npaths, uint32_t width, uint32_t first_pass, uint64_t seed_seq) {
-  hipLaunchKernelGGL(k_generate, dim3(grid_for(npaths, 8192)), dim3(kBlock), 0, s, P, cam, pix_index, npix, npaths, width,
-                     first_pass, seed_seq);
+                     uint32_t npaths, uint32_t slot0, uint32_t width, uint32_t first_pass, uint64_t seed_seq) {
+  hipLaunchKernelGGL(k_generate, dim3(grid_for(npaths, 8192)), dim3(kBlock), 0, s, P, cam, pix_index, npix, npaths, slot0,
+                     width, first_pass, seed_seq);
 }
-void launch_trace_closest(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, bool stats) {
+void launch_trace(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, bool stats) {
   dim3 g(grid_for(n_upper, kTraceGridCap));
   const bool curves = sc.num_curves != 0;
-  if (stats && curves) hipLaunchKernelGGL((k_trace_closest<true, true>), g, dim3(kBlock), 0, s, P, sc);
-  else if (stats) hipLaunchKernelGGL((k_trace_closest<true, false>), g, dim3(kBlock), 0, s, P, sc);
-  else if (curves) hipLaunchKernelGGL((k_trace_closest<false, true>), g, dim3(kBlock), 0, s, P, sc);
-  else hipLaunchKernelGGL((k_trace_closest<false, false>), g, dim3(kBlock), 0, s, P, sc);
-}
-void launch_trace_shadow(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, bool stats) {
-  dim3 g(grid_for(n_upper, kTraceGridCap));
-  const bool curves = sc.num_curves != 0;
-  if (stats && curves) hipLaunchKernelGGL((k_trace_shadow<true, true>), g, dim3(kBlock), 0, s, P, sc);
-  else if (stats) hipLaunchKernelGGL((k_trace_shadow<true, false>), g, dim3(kBlock), 0, s, P, sc);
-  else if (curves) hipLaunchKernelGGL((k_trace_shadow<false, true>), g, dim3(kBlock), 0, s, P, sc);
-  else hipLaunchKernelGGL((k_trace_shadow<false, false>), g, dim3(kBlock), 0, s, P, sc);
+  if (stats && curves) hipLaunchKernelGGL((k_trace<true, true>), g, dim3(kBlock), 0, s, P, sc);
+  else if (stats) hipLaunchKernelGGL((k_trace<true, false>), g, dim3(kBlock), 0, s, P, sc);
+  else if (curves) hipLaunchKernelGGL((k_trace<false, true>), g, dim3(kBlock), 0, s, P, sc);
+  else hipLaunchKernelGGL((k_trace<false, false>), g, dim3(kBlock), 0, s, P, sc);
 }
 static inline uint32_t tiles_grid(uint32_t n_upper) {
   uint32_t g = (n_upper + kTileItems - 1) / kTileItems;

@@ -119,14 +119,15 @@ struct pbrhip_scene {
   // render working set (grown on demand, reused across calls)
   DevBuf<float4> ray_o, ray_d, thr, L, hit, sss[6], sh[4];
   DevBuf<uint64_t> rng;
-  DevBuf<uint32_t> flags, q[6], counts, pix_index, spill;
+  DevBuf<uint32_t> flags, q[7], counts, pix_index, spill;
   DevBuf<unsigned long long> stats;
   DevBuf<float> own_rgba;
   DevBuf<uint32_t> own_count;
   DevBuf<float4> hook_rays;
   DevBuf<HookHit> hook_hits;
   DevBuf<uint8_t> hook_occ;
-  uint32_t* h_counts = nullptr;  // pinned
+  uint32_t* h_counts = nullptr;  // pinned, kMaxGroups x kCntNum
+  std::vector<hipStream_t> group_streams;  // streams of path groups 1.. (group 0 uses `stream`)
   // pixel list cache key
   uint32_t pk_w = 0, pk_h = 0, pk_rank = 0, pk_world = 0, pk_npix = 0;
   std::vector<hipEvent_t> events;
@@ -148,7 +149,7 @@ extern "C" int pbrhip_scene_create(pbrhip_scene** out) {
   std::unique_ptr<pbrhip_scene> s(new pbrhip_scene());
   s->device = g_device;
   HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-  HIPCHK(hipHostMalloc((void**)&s->h_counts, sizeof(uint32_t) * kCntNum, hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&s->h_counts, sizeof(uint32_t) * kCntNum * kMaxGroups, hipHostMallocDefault));
   memset(&s->dscene, 0, sizeof(s->dscene));
   *out = s.release();
   return PBRHIP_OK;
@@ -159,6 +160,7 @@ extern "C" int pbrhip_scene_destroy(pbrhip_scene* s) {
   (void)hipSetDevice(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
+  for (hipStream_t g : s->group_streams) (void)hipStreamDestroy(g);
   if (s->h_counts) (void)hipHostFree(s->h_counts);
   hipStream_t st = s->stream;
   delete s;
@@ -639,11 +641,13 @@ static Camera make_camera(const pbrhip_scene* s, uint32_t width, uint32_t height
 }
 
 // ------------------------------------------------------------------ render
-static constexpr uint64_t kBytesPerPath = 5 * 16 + 8 + 4 + 6 * 16 + 6 * 4 + 4 * 16;  // ensure_paths()
+static constexpr uint64_t kBytesPerPath = 5 * 16 + 8 + 4 + 6 * 16 + 7 * 4 + 4 * 16;  // ensure_paths()
 namespace {
 struct Timer {
   pbrhip_scene* s;
   bool on;
+  hipStream_t stream;
+  std::vector<hipEvent_t> events;  // owned by the scene's pool once collected
   size_t used = 0;
   struct Rec {
     size_t ev;
@@ -652,18 +656,23 @@ struct Timer {
   std::vector<Rec> recs;
   hipError_t begin(double* acc) {
     if (!on) return hipSuccess;
-    while (s->events.size() < used + 2) {
+    while (events.size() < used + 2) {
       hipEvent_t e;
-      hipError_t rc = hipEventCreate(&e);
-      if (rc != hipSuccess) return rc;
-      s->events.push_back(e);
+      if (!s->events.empty()) {
+        e = s->events.back();
+        s->events.pop_back();
+      } else {
+        hipError_t rc = hipEventCreate(&e);
+        if (rc != hipSuccess) return rc;
+      }
+      events.push_back(e);
     }
     recs.push_back({used, acc});
-    return hipEventRecord(s->events[used], s->stream);
+    return hipEventRecord(events[used], stream);
   }
   hipError_t end() {
     if (!on) return hipSuccess;
-    hipError_t rc = hipEventRecord(s->events[used + 1], s->stream);
+    hipError_t rc = hipEventRecord(events[used + 1], stream);
     used += 2;
     return rc;
   }
@@ -672,12 +681,14 @@ struct Timer {
     if (!on) return hipSuccess;
     for (const Rec& r : recs) {
       float ms = 0.f;
-      hipError_t rc = hipEventElapsedTime(&ms, s->events[r.ev], s->events[r.ev + 1]);
+      hipError_t rc = hipEventElapsedTime(&ms, events[r.ev], events[r.ev + 1]);
       if (rc != hipSuccess) return rc;
       *r.acc += (double)ms;
     }
     recs.clear();
     used = 0;
+    for (hipEvent_t e : events) s->events.push_back(e);  // back to the scene's pool
+    events.clear();
     return hipSuccess;
   }
 };
@@ -701,6 +712,17 @@ static int ensure_pixels(pbrhip_scene* s, uint32_t w, uint32_t h, uint32_t rank,
   return PBRHIP_OK;
 }
 
+static int ensure_groups(pbrhip_scene* s, uint32_t groups) {
+  while (s->group_streams.size() + 1 < groups) {
+    hipStream_t g;
+    HIPCHK(hipStreamCreateWithFlags(&g, hipStreamNonBlocking));
+    s->group_streams.push_back(g);
+  }
+  HIPCHK(s->counts.reserve(kCntNum * kMaxGroups));
+  HIPCHK(s->spill.reserve((size_t)groups * kStackDepth * kTraceGridCap * 256));
+  return PBRHIP_OK;
+}
+
 static int ensure_paths(pbrhip_scene* s, size_t n) {
   HIPCHK(s->ray_o.reserve(n));
   HIPCHK(s->ray_d.reserve(n));
@@ -712,9 +734,8 @@ static int ensure_paths(pbrhip_scene* s, size_t n) {
   HIPCHK(s->rng.reserve(n));
   HIPCHK(s->flags.reserve(n));
   for (auto& b : s->q) HIPCHK(b.reserve(n));
-  HIPCHK(s->counts.reserve(kCntNum));
+  HIPCHK(s->counts.reserve(kCntNum * kMaxGroups));
   HIPCHK(s->stats.reserve(kStatNum));
-  HIPCHK(s->spill.reserve((size_t)kStackDepth * kTraceGridCap * 256));
   return PBRHIP_OK;
 }
 
@@ -739,7 +760,6 @@ static int render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volat
   if (int rc = ensure_pixels(s, d->width, d->height, d->tile_rank, world)) return rc;
   const uint32_t npix = s->pk_npix;
   const bool want_stats = (d->flags & PBRHIP_RENDER_STATS) != 0;
-  Timer tm{s, (d->flags & PBRHIP_RENDER_TIMING) != 0};
   if (npix > 0 && d->num_sample > 0) {
     // default: as many paths in flight as half of the free HBM holds (288 GB: a whole 1080p x 64 spp frame,
     // 132.7 M paths x ~272 B, is one chunk) -- fewer, larger launches and one tail instead of many
@@ -770,7 +790,7 @@ static int render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volat
     P.rng = s->rng.p, P.flags = s->flags.p;
     P.sss_sigt = s->sss[0].p, P.sss_sigs = s->sss[1].p, P.sss_thr = s->sss[2].p, P.sss_pdf = s->sss[3].p;
     P.sss_ez = s->sss[4].p, P.sss_A = s->sss[5].p;
-    P.q_in = s->q[0].p, P.q_out = s->q[1].p, P.q_principled = s->q[2].p, P.q_hair = s->q[3].p, P.q_sss = s->q[4].p, P.q_shadow = s->q[5].p;
+    P.q_in = s->q[0].p, P.q_out = s->q[1].p, P.q_principled = s->q[2].p, P.q_hair = s->q[3].p, P.q_sss = s->q[4].p, P.q_shadow = s->q[5].p, P.q_shadow_in = s->q[6].p;
     P.sh_o = s->sh[0].p, P.sh_d = s->sh[1].p, P.sh_c = s->sh[2].p, P.sh_e = s->sh[3].p;
     P.counts = s->counts.p, P.stats = s->stats.p, P.spill = s->spill.p;
     HIPCHK(hipMemsetAsync(P.stats, 0, sizeof(unsigned long long) * kStatNum, st));
@@ -778,70 +798,115 @@ static int render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volat
     const uint64_t rng_inc = (d->seed_seq << 1u) | 1u;  // pcg32_srandom (rng.h:30-36)
     const DScene& sc = s->dscene;
 
+    // Path GROUPS: the passes of a chunk are split into up to kMaxGroups independent sub-populations, each with
+    // its own queues, counters and HIP stream.  Every wavefront iteration ends in a latency-bound drain (the
+    // slowest ray's dependent-load chain: 0.1-0.4 ms with the GPU almost idle); with several groups in flight
+    // one group's drain overlaps the others' bulk work.  Path slots stay global, so results are unchanged.
+    uint32_t want_groups = d->num_streams ? d->num_streams : 1u;
+    if (const char* e = getenv("PBRHIP_STREAMS")) want_groups = (uint32_t)atoi(e);
+    want_groups = std::max(1u, std::min(want_groups, (uint32_t)kMaxGroups));
+    if (int rc = ensure_groups(s, want_groups)) return rc;
+    struct Group {
+      PathState P;
+      hipStream_t st;
+      uint32_t* h_counts;
+      uint32_t n, first_pass, npass, slot0;
+      Timer tm;
+    };
+
     for (uint32_t done = 0; done < d->num_sample;) {
       if (cancel && *cancel) break;  // render.cc:217 (cooperative, chunk granularity)
       uint32_t np = std::min(chunk_passes, d->num_sample - done);
-      uint32_t n = np * npix;
-      memset(s->h_counts, 0, sizeof(uint32_t) * kCntNum);
-      s->h_counts[kCntIn] = n;
-      HIPCHK(hipMemcpyAsync(P.counts, s->h_counts, sizeof(uint32_t) * kCntNum, hipMemcpyHostToDevice, st));
-      HIPCHK(tm.begin(&S.ms_generate));
-      launch_generate(st, P, cam, s->pix_index.p, npix, n, d->width, d->first_pass + done, d->seed_seq);
-      HIPCHK(tm.end());
-      while (n > 0) {
+      const uint32_t ng = std::min(want_groups, np);
+      HIPCHK(hipStreamSynchronize(st));  // clears / previous chunk's accumulate are done before groups start
+      std::vector<Group> G;
+      G.reserve(ng);
+      for (uint32_t g = 0; g < ng; g++) {
+        uint32_t p0 = (uint32_t)((uint64_t)np * g / ng), p1 = (uint32_t)((uint64_t)np * (g + 1) / ng);
+        Group gr{P, g == 0 ? st : s->group_streams[g - 1], s->h_counts + g * kCntNum, (p1 - p0) * npix,
+                 d->first_pass + done + p0, p1 - p0, p0 * npix, Timer{s, (d->flags & PBRHIP_RENDER_TIMING) != 0, g == 0 ? st : s->group_streams[g - 1]}};
+        const size_t off = gr.slot0;
+        gr.P.q_in += off, gr.P.q_out += off, gr.P.q_principled += off, gr.P.q_hair += off, gr.P.q_sss += off, gr.P.q_shadow += off, gr.P.q_shadow_in += off;
+        gr.P.counts = s->counts.p + g * kCntNum;
+        gr.P.spill = s->spill.p + (size_t)g * kStackDepth * kTraceGridCap * 256;
+        G.push_back(gr);
+      }
+      auto enqueue = [&](Group& gr) -> int {
         // Long tails (few paths, many bounces) are latency-bound: below 256 Ki active paths several iterations
         // are queued per host round trip (kernels read their counts on the device and fall through when empty).
-        const int burst = n < (1u << 18) ? 8 : 1;
+        const int burst = gr.n < (1u << 18) ? 8 : 1;
+        const uint32_t n = std::max(gr.n, 1u);
         for (int it = 0; it < burst; it++) {
-          HIPCHK(tm.begin(&S.ms_trace_closest));
-          launch_trace_closest(st, P, sc, n, want_stats);
-          HIPCHK(tm.end());
-          HIPCHK(tm.begin(&S.ms_surface));
-          launch_classify(st, P, sc, n);
-          HIPCHK(tm.end());
-          HIPCHK(tm.begin(&S.ms_shade_principled));
-          launch_shade_principled(st, P, sc, n, rng_inc);
-          HIPCHK(tm.end());
+          HIPCHK(gr.tm.begin(&S.ms_trace_closest));
+          launch_trace(gr.st, gr.P, sc, 2 * n, want_stats);  // this bounce's closest rays + last bounce's shadow rays
+          HIPCHK(gr.tm.end());
+          HIPCHK(gr.tm.begin(&S.ms_surface));
+          launch_classify(gr.st, gr.P, sc, n);
+          HIPCHK(gr.tm.end());
+          HIPCHK(gr.tm.begin(&S.ms_shade_principled));
+          launch_shade_principled(gr.st, gr.P, sc, n, rng_inc);
+          HIPCHK(gr.tm.end());
           if (s->has_hair) {
-            HIPCHK(tm.begin(&S.ms_shade_hair));
-            launch_shade_hair(st, P, sc, n, rng_inc);
-            HIPCHK(tm.end());
+            HIPCHK(gr.tm.begin(&S.ms_shade_hair));
+            launch_shade_hair(gr.st, gr.P, sc, n, rng_inc);
+            HIPCHK(gr.tm.end());
             S.n_shade_hair++;
           }
           if (s->has_sss) {
-            HIPCHK(tm.begin(&S.ms_sss_step));
-            launch_sss_step(st, P, sc, n, rng_inc);
-            HIPCHK(tm.end());
+            HIPCHK(gr.tm.begin(&S.ms_sss_step));
+            launch_sss_step(gr.st, gr.P, sc, n, rng_inc);
+            HIPCHK(gr.tm.end());
             S.n_sss_step++;
           }
-          HIPCHK(tm.begin(&S.ms_compact));
-          launch_compact(st, P, n);
-          HIPCHK(tm.end());
-          HIPCHK(tm.begin(&S.ms_trace_shadow));
-          launch_trace_shadow(st, P, sc, n, want_stats);
-          HIPCHK(tm.end());
-          S.n_trace_closest++, S.n_trace_shadow++, S.n_surface++, S.n_shade_principled++;
-          launch_advance(st, P);
-          std::swap(P.q_in, P.q_out);
+          HIPCHK(gr.tm.begin(&S.ms_compact));
+          launch_compact(gr.st, gr.P, n);
+          HIPCHK(gr.tm.end());
+          S.n_trace_closest++, S.n_surface++, S.n_shade_principled++;
+          launch_advance(gr.st, gr.P);
+          std::swap(gr.P.q_in, gr.P.q_out);
+          std::swap(gr.P.q_shadow, gr.P.q_shadow_in);
           S.iterations++;
         }
-        HIPCHK(hipMemcpyAsync(s->h_counts, P.counts, sizeof(uint32_t) * kCntNum, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        HIPCHK(tm.collect());
-        if (s->h_counts[kCntOverflow]) return fail(PBRHIP_EOVERFLOW, "BVH traversal stack overflow");
-        n = s->h_counts[kCntIn];
+        HIPCHK(hipMemcpyAsync(gr.h_counts, gr.P.counts, sizeof(uint32_t) * kCntNum, hipMemcpyDeviceToHost, gr.st));
+        return PBRHIP_OK;
+      };
+      for (Group& gr : G) {
+        memset(gr.h_counts, 0, sizeof(uint32_t) * kCntNum);
+        gr.h_counts[kCntIn] = gr.n;
+        HIPCHK(hipMemcpyAsync(gr.P.counts, gr.h_counts, sizeof(uint32_t) * kCntNum, hipMemcpyHostToDevice, gr.st));
+        HIPCHK(gr.tm.begin(&S.ms_generate));
+        launch_generate(gr.st, gr.P, cam, s->pix_index.p, npix, gr.n, gr.slot0, d->width, gr.first_pass, d->seed_seq);
+        HIPCHK(gr.tm.end());
+        if (int rc = enqueue(gr)) return rc;
       }
+      // round-robin: wait for a group's burst, queue its next one, move on -- every live group keeps work in flight
+      for (uint32_t live = ng; live > 0;) {
+        for (Group& gr : G) {
+          if (gr.n == 0) continue;
+          HIPCHK(hipStreamSynchronize(gr.st));
+          HIPCHK(gr.tm.collect());
+          if (gr.h_counts[kCntOverflow]) return fail(PBRHIP_EOVERFLOW, "BVH traversal stack overflow");
+          gr.n = std::max(gr.h_counts[kCntIn], gr.h_counts[kCntShadowIn]);  // pending shadow rays need one more trace
+          if (gr.n == 0) {
+            live--;
+            continue;
+          }
+          if (int rc = enqueue(gr)) return rc;
+        }
+      }
+      Timer tm{s, (d->flags & PBRHIP_RENDER_TIMING) != 0, st};
       HIPCHK(tm.begin(&S.ms_accumulate));
       launch_accumulate(st, P, s->pix_index.p, npix, np, d_rgba, d_count);
       HIPCHK(tm.end());
       HIPCHK(hipGetLastError());
+      HIPCHK(hipStreamSynchronize(st));
+      HIPCHK(tm.collect());
       done += np;
       S.chunks++;
       S.samples += (uint64_t)np * npix;
       if (finish_pass) *finish_pass = done;  // render.cc:224-231
     }
     HIPCHK(hipStreamSynchronize(st));
-    HIPCHK(tm.collect());
     if (want_stats) {
       unsigned long long hs[kStatNum];
       HIPCHK(hipMemcpy(hs, P.stats, sizeof(hs), hipMemcpyDeviceToHost));
@@ -901,7 +966,7 @@ extern "C" int pbrhip_trace_closest(pbrhip_scene* s, const pbrhip_ray* rays, siz
   HIPCHK(hipSetDevice(s->device));
   HIPCHK(s->hook_rays.reserve(2 * n));
   HIPCHK(s->hook_hits.reserve(n));
-  HIPCHK(s->counts.reserve(kCntNum));
+  HIPCHK(s->counts.reserve(kCntNum * kMaxGroups));
   HIPCHK(hipMemsetAsync(s->counts.p, 0, sizeof(uint32_t) * kCntNum, s->stream));
   HIPCHK(hipMemcpyAsync(s->hook_rays.p, rays, n * sizeof(pbrhip_ray), hipMemcpyHostToDevice, s->stream));
   HIPCHK(s->spill.reserve((size_t)kStackDepth * kTraceGridCap * 256));
@@ -922,7 +987,7 @@ extern "C" int pbrhip_trace_any(pbrhip_scene* s, const pbrhip_ray* rays, size_t 
   HIPCHK(hipSetDevice(s->device));
   HIPCHK(s->hook_rays.reserve(2 * n));
   HIPCHK(s->hook_occ.reserve(n));
-  HIPCHK(s->counts.reserve(kCntNum));
+  HIPCHK(s->counts.reserve(kCntNum * kMaxGroups));
   HIPCHK(hipMemsetAsync(s->counts.p, 0, sizeof(uint32_t) * kCntNum, s->stream));
   HIPCHK(hipMemcpyAsync(s->hook_rays.p, rays, n * sizeof(pbrhip_ray), hipMemcpyHostToDevice, s->stream));
   HIPCHK(s->spill.reserve((size_t)kStackDepth * kTraceGridCap * 256));

@@ -7,5 +7,5 @@ variant = os.environ.get("VARIANT", "ggx")
 desc = scenes.hair_scene(seed=1) if variant == "hair" else scenes.cornell_scene(variant, seed=1)
 s = pa.scene_from_desc(desc)
 layer = pa.RenderLayer()
-ok, st = pa.Render(s, 1920, 1080, int(os.environ.get("SPP", "1")), layer=layer)
+ok, st = pa.Render(s, 1920, 1080, int(os.environ.get("SPP", "1")), layer=layer, tile_world=int(os.environ.get("WORLD", "1")))
 print(st["ms_total"], st["iterations"])
