@@ -43,7 +43,7 @@ typedef struct {
   float subsurface_color[3];
   float metallic, specular, specular_tint, roughness, anisotropic, anisotropic_rotation;
   float sheen, sheen_tint, clearcoat, clearcoat_roughness, ior, transmission, transmission_roughness;
-  uint32_t base_color_tex_id, subsurface_color_tex_id; /* PBRHIP_NONE: textures are row N4 (not yet) */
+  uint32_t base_color_tex_id, subsurface_color_tex_id; /* PBRHIP_NONE or an id from pbrhip_scene_add_texture */
 } pbrhip_principled_param;
 
 /* pbrlab::HairBsdfParameter (src/material-param.h:51-72) */
@@ -124,6 +124,11 @@ int pbrhip_scene_add_curve_mesh(pbrhip_scene*, const float* vertices_xyzr, uint3
 /* Scene::AddMaterialParam (scene.h:39-44) for the two alternatives of MaterialParameter */
 int pbrhip_scene_add_principled_material(pbrhip_scene*, const pbrhip_principled_param*, uint32_t* material_id);
 int pbrhip_scene_add_hair_material(pbrhip_scene*, const pbrhip_hair_param*, uint32_t* material_id);
+/* Scene::AddTexture (scene.h:46-51) with pbrlab::Texture (src/texture.h:13-44): float pixels, row-major, `channels`
+ * (1..4) interleaved; sampled bilinearly with clamp addressing like Texture::FetchFloat3 (texture.cc:43-68,
+ * image-utils.cc:99-167).  Referenced by base_color_tex_id / subsurface_color_tex_id; ids are checked at commit. */
+int pbrhip_scene_add_texture(pbrhip_scene*, const float* pixels, uint32_t width, uint32_t height, uint32_t channels,
+                             uint32_t* texture_id);
 /* Scene::AddLightParam (scene.h:34-37) with AreaLightParameter (light-param.h:20-23) */
 int pbrhip_scene_add_area_light(pbrhip_scene*, const float emission[3], uint32_t* light_id);
 /* Scene::CreateLocalScene (scene.cc:157-164), AddMeshToLocalScene (scene.cc:14-62), CreateInstance (scene.cc:106-155;

@@ -88,6 +88,13 @@ public:
                                       uint32_t(indices.size()), &m.id));
     return m;
   }
+  // Scene::AddTexture(pixels, width, height, channels, name) (scene.h:46-51, texture.cc:10-21)
+  uint32_t AddTexture(const std::vector<float>& pixels, uint32_t width, uint32_t height, uint32_t channels,
+                      const std::string& /*name*/ = "") {
+    uint32_t id;
+    Check(pbrhip_scene_add_texture(h_, pixels.data(), width, height, channels, &id));
+    return id;
+  }
   uint32_t AddLightParam(const AreaLightParameter& p) {
     uint32_t id;
     Check(pbrhip_scene_add_area_light(h_, p.emission, &id));

@@ -72,6 +72,11 @@ typedef struct {
   uint32_t instance_id, geom_id;
 } orc_light;
 
+typedef struct orc_texture {
+  float* pixels;
+  uint32_t width, height, channels;
+} orc_texture;
+
 /* flattened primitive reference used by the BVH */
 typedef struct {
   uint32_t instance_id, geom_id, prim_id, kind;
@@ -91,6 +96,8 @@ struct orc_scene {
   uint32_t ninstances;
   orc_material* materials;
   uint32_t nmaterials;
+  struct orc_texture* textures; /* src/texture.h:13-44 */
+  uint32_t ntextures;
   f3* light_params; /* AreaLightParameter.emission */
   uint32_t nlight_params;
   orc_light* lights;
@@ -149,6 +156,8 @@ void orc_scene_destroy(orc_scene* s) {
     free(in->material_ids), free(in->nmaterial_ids), free(in->light_ids), free(in->nlight_ids);
     free(in->area_lights);
   }
+  for (uint32_t i = 0; i < s->ntextures; i++) free(s->textures[i].pixels);
+  free(s->textures);
   free(s->meshes), free(s->locals), free(s->instances), free(s->materials), free(s->light_params);
   free(s->lights), free(s->light_cdf), free(s->prims), free(s->prim_geo), free(s->order), free(s->nodes);
   free(s);
@@ -214,6 +223,49 @@ int orc_add_hair(orc_scene* s, const orc_hair_param* p) {
   s->materials[s->nmaterials].hr = *p;
   return (int)s->nmaterials++;
 }
+/* Scene::AddTexture (scene.h:46-51) with Texture(pixels, width, height, channels) (texture.cc:10-21) */
+int orc_add_texture(orc_scene* s, const float* pixels, uint32_t width, uint32_t height, uint32_t channels) {
+  s->textures = (orc_texture*)xrealloc(s->textures, sizeof(orc_texture) * (s->ntextures + 1));
+  orc_texture* t = &s->textures[s->ntextures];
+  t->pixels = (float*)xdup(pixels, sizeof(float) * (size_t)width * height * channels);
+  t->width = width, t->height = height, t->channels = channels;
+  return (int)s->ntextures++;
+}
+/* BilinearFilter with clamp addressing (image-utils.cc:99-167) behind Texture::FetchFloat3 (texture.cc:43-68):
+ * px = width*u (no half-texel offset), channels beyond the image's are 0 */
+static void texture_fetch3(const orc_texture* t, float u, float v, float dst[3]) {
+  float uu = orc_max(u, 0.0f);
+  uu = orc_min(uu, 1.0f);
+  float vv = orc_max(v, 0.0f);
+  vv = orc_min(vv, 1.0f);
+  const int width = (int)t->width, height = (int)t->height, stride = (int)t->channels;
+  const float px = (float)t->width * uu;
+  const float py = (float)t->height * vv;
+  int x0 = (int)px, y0 = (int)py;
+  x0 = x0 < width - 1 ? x0 : width - 1;   /* std::min(int(width) - 1, int(px)) */
+  x0 = x0 > 0 ? x0 : 0;                   /* std::max(0, ...) */
+  y0 = y0 < height - 1 ? y0 : height - 1;
+  y0 = y0 > 0 ? y0 : 0;
+  const int x1 = ((x0 + 1) >= width) ? (width - 1) : (x0 + 1);
+  const int y1 = ((y0 + 1) >= height) ? (height - 1) : (y0 + 1);
+  const float dx = px - (float)x0;
+  const float dy = py - (float)y0;
+  const float w0 = (1.0f - dx) * (1.0f - dy), w1 = (1.0f - dx) * dy, w2 = dx * (1.0f - dy), w3 = dx * dy;
+  const int i00 = stride * (y0 * width + x0), i01 = stride * (y0 * width + x1);
+  const int i10 = stride * (y1 * width + x0), i11 = stride * (y1 * width + x1);
+  for (int i = 0; i < 3; i++) {
+    if (i < stride)
+      dst[i] = t->pixels[i00 + i] * w0 + t->pixels[i10 + i] * w1 + t->pixels[i01 + i] * w2 + t->pixels[i11 + i] * w3;
+    else
+      dst[i] = 0.f;
+  }
+}
+void orc_kat_texture_fetch(const float* pixels, uint32_t width, uint32_t height, uint32_t channels, float u, float v,
+                           float out[3]) {
+  orc_texture t = {(float*)pixels, width, height, channels};
+  texture_fetch3(&t, u, v, out);
+}
+
 int orc_add_area_light(orc_scene* s, const float emission[3]) {
   s->light_params = (f3*)xrealloc(s->light_params, sizeof(f3) * (s->nlight_params + 1));
   s->light_params[s->nlight_params] = f3_make(emission[0], emission[1], emission[2]);
@@ -964,6 +1016,7 @@ typedef struct {
   float u, v;
   uint32_t instance_id, geom_id, prim_id;
   f3 global_position, normal_s, normal_g;
+  float texcoord[2];
   int face_direction;
   const orc_material* material;
 } orc_surface;
@@ -1011,6 +1064,17 @@ static orc_surface trace_result_to_surface(const orc_scene* s, const orc_rayf* r
   f3 ng = f3_make(tr->normal_g[0], tr->normal_g[1], tr->normal_g[2]);
   si.normal_s = (m->kind == 0) ? mesh_shading_normal(m, tr->prim_id, tr->u, tr->v) : ng;
   si.normal_g = ng;
+  /* Scene::FetchMeshTexcoord (scene.cc:230-249) + TriangleMesh::FetchTexcoord (mesh/triangle-mesh.cc:126-156) */
+  si.texcoord[0] = si.texcoord[1] = 0.f;
+  if (m->kind == 0) {
+    uint32_t a = m->tid[tr->prim_id * 3 + 0], b = m->tid[tr->prim_id * 3 + 1], c = m->tid[tr->prim_id * 3 + 2];
+    if (a == ORC_NONE || b == ORC_NONE || c == ORC_NONE) {
+      si.texcoord[0] = tr->u, si.texcoord[1] = tr->v;
+    } else {
+      const float *ta = m->uvs + (size_t)a * 2, *tb = m->uvs + (size_t)b * 2, *tc = m->uvs + (size_t)c * 2;
+      for (int k = 0; k < 2; k++) si.texcoord[k] = (1.0f - tr->u - tr->v) * ta[k] + tr->u * tb[k] + tr->v * tc[k];
+    }
+  }
   float dg = f3_dot(ray->dir, si.normal_g), ds = f3_dot(ray->dir, si.normal_s);
   if (dg < 0.0f && ds < 0.0f)
     si.face_direction = ORC_FRONT;
@@ -1401,13 +1465,23 @@ static void sample_bsdf(orc_ctx* c, f3 omega_out, const orc_bsdf* b, orc_rng* rn
   eval_bsdf(*omega_in, omega_out, b, bsdf_f, pdf);
 }
 
-/* cycles-principled-shader.cc:244-412 (textures: row N4, not yet in the oracle) */
-static void param_to_bsdf(const orc_principled_param* mp, orc_bsdf* bsdf) {
+/* cycles-principled-shader.cc:244-412; scene/uv may be NULL when the material has no texture */
+static void param_to_bsdf(const orc_scene* scene, const float* uv, const orc_principled_param* mp, orc_bsdf* bsdf) {
   f3 weight = f3_set1(1.f);
   f3 base_color = f3_make(mp->base_color[0], mp->base_color[1], mp->base_color[2]);
+  if (mp->base_color_tex_id != ORC_NONE) { /* :281-288 */
+    float c[3];
+    texture_fetch3(&scene->textures[mp->base_color_tex_id], uv[0], uv[1], c);
+    base_color = f3_make(c[0], c[1], c[2]);
+  }
   float subsurface = mp->subsurface;
   f3 subsurface_radius = f3_make(mp->subsurface_radius[0], mp->subsurface_radius[1], mp->subsurface_radius[2]);
   f3 subsurface_color = f3_make(mp->subsurface_color[0], mp->subsurface_color[1], mp->subsurface_color[2]);
+  if (mp->subsurface_color_tex_id != ORC_NONE) { /* :292-301 */
+    float c[3];
+    texture_fetch3(&scene->textures[mp->subsurface_color_tex_id], uv[0], uv[1], c);
+    subsurface_color = f3_make(c[0], c[1], c[2]);
+  }
   const float cutoff = ORC_EPS;
   bsdf_default(bsdf);
   float diffuse_w = (1.0f - orc_saturate(mp->metallic)) * (1.0f - orc_saturate(mp->transmission));
@@ -1475,7 +1549,7 @@ static void principled_shader(orc_ctx* c, f3 global_omega_out, orc_rng* rng, orc
   orc_mat3 Rgl = global_to_local(ex, ey, ez);
   f3 omega_out = mult_v(global_omega_out, &Rgl);
   orc_bsdf bsdf;
-  param_to_bsdf(&si->material->pr, &bsdf);
+  param_to_bsdf(c->scene, si->texcoord, &si->material->pr, &bsdf);
   *contribute = f3_set1(0.f);
   {
     orc_eval ev = {0, &bsdf, NULL};
@@ -1902,7 +1976,7 @@ void orc_kat_triangle_sampler(float u1, float u2, float out[2]) { orc_triangle_u
  *      [24] en_coat [25..27] coat_w [28] cax [29] cay [30] cior [31..33] coat_color */
 void orc_kat_param_to_bsdf(const orc_principled_param* p, float out[34]) {
   orc_bsdf b;
-  param_to_bsdf(p, &b);
+  param_to_bsdf(NULL, NULL, p, &b);
   out[0] = (float)b.enable_diffuse, out[1] = b.diffuse_weight.x, out[2] = b.diffuse_weight.y, out[3] = b.diffuse_weight.z;
   out[4] = (float)b.enable_subsurface;
   out[5] = b.subsurface_weight.x, out[6] = b.subsurface_weight.y, out[7] = b.subsurface_weight.z;

@@ -82,6 +82,10 @@ int orc_add_curve_mesh(orc_scene*, const float* vertices_xyzr, uint32_t num_vert
 int orc_add_principled(orc_scene*, const orc_principled_param*);
 int orc_add_hair(orc_scene*, const orc_hair_param*);
 int orc_add_area_light(orc_scene*, const float emission[3]);
+/* Scene::AddTexture (scene.h:46-51): float pixels, row-major, `channels` interleaved */
+int orc_add_texture(orc_scene*, const float* pixels, uint32_t width, uint32_t height, uint32_t channels);
+void orc_kat_texture_fetch(const float* pixels, uint32_t width, uint32_t height, uint32_t channels, float u, float v,
+                           float out[3]);
 int orc_create_local_scene(orc_scene*);
 int orc_add_mesh_to_local_scene(orc_scene*, uint32_t local_scene_id, uint32_t mesh_id);
 int orc_create_instance(orc_scene*, uint32_t local_scene_id, const float transform[16]);

@@ -8,7 +8,8 @@
 // Only reference files whose includes resolve inside /root/reference/src are used:
 //   random/rng.h, sampler/sampling-utils.h, pbrlab_math.h, pbrlab-util.h, type.h (+ nanort.h),
 //   closure/{lambert,closure-util,microfacet-ggx}.h, closure/energy‐conserving-hair-bsdf.h,
-//   matrix.{h,cc}, render-tile.{h,cc}, curve-util.{h,cc}, mesh/triangle-mesh.{h,cc}, mesh/attribute.h.
+//   matrix.{h,cc}, render-tile.{h,cc}, curve-util.{h,cc}, mesh/triangle-mesh.{h,cc}, mesh/attribute.h,
+//   texture.{h,cc}, image-utils.{h,cc}.
 // Anything that needs mpark/variant.hpp or embree4/rtcore.h (shaders, Scene, LightManager, render.cc,
 // raytracer) is NOT built: those headers are absent and no stand-ins are written.
 #include <array>
@@ -29,6 +30,8 @@
 #include "random/rng.h"
 #include "render-tile.h"
 #include "sampler/sampling-utils.h"
+#include "texture.h"
+#include "image-utils.h"
 #include "type.h"
 
 using namespace pbrlab;
@@ -186,6 +189,16 @@ void ref_triangle_fetch(const float* vertices_xyzw, uint32_t nv, const float* no
   if (what == 3) r = float3(mesh.FetchFaceArea(prim));
   out[0] = r[0], out[1] = r[1], out[2] = r[2];
 }
+
+// Texture::FetchFloat3 (texture.cc:65-67) -> BilinearFilter (image-utils.cc:99-167)
+void ref_texture_fetch(const float* pixels, uint32_t width, uint32_t height, uint32_t channels, float u, float v,
+                       float out[3]) {
+  Texture tex(std::vector<float>(pixels, pixels + size_t(width) * height * channels), width, height, channels, "t");
+  tex.FetchFloat3(u, v, out);
+}
+// LinerTosRGB / SrgbToLiner (image-utils.cc:10-38): the CLI's output stage (pc/pbrlab-cli.cc:56)
+float ref_linear_to_srgb(float c) { return LinerTosRGB(c); }
+float ref_srgb_to_linear(float c) { return SrgbToLiner(c); }
 
 float ref_spectrum_norm(const float c[3]) { return SpectrumNorm(float3(c)); }
 float ref_rgb_to_y(const float c[3]) { return RgbToY(float3(c)); }

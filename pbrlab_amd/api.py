@@ -196,6 +196,15 @@ class Scene:
         else:
             _chk(self.L.pbrhip_scene_update_hair_material(self.h, material_id, C.byref(p)))
 
+    def AddTexture(self, pixels):
+        """Scene::AddTexture: pixels (H, W, C) float32."""
+        px = np.ascontiguousarray(pixels, np.float32)
+        if px.ndim == 2:
+            px = px[..., None]
+        out = C.c_uint32()
+        _chk(self.L.pbrhip_scene_add_texture(self.h, _ptr(px), px.shape[1], px.shape[0], px.shape[2], C.byref(out)))
+        return out.value
+
     def AddLightParam(self, emission):
         e = np.ascontiguousarray(emission, np.float32).reshape(3)
         out = C.c_uint32()

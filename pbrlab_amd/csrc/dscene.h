@@ -7,7 +7,8 @@
 //                curve   : 4 cubic Bezier control points xyz + radius  (world space)
 //   shade      one 128-byte line per slot with everything a hit needs for shading: triangle corners,
 //              corner normals, canonical primitive id (gid), material id, light record, flags, TraceResult ids
-//   materials  one closure record per material (ParamToBsdf hoisted to commit time)
+//   materials  one closure record per material (ParamToBsdf hoisted to commit time unless textured)
+//   textures   float pixel pool + descriptor table (bilinear, clamp addressing)
 //   lights     per-light and per-light-primitive sampling tables (LightManager::Commit)
 #pragma once
 
@@ -40,13 +41,15 @@ constexpr uint32_t kSlotHasNormals = 1u;
 constexpr uint32_t kSlotIsCurve = 2u;
 constexpr uint32_t kSlotMatHair = 4u;   // material kind, denormalised here so a hit can be routed without
 constexpr uint32_t kSlotMatNone = 8u;   // touching the material table (shader.cc:11-17 for "none")
+constexpr uint32_t kSlotHasUV = 16u;
 
 struct alignas(128) ShadeRec {
   float v[9];   // triangle corners xyz (world); unused for curves (their control points live in `slots`)
   float n[9];   // corner shading normals xyz (kSlotHasNormals)
   uint32_t gid, material, lightrec, flags;
   uint32_t instance_id, geom_id, prim_id;
-  uint32_t pad[7];
+  float uv[6];  // corner texcoords (kSlotHasUV), mesh/triangle-mesh.cc:126-156
+  uint32_t pad[1];
 };
 static_assert(sizeof(ShadeRec) == 128, "one cache line per primitive");
 
@@ -80,13 +83,36 @@ PB_HD PrincipledBsdf default_bsdf() {
   return b;
 }
 
+struct PrincipledParam {  // == pbrhip_principled_param == CyclesPrincipledBsdfParameter (material-param.h:24-49)
+  float base_color[3];
+  float subsurface;
+  float subsurface_radius[3];
+  float subsurface_color[3];
+  float metallic, specular, specular_tint, roughness, anisotropic, anisotropic_rotation;
+  float sheen, sheen_tint, clearcoat, clearcoat_roughness, ior, transmission, transmission_roughness;
+  uint32_t base_color_tex_id, subsurface_color_tex_id;
+};
+struct HairParam {  // == pbrhip_hair_param == HairBsdfParameter (material-param.h:51-72)
+  uint32_t coloring_hair;
+  float base_color[3];
+  float melanin, melanin_redness, melanin_randomize;
+  float roughness, azimuthal_roughness, ior, shift;
+  float specular_tint[3], second_specular_tint[3], transmission_tint[3];
+};
+
 enum : uint32_t { kMatPrincipled = 0, kMatHair = 1 };
 
 struct alignas(16) Material {
   uint32_t kind;
-  uint32_t pad[3];
-  PrincipledBsdf bsdf;  // kMatPrincipled
+  uint32_t textured;    // kMatPrincipled with map_base_color / map_subsurface_color: ParamToBsdf runs per hit
+  uint32_t pad[2];
+  PrincipledBsdf bsdf;  // kMatPrincipled without textures: ParamToBsdf hoisted to commit time
   HairBsdf hair;        // kMatHair: everything except h (= hit v), hair-shader.cc:100-151
+  PrincipledParam param;  // raw parameters (used when textured)
+};
+
+struct TexDesc {  // pbrlab::Texture (src/texture.h:13-44): float pixels, row-major, interleaved channels
+  uint32_t offset, width, height, channels;
 };
 
 struct alignas(16) LightRec {  // one per (area light, primitive) ; light-manager.h:79-170
@@ -110,7 +136,9 @@ struct DScene {
   const LightHead* light_heads;
   const float* lprim_cdf;
   const LightRec* lrecs;
-  uint32_t num_nodes, num_slots, num_lights, num_materials, num_curves;
+  const float* tex_pixels;
+  const TexDesc* textures;
+  uint32_t num_nodes, num_slots, num_lights, num_materials, num_curves, num_textures;
 };
 
 // camera of RenderingTile (render.cc:132-158), derived on the host from the scene AABB

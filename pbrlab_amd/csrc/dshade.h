@@ -11,6 +11,7 @@ enum : int { kFront = 0, kBack = 1, kAmbiguous = 2 };
 // SurfaceInfo (shader/shader-utils.h:18-41), rebuilt from the 16-byte hit record
 struct Surface {
   V3 pos, n_s, n_g;
+  float tu, tv;  // Scene::FetchMeshTexcoord (scene.cc:230-249)
   int face;
   uint32_t material, lightrec, flags;
 };
@@ -25,6 +26,7 @@ __device__ __forceinline__ Surface make_surface(const DScene& sc, V3 org, V3 dir
   // words: v[0..8] n[9..17] gid(18) material(19) lightrec(20) flags(21) instance(22) geom(23) prim(24)
   s.material = __float_as_uint(r4.w), s.lightrec = __float_as_uint(r5.x), s.flags = __float_as_uint(r5.y);
   if (instance_id) *instance_id = __float_as_uint(r5.z);
+  s.tu = 0.f, s.tv = 0.f;  // curves: (0,0) (scene.cc:243-245)
   if (s.flags & kSlotIsCurve) {
     const float4* g = sc.slots + (size_t)h.slot * 4;
     float4 cp[4] = {g[0], g[1], g[2], g[3]};
@@ -39,11 +41,50 @@ __device__ __forceinline__ Surface make_surface(const DScene& sc, V3 org, V3 dir
     } else {
       s.n_s = vnormalize(cross(v1 - v0, v2 - v1));  // CalcGeometryNormal, triangle-mesh.cc:181-184
     }
+    if (s.flags & kSlotHasUV) {  // TriangleMesh::FetchTexcoord, triangle-mesh.cc:126-156 (only textured scenes pay)
+      float4 r6 = r[6], r7 = r[7];  // words 24..31: prim, uv[0..5], pad
+      float w0 = 1.0f - h.u - h.v;
+      s.tu = w0 * r6.y + h.u * r6.w + h.v * r7.y;
+      s.tv = w0 * r6.z + h.u * r7.x + h.v * r7.z;
+    } else {
+      s.tu = h.u, s.tv = h.v;
+    }
   }
   s.pos = org + h.t * dir;
   float dg = dot(dir, s.n_g), ds = dot(dir, s.n_s);
   s.face = (dg < 0.0f && ds < 0.0f) ? kFront : ((dg > 0.0f && ds > 0.0f) ? kBack : kAmbiguous);
   return s;
+}
+
+// Texture::FetchFloat3 (texture.cc:43-68) -> BilinearFilter with clamp addressing (image-utils.cc:99-167):
+// px = width * u (no half-texel offset); channels the image lacks read as 0
+__device__ __forceinline__ V3 texture_fetch3(const DScene& sc, uint32_t tex_id, float u, float v) {
+  const TexDesc t = sc.textures[tex_id];
+  float uu = smax(u, 0.0f);
+  uu = smin(uu, 1.0f);
+  float vv = smax(v, 0.0f);
+  vv = smin(vv, 1.0f);
+  const int width = (int)t.width, height = (int)t.height, stride = (int)t.channels;
+  const float px = (float)t.width * uu;
+  const float py = (float)t.height * vv;
+  int x0 = (int)px, y0 = (int)py;
+  x0 = x0 < width - 1 ? x0 : width - 1;
+  x0 = x0 > 0 ? x0 : 0;
+  y0 = y0 < height - 1 ? y0 : height - 1;
+  y0 = y0 > 0 ? y0 : 0;
+  const int x1 = ((x0 + 1) >= width) ? (width - 1) : (x0 + 1);
+  const int y1 = ((y0 + 1) >= height) ? (height - 1) : (y0 + 1);
+  const float dx = px - (float)x0;
+  const float dy = py - (float)y0;
+  const float w0 = (1.0f - dx) * (1.0f - dy), w1 = (1.0f - dx) * dy, w2 = dx * (1.0f - dy), w3 = dx * dy;
+  const float* p = sc.tex_pixels + t.offset;
+  const int i00 = stride * (y0 * width + x0), i01 = stride * (y0 * width + x1);
+  const int i10 = stride * (y1 * width + x0), i11 = stride * (y1 * width + x1);
+  float c[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+    c[i] = (i < stride) ? p[i00 + i] * w0 + p[i10 + i] * w1 + p[i01 + i] * w2 + p[i11 + i] * w3 : 0.f;
+  return V3(c[0], c[1], c[2]);
 }
 
 // std::lower_bound on a float CDF, clamped to the last entry (Q10)
@@ -166,23 +207,6 @@ PB_HD int pick_closure(float select, const SampleWeight& w) {
 }
 
 // ------------------------------------------------------------------ ParamToBsdf, hoisted to commit time
-struct PrincipledParam {  // == pbrhip_principled_param == CyclesPrincipledBsdfParameter (material-param.h:24-49)
-  float base_color[3];
-  float subsurface;
-  float subsurface_radius[3];
-  float subsurface_color[3];
-  float metallic, specular, specular_tint, roughness, anisotropic, anisotropic_rotation;
-  float sheen, sheen_tint, clearcoat, clearcoat_roughness, ior, transmission, transmission_roughness;
-  uint32_t base_color_tex_id, subsurface_color_tex_id;
-};
-struct HairParam {  // == pbrhip_hair_param == HairBsdfParameter (material-param.h:51-72)
-  uint32_t coloring_hair;
-  float base_color[3];
-  float melanin, melanin_redness, melanin_randomize;
-  float roughness, azimuthal_roughness, ior, shift;
-  float specular_tint[3], second_specular_tint[3], transmission_tint[3];
-};
-
 // random-walk-sss.h:35-104 (BssrdfSetup with burley radius, mfp scaling, eq. 5)
 PB_HD float burley_fitting5(float A) { return 1.85f - A + 7.0f * fabsf((A - 0.8f) * (A - 0.8f) * (A - 0.8f)); }
 PB_HD void bssrdf_setup(V3& weight, V3 albedo, V3& radius, V3& diffuse_weight) {
@@ -206,13 +230,11 @@ PB_HD void bssrdf_setup(V3& weight, V3 albedo, V3& radius, V3& diffuse_weight) {
     radius = l / s;
   }
 }
-// cycles-principled-shader.cc:244-412 without textures (row N4)
-PB_HD PrincipledBsdf param_to_bsdf(const PrincipledParam& m) {
+// cycles-principled-shader.cc:244-412; base_color / subsurface_color already resolved (parameter or texture, :281-301)
+PB_HD PrincipledBsdf param_to_bsdf(const PrincipledParam& m, V3 base_color, V3 subsurface_color) {
   const V3 weight(1.f);
-  V3 base_color(m.base_color[0], m.base_color[1], m.base_color[2]);
   float subsurface = m.subsurface;
   V3 subsurface_radius(m.subsurface_radius[0], m.subsurface_radius[1], m.subsurface_radius[2]);
-  V3 subsurface_color(m.subsurface_color[0], m.subsurface_color[1], m.subsurface_color[2]);
   const float cutoff = kEps;
   PrincipledBsdf b = default_bsdf();
   float diffuse_w = (1.0f - saturate(m.metallic)) * (1.0f - saturate(m.transmission));
@@ -258,6 +280,11 @@ PB_HD PrincipledBsdf param_to_bsdf(const PrincipledParam& m) {
     b.clearcoat_ior = 1.5f;
   }
   return b;
+}
+
+PB_HD PrincipledBsdf param_to_bsdf(const PrincipledParam& m) {
+  return param_to_bsdf(m, V3(m.base_color[0], m.base_color[1], m.base_color[2]),
+                       V3(m.subsurface_color[0], m.subsurface_color[1], m.subsurface_color[2]));
 }
 
 PB_HD float pow_n(float v, int n) {  // pbrlab_math.h:40-55

@@ -341,7 +341,15 @@ __global__ __launch_bounds__(kBlock) void k_shade_principled(PathState P, DScene
         fr.ez = (s.face == kFront) ? s.n_s : -s.n_s;
         branchless_onb(fr.ez, fr.ex, fr.ey);
         V3 wo = to_local(fr, wo_g);
-        const PrincipledBsdf& b = sc.materials[s.material].bsdf;
+        PrincipledBsdf b = sc.materials[s.material].bsdf;
+        if (sc.materials[s.material].textured) {  // ParamToBsdf per hit (cycles-principled-shader.cc:281-301)
+          const PrincipledParam mp = sc.materials[s.material].param;
+          V3 bc(mp.base_color[0], mp.base_color[1], mp.base_color[2]);
+          V3 ssc(mp.subsurface_color[0], mp.subsurface_color[1], mp.subsurface_color[2]);
+          if (mp.base_color_tex_id != kNone) bc = texture_fetch3(sc, mp.base_color_tex_id, s.tu, s.tv);
+          if (mp.subsurface_color_tex_id != kNone) ssc = texture_fetch3(sc, mp.subsurface_color_tex_id, s.tu, s.tv);
+          b = param_to_bsdf(mp, bc, ssc);
+        }
         SampleWeight w = closure_sample_weight(wo, b);
         // DirectIllumination (shader-utils.h:166-212)
         V3 d1(0.f);

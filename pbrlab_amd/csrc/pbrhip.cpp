@@ -102,6 +102,8 @@ struct pbrhip_scene {
   std::vector<HostInstance> instances;
   std::vector<HostMaterial> materials;
   std::vector<V3> light_params;
+  std::vector<TexDesc> tex_descs;      // Scene::AddTexture
+  std::vector<float> tex_pixels;
   std::vector<HostLight> lights;
   std::vector<float> light_cdf;
   bool committed = false, has_hair = false, has_sss = false;
@@ -112,7 +114,8 @@ struct pbrhip_scene {
   DevBuf<float4> d_slots;
   DevBuf<ShadeRec> d_shade;
   DevBuf<Material> d_materials;
-  DevBuf<float> d_light_cdf, d_lprim_cdf;
+  DevBuf<float> d_light_cdf, d_lprim_cdf, d_tex_pixels;
+  DevBuf<TexDesc> d_tex_descs;
   DevBuf<LightHead> d_heads;
   DevBuf<LightRec> d_lrecs;
   DScene dscene;
@@ -183,6 +186,10 @@ extern "C" int pbrhip_scene_add_triangle_mesh(pbrhip_scene* s, const float* vert
     for (size_t i = 0; i < (size_t)num_faces * 3; i++)
       if (normal_ids[i] != kNone && normal_ids[i] >= num_normals)
         return fail(PBRHIP_EINVAL, "normal id %u out of range", normal_ids[i]);
+  if (texcoord_ids)
+    for (size_t i = 0; i < (size_t)num_faces * 3; i++)
+      if (texcoord_ids[i] != kNone && texcoord_ids[i] >= num_texcoords)
+        return fail(PBRHIP_EINVAL, "texcoord id %u out of range", texcoord_ids[i]);
   HostMesh m;
   m.kind = 0;
   m.nfaces = num_faces;
@@ -221,9 +228,20 @@ extern "C" int pbrhip_scene_add_curve_mesh(pbrhip_scene* s, const float* vertice
   return PBRHIP_OK;
 }
 
-static int check_tex(const pbrhip_principled_param* p) {
-  if (p->base_color_tex_id != kNone || p->subsurface_color_tex_id != kNone)
-    return fail(PBRHIP_EUNSUPPORTED, "textured materials (map_base_color / map_subsurface_color) are not supported yet");
+// texture ids are validated at commit (pc/pc-common.cc:116-139 adds materials first, textures after)
+static int check_tex(const pbrhip_principled_param*) { return PBRHIP_OK; }
+// Scene::AddTexture (scene.h:46-51) with Texture(pixels, width, height, channels) (texture.cc:10-21)
+extern "C" int pbrhip_scene_add_texture(pbrhip_scene* s, const float* pixels, uint32_t width, uint32_t height,
+                                        uint32_t channels, uint32_t* texture_id) {
+  if (!s || !pixels || !texture_id) return fail(PBRHIP_EINVAL, "add_texture: NULL argument");
+  if (width == 0 || height == 0 || channels == 0 || channels > 4) return fail(PBRHIP_EINVAL, "add_texture: bad shape");
+  if (s->committed) return fail(PBRHIP_ESTATE, "scene already committed");
+  size_t n = (size_t)width * height * channels;
+  if (s->tex_pixels.size() + n >= (1ull << 32)) return fail(PBRHIP_EUNSUPPORTED, "texture pool exceeds 2^32 floats");
+  TexDesc t = {(uint32_t)s->tex_pixels.size(), width, height, channels};
+  s->tex_pixels.insert(s->tex_pixels.end(), pixels, pixels + n);
+  *texture_id = (uint32_t)s->tex_descs.size();
+  s->tex_descs.push_back(t);
   return PBRHIP_OK;
 }
 extern "C" int pbrhip_scene_add_principled_material(pbrhip_scene* s, const pbrhip_principled_param* p, uint32_t* id) {
@@ -385,8 +403,13 @@ static Material make_material(const HostMaterial& hm) {
   memset(&m, 0, sizeof(m));
   m.kind = hm.kind;
   m.bsdf = default_bsdf();
-  if (hm.kind == kMatPrincipled) m.bsdf = param_to_bsdf(hm.pr);
-  else m.hair = hair_param_to_bsdf(hm.hr);
+  if (hm.kind == kMatPrincipled) {
+    m.bsdf = param_to_bsdf(hm.pr);
+    m.param = hm.pr;
+    m.textured = (hm.pr.base_color_tex_id != kNone || hm.pr.subsurface_color_tex_id != kNone) ? 1u : 0u;
+  } else {
+    m.hair = hair_param_to_bsdf(hm.hr);
+  }
   return m;
 }
 
@@ -513,6 +536,15 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
         const HostAreaLight& al = in.area_lights[pr.geom_id];
         if (al.light_param_ids[pr.prim_id] != kNone) lightrec = heads[al.global_id].first + pr.prim_id;
       }
+      uint32_t ta = m.tid[pr.prim_id * 3 + 0], tb = m.tid[pr.prim_id * 3 + 1], tc = m.tid[pr.prim_id * 3 + 2];
+      if (ta != kNone && tb != kNone && tc != kNone) {  // triangle-mesh.cc:130-133
+        flags |= kSlotHasUV;
+        const uint32_t idx[3] = {ta, tb, tc};
+        for (int q = 0; q < 3; q++) {
+          sr.uv[2 * q + 0] = m.texcoords[(size_t)idx[q] * 2 + 0];
+          sr.uv[2 * q + 1] = m.texcoords[(size_t)idx[q] * 2 + 1];
+        }
+      }
     } else {
       flags |= kSlotIsCurve;
       for (int c = 0; c < 4; c++) {
@@ -526,7 +558,12 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
   std::vector<Material> mats(s->materials.size());
   s->has_hair = s->has_sss = false;
   for (size_t i = 0; i < mats.size(); i++) {
+    const HostMaterial& hm = s->materials[i];
+    if (hm.kind == kMatPrincipled)
+      for (uint32_t t : {hm.pr.base_color_tex_id, hm.pr.subsurface_color_tex_id})
+        if (t != kNone && t >= s->tex_descs.size()) return fail(PBRHIP_EINVAL, "material %zu: texture id %u out of range", i, t);
     mats[i] = make_material(s->materials[i]);
+    if (mats[i].textured) s->has_sss = true;  // a subsurface_color / base_color map can switch the SSS closure on per hit
     s->has_hair = s->has_hair || mats[i].kind == kMatHair;
     s->has_sss = s->has_sss || (mats[i].kind == kMatPrincipled && mats[i].bsdf.enable_subsurface);
   }
@@ -540,6 +577,8 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
   HIPCHK(s->d_heads.upload(heads, st));
   HIPCHK(s->d_lprim_cdf.upload(lprim_cdf, st));
   HIPCHK(s->d_lrecs.upload(lrecs, st));
+  HIPCHK(s->d_tex_pixels.upload(s->tex_pixels, st));
+  HIPCHK(s->d_tex_descs.upload(s->tex_descs, st));
   HIPCHK(hipStreamSynchronize(st));
   DScene& d = s->dscene;
   d.nodes = s->d_nodes.p, d.slots = s->d_slots.p, d.shade = s->d_shade.p;
@@ -547,6 +586,7 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
   d.light_heads = s->d_heads.p, d.lprim_cdf = s->d_lprim_cdf.p, d.lrecs = s->d_lrecs.p;
   d.num_nodes = (uint32_t)bvh.nodes.size(), d.num_slots = ns, d.num_lights = (uint32_t)s->lights.size();
   d.num_materials = (uint32_t)mats.size();
+  d.tex_pixels = s->d_tex_pixels.p, d.textures = s->d_tex_descs.p, d.num_textures = (uint32_t)s->tex_descs.size();
   d.num_curves = 0;
   for (uint8_t kd : kinds) d.num_curves += kd ? 1u : 0u;
   s->committed = true;
@@ -576,7 +616,10 @@ static int update_material(pbrhip_scene* s, uint32_t id, const HostMaterial& hm)
   if (s->committed) {
     HIPCHK(hipSetDevice(s->device));
     Material m = make_material(hm);
-    s->has_sss = s->has_sss || (m.kind == kMatPrincipled && m.bsdf.enable_subsurface);
+    s->has_sss = s->has_sss || (m.kind == kMatPrincipled && (m.bsdf.enable_subsurface || m.textured));
+    if (m.kind == kMatPrincipled)
+      for (uint32_t t : {hm.pr.base_color_tex_id, hm.pr.subsurface_color_tex_id})
+        if (t != kNone && t >= s->tex_descs.size()) return fail(PBRHIP_EINVAL, "texture id %u out of range", t);
     HIPCHK(hipMemcpyAsync(s->d_materials.p + id, &m, sizeof(m), hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
   }

@@ -70,6 +70,7 @@ class Shape:
     vertex_ids: np.ndarray            # (F,3) u32 into the shared attribute
     normal_ids: Optional[np.ndarray]  # (F,3) u32 or None
     material_ids: np.ndarray          # (F,) u32 (scene-global material ids)
+    texcoord_ids: Optional[np.ndarray] = None  # (F,3) u32 into SceneDesc.texcoords or None
 
 
 @dataclass
@@ -88,6 +89,8 @@ class SceneDesc:
     shapes: List[Shape]
     curves: List[CurveShape] = field(default_factory=list)
     light_emission: tuple = (3.0, 3.0, 3.0)   # pc/pc-common.cc:174
+    texcoords: Optional[np.ndarray] = None     # (T,2) uv, shared attribute (mesh/attribute.h:11)
+    textures: List[np.ndarray] = field(default_factory=list)  # (H,W,C) float32; material *_tex_id index this list
 
     def num_triangles(self):
         return int(sum(len(s.vertex_ids) for s in self.shapes))
@@ -398,20 +401,60 @@ def cornell_hair_scene(variant="sss", seed=1, n_strands=50000, n_segments=24, **
     return d
 
 
+def textured_cornell_scene(seed=1, **kw):
+    """S-cornell with the two texture slots pbrlab reads (`map_base_color`, `map_subsurface_color`,
+    cycles-principled-shader.cc:281-301): a checker/gradient base-colour map on the floor (with explicit
+    texcoords), a 1-channel map on the back wall (no texcoords: falls back to the barycentrics (u,v),
+    mesh/triangle-mesh.cc:130-133) and a subsurface-colour map on the Lucy stand-in."""
+    d = cornell_scene("sss", seed, **kw)
+    rng = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:32, 0:48]
+    checker = (((xx // 6) + (yy // 4)) % 2).astype(np.float32)
+    tex0 = np.stack([0.15 + 0.7 * checker, 0.2 + 0.6 * (xx / 47.0), 0.25 + 0.5 * (yy / 31.0)], -1).astype(np.float32)
+    tex1 = (0.2 + 0.6 * rng.rand(9, 7)).astype(np.float32)[..., None]              # 1 channel: g,b read as 0
+    tex2 = np.stack([0.9 * np.ones((16, 16)), 0.3 + 0.6 * rng.rand(16, 16), 0.3 + 0.6 * rng.rand(16, 16),
+                     np.ones((16, 16))], -1).astype(np.float32)                        # 4 channels: alpha ignored
+    d.textures = [tex0, tex1, tex2]
+    d.materials[0] = dict(d.materials[0], base_color_tex_id=0)                       # Floor
+    d.materials[7] = dict(d.materials[7], base_color_tex_id=1)                       # Wall_White (ceiling, back)
+    d.materials[3] = dict(d.materials[3], subsurface_color_tex_id=2)                 # Lucy
+    # explicit texcoords for the floor quad only (uv outside [0,1] exercises the clamp)
+    d.texcoords = np.array([[-0.1, -0.1], [1.1, -0.1], [1.1, 1.1], [-0.1, 1.1]], np.float32)
+    d.shapes[0].texcoord_ids = np.array([[0, 1, 2], [0, 2, 3]], np.uint32)
+    # Lucy: planar-ish texcoords from the vertex positions
+    lucy = next(s for s in d.shapes if s.name == "lucy")
+    base = len(d.texcoords)
+    vids = np.unique(lucy.vertex_ids)
+    remap = np.zeros(int(vids.max()) + 1, np.uint32)
+    remap[vids] = np.arange(len(vids), dtype=np.uint32) + base
+    uv = d.vertices[vids][:, [0, 1]] * np.float32(0.9) + np.float32(0.45)
+    d.texcoords = np.concatenate([d.texcoords, uv.astype(np.float32)])
+    lucy.texcoord_ids = remap[lucy.vertex_ids]
+    return d
+
+
 # --------------------------------------------------------------------------------------------------
 def build_scene(scene, desc: SceneDesc, make_principled, make_hair):
     """Replay `desc` through a Scene-like object exposing pbrlab's builder names (src/scene.h:19-91),
     in the order pc/pc-common.cc:100-237 uses.  `make_principled(dict)` / `make_hair(dict)` build the
     back end's POD material parameter.  Returns the list of instance ids."""
     mat_ids = []
+    tex_ids = [scene.AddTexture(t) for t in desc.textures]   # Scene::AddTexture; ids remapped like FixTextureId
     for m in desc.materials:
-        p = make_principled(m) if m.get("kind", "principled") == "principled" else make_hair(m)
+        if m.get("kind", "principled") == "principled":
+            m = dict(m)
+            for k in ("base_color_tex_id", "subsurface_color_tex_id"):
+                if m[k] != 0xFFFFFFFF:
+                    m[k] = tex_ids[m[k]]
+            p = make_principled(m)
+        else:
+            p = make_hair(m)
         mat_ids.append(scene.AddMaterialParam(p))
     mat_ids = np.asarray(mat_ids, np.uint32)
     instances = []
     for sh in desc.shapes:
-        mesh = scene.AddTriangleMesh(desc.vertices, desc.normals, None, sh.vertex_ids, sh.normal_ids, None,
-                                     mat_ids[sh.material_ids])
+        mesh = scene.AddTriangleMesh(desc.vertices, desc.normals, desc.texcoords, sh.vertex_ids, sh.normal_ids,
+                                     sh.texcoord_ids, mat_ids[sh.material_ids])
         ls = scene.CreateLocalScene()
         scene.AddMeshToLocalScene(ls, mesh)
         inst = scene.CreateInstance(ls, None)

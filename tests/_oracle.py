@@ -73,6 +73,8 @@ def lib():
         L.orc_add_principled.argtypes = [C.c_void_p, C.POINTER(PrincipledParam)]
         L.orc_add_hair.argtypes = [C.c_void_p, C.POINTER(HairParam)]
         L.orc_add_area_light.argtypes = [C.c_void_p, fp]
+        L.orc_add_texture.argtypes = [C.c_void_p, fp, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.orc_kat_texture_fetch.argtypes = [fp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_float, fp]
         L.orc_create_local_scene.argtypes = [C.c_void_p]
         L.orc_add_mesh_to_local_scene.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
         L.orc_create_instance.argtypes = [C.c_void_p, C.c_uint32, fp]
@@ -146,6 +148,11 @@ def ref():
         R.ref_to_cubic_bezier.argtypes = [fp, fp, C.c_uint32, fp]
         R.ref_triangle_fetch.argtypes = [fp, C.c_uint32, fp, C.c_uint32, u32p, u32p, C.c_uint32, C.c_uint32,
                                          C.c_float, C.c_float, C.c_int, fp]
+        R.ref_texture_fetch.argtypes = [fp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_float, fp]
+        R.ref_linear_to_srgb.argtypes = [C.c_float]
+        R.ref_linear_to_srgb.restype = C.c_float
+        R.ref_srgb_to_linear.argtypes = [C.c_float]
+        R.ref_srgb_to_linear.restype = C.c_float
         R.ref_spectrum_norm.argtypes = [fp]
         R.ref_spectrum_norm.restype = C.c_float
         R.ref_rgb_to_y.argtypes = [fp]
@@ -196,6 +203,12 @@ class OracleScene:
         if isinstance(p, PrincipledParam):
             return self.L.orc_add_principled(self.h, C.byref(p))
         return self.L.orc_add_hair(self.h, C.byref(p))
+
+    def AddTexture(self, pixels):
+        px = np.ascontiguousarray(pixels, np.float32)
+        if px.ndim == 2:
+            px = px[..., None]
+        return self.L.orc_add_texture(self.h, _ptr(px), px.shape[1], px.shape[0], px.shape[2])
 
     def AddLightParam(self, emission):
         e = f32(*emission)

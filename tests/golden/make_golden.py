@@ -33,6 +33,7 @@ def golden_scenes():
         "ggx": scenes.cornell_scene("ggx", monkey_subdiv=2, lucy_nu=64, lucy_nv=12),
         "sss": scenes.cornell_scene("sss", monkey_subdiv=2, lucy_nu=64, lucy_nv=12),
         "hair": scenes.hair_scene(n_strands=500, n_segments=6, head_subdiv=2),
+        "textured": scenes.textured_cornell_scene(monkey_subdiv=2, lucy_nu=64, lucy_nv=12),
     }
 
 
@@ -44,6 +45,10 @@ def scene_digest(desc):
         h.update(np.ascontiguousarray(s.vertex_ids).tobytes())
     for c in desc.curves:
         h.update(np.ascontiguousarray(c.vertices).tobytes())
+    for t in desc.textures:
+        h.update(np.ascontiguousarray(t).tobytes())
+    if desc.texcoords is not None:
+        h.update(np.ascontiguousarray(desc.texcoords).tobytes())
     return h.hexdigest()
 
 
@@ -126,6 +131,18 @@ def make_ref_leaf():
     bez = np.zeros(8 * 16, np.float32)
     R.ref_to_cubic_bezier(P(cvs), P(rad), 9, P(bez))
     out.update(bezier_cvs=cvs, bezier_radii=rad, bezier_out=bez.reshape(-1, 4))
+    # Texture::FetchFloat3 (bilinear, clamp) on images with 1..4 channels, uv partly outside [0,1]
+    for c in (1, 2, 3, 4):
+        px = np.ascontiguousarray(rng.rand(5, 7, c).astype(np.float32))
+        uvs = np.float32(np.concatenate([rng.uniform(-0.2, 1.2, (60, 2)), [[0, 0], [1, 1], [0.999999, 0.5], [1, 0]]]))
+        res = np.zeros((len(uvs), 3), np.float32)
+        for i, (u, v) in enumerate(uvs):
+            R.ref_texture_fetch(P(px), 7, 5, c, u, v, P(res[i]))
+        out[f"tex{c}_pixels"], out[f"tex{c}_uv"], out[f"tex{c}_rgb"] = px, uvs, res
+    xs = np.float32(np.concatenate([np.linspace(0, 1.5, 200), [0.0031308, 0.04045, 1.0]]))
+    out["srgb_x"] = xs
+    out["srgb_oetf"] = np.float32([R.ref_linear_to_srgb(float(x)) for x in xs])
+    out["srgb_eotf"] = np.float32([R.ref_srgb_to_linear(float(x)) for x in xs])
     np.savez_compressed(os.path.join(HERE, "ref_leaf_kats.npz"), **out)
 
 

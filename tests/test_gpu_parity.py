@@ -52,7 +52,7 @@ def image_check(gpu_rgba, ref_rgba, exact_fraction=MAX_DIVERGENT):
     return int(d.sum()), rel
 
 
-@pytest.mark.parametrize("name", ["lambert", "ggx", "sss", "hair"])
+@pytest.mark.parametrize("name", ["lambert", "ggx", "sss", "hair", "textured"])
 def test_trace_hooks_bit_exact(pa, pairs, name):
     from pbrlab_amd import scenes
     desc, sg, so = pairs[name]
@@ -88,7 +88,7 @@ def test_trace_edge_cases(pa, pairs):
     assert_hits_equal(sg.trace_closest(z), so.trace_closest(z))
 
 
-@pytest.mark.parametrize("name", ["lambert", "ggx", "sss", "hair"])
+@pytest.mark.parametrize("name", ["lambert", "ggx", "sss", "hair", "textured"])
 def test_render_matches_oracle_and_fixture(pa, pairs, name):
     desc, sg, so = pairs[name]
     layer = pa.RenderLayer()
@@ -176,6 +176,19 @@ def test_material_update_and_errors(pa, pairs):
     lay = pa.RenderLayer()
     pa.Render(s3, 8, 8, 2, layer=lay)
     assert not lay.rgba[..., :3].any() and (lay.count == 2).all()
+
+
+def test_texture_errors(pa):
+    from pbrlab_amd import scenes
+    s = pa.Scene()
+    s.AddTexture(np.ones((2, 2, 3), np.float32))
+    s.AddMaterialParam(pa.make_principled(dict(scenes.PRINCIPLED_DEFAULTS, base_color_tex_id=7)))   # no such texture
+    with pytest.raises(pa.PbrHipError) as e:
+        s.CommitScene()                                             # ids are checked at commit
+    assert e.value.code == -1
+    s = pa.Scene()
+    with pytest.raises(pa.PbrHipError):
+        s.AddTexture(np.zeros((4, 4, 5), np.float32))               # more than 4 channels
 
 
 def test_cancel_and_finish_pass(pa, pairs):

@@ -95,7 +95,19 @@ def test_reference_misc_vectors(kat):
     assert eq(out.reshape(-1, 4), kat["bezier_out"])
 
 
-@pytest.mark.parametrize("name", ["lambert", "ggx", "sss", "hair"])
+def test_reference_texture_vectors(kat):
+    L = O.lib()
+    for c in (1, 2, 3, 4):
+        px = np.ascontiguousarray(kat[f"tex{c}_pixels"])
+        got = np.zeros_like(kat[f"tex{c}_rgb"])
+        for i, (u, v) in enumerate(kat[f"tex{c}_uv"]):
+            L.orc_kat_texture_fetch(P(px), 7, 5, c, u, v, P(got[i]))
+        assert eq(got, kat[f"tex{c}_rgb"]), c
+        if c < 3:
+            assert not got[:, c:].any()      # channels the image lacks read as 0 (texture.cc:52-58)
+
+
+@pytest.mark.parametrize("name", ["lambert", "ggx", "sss", "hair", "textured"])
 def test_oracle_images_reproduce(img, name):
     desc = golden_scenes()[name]
     assert bytes(img[f"{name}_digest"]).hex() == scene_digest(desc), "scene generator drifted"
@@ -121,7 +133,7 @@ def test_libm_vs_f64r_tolerance(img):
     """The reference calls libm's float functions; the GPU (and oracle mode f64r) use the double result
     rounded once.  The two differ in the last ulp of a few calls; on these images the effect must stay
     far below the 1e-4 relative-L2 bar of BASELINE.json, and the divergent-pixel count is reported."""
-    for name in ("lambert", "ggx", "sss", "hair"):
+    for name in ("lambert", "ggx", "sss", "hair", "textured"):
         a, b = img[f"{name}_libm_rgba"][..., :3], img[f"{name}_f64r_rgba"][..., :3]
         rel = np.linalg.norm(a - b) / np.linalg.norm(a)
         px_rel = np.abs(a - b).max(axis=2) / np.maximum(np.abs(a).max(axis=2), 1e-12)

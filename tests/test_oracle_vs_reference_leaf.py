@@ -232,3 +232,17 @@ def test_mult_v_bit_exact():
     want = [np.float32(np.float32(np.float32(rows[0 + k] * v[0]) + np.float32(rows[3 + k] * v[1])) + np.float32(
         rows[6 + k] * v[2])) + np.float32(0) for k in range(3)]
     assert same_bits(out, want)
+
+
+@needs_ref
+def test_texture_fetch_bit_exact():
+    """Texture::FetchFloat3 -> BilinearFilter (texture.cc:43-68, image-utils.cc:99-167), reference compiled unmodified"""
+    L, R = O.lib(), O.ref()
+    rng = np.random.RandomState(8)
+    for (w, h, c) in [(4, 4, 3), (7, 3, 4), (1, 1, 3), (16, 9, 1), (5, 5, 2)]:
+        px = np.ascontiguousarray(rng.rand(h, w, c).astype(np.float32))
+        uvs = np.float32(np.concatenate([rng.uniform(-0.3, 1.3, (400, 2)), [[0, 0], [1, 1], [0.999999, 0.5], [1, 0], [0.5, 1]]]))
+        for u, v in uvs:
+            a, b = np.zeros(3, np.float32), np.zeros(3, np.float32)
+            L.orc_kat_texture_fetch(P(px), w, h, c, u, v, P(a)), R.ref_texture_fetch(P(px), w, h, c, u, v, P(b))
+            assert same_bits(a, b), (w, h, c, u, v, a, b)
