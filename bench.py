@@ -43,6 +43,18 @@ NODE_B, TRI_B, CURVE_B, RAY_B, SHADOW_RAY_B = 64, 48, 64, 52, 68
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
+def pmc_traffic(workload, spp, world):
+    """HBM bytes per k_trace launch from the committed PMC passes (profiles/README.md: FETCH_SIZE and WRITE_SIZE in
+    separate --pmc runs of the same render, (2*FETCH_SIZE + WRITE_SIZE) * 1024 with the gfx950 FETCH_SIZE x2
+    correction of MI355X_MICROARCH.md, calibrated on k_accumulate's known 2.12 GB stream).  Counters cannot be read
+    live, so this is only reported for the exact configuration they were collected on; otherwise null."""
+    path = os.path.join(ROOT, "profiles", "r1_c2_hbm_traffic_pmc.json")
+    if workload != "c2" or spp != WORKLOADS["c2"]["spp"] or world != 1 or not os.path.exists(path):
+        return None
+    rec = json.load(open(path)).get("pb::k_trace<false, false>")
+    return rec["hbm_bytes_per_dispatch_fetch_x2"] if rec else None
+
+
 def make_desc(w):
     from pbrlab_amd import scenes
     if w["scene"] == "cornell":
@@ -176,7 +188,8 @@ def main():
         if ms_step > 0:
             achieved = bytes_step / (ms_step * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": "k_trace (closest-hit rays of bounce k + shadow rays of bounce k-1)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "traffic": None if args.max_paths else pmc_traffic(args.workload, spp, world),
                         "algorithmic_bytes_per_launch": bytes_step / max(launches, 1),
                         "avg_launch_ms": ms_step / max(launches, 1), "launches_per_step": launches,
                         "rays_per_step": sst["closest_rays"] + sst["shadow_rays"],
