@@ -1,0 +1,762 @@
+// image_codec.cpp -- see image_codec.h
+#include "image_codec.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+
+namespace pbio {
+namespace {
+
+// ---------------------------------------------------------------- checksums
+uint32_t crc32_update(uint32_t crc, const uint8_t* p, size_t n) {
+  static uint32_t table[256];
+  static bool ready = false;
+  if (!ready) {
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+      table[i] = c;
+    }
+    ready = true;
+  }
+  crc = ~crc;
+  for (size_t i = 0; i < n; ++i) crc = table[(crc ^ p[i]) & 0xFF] ^ (crc >> 8);
+  return ~crc;
+}
+
+uint32_t adler32(const uint8_t* p, size_t n) {
+  uint32_t a = 1, b = 0;
+  while (n) {
+    const size_t k = n < 5552 ? n : 5552;
+    for (size_t i = 0; i < k; ++i) a += p[i], b += a;
+    a %= 65521u, b %= 65521u;
+    p += k, n -= k;
+  }
+  return (b << 16) | a;
+}
+
+// ---------------------------------------------------------------- inflate (RFC 1951)
+const uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+const uint8_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+const uint16_t kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+const uint8_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+
+struct BitReader {
+  const uint8_t* p;
+  size_t n, pos = 0;
+  uint32_t acc = 0;
+  int nbits = 0;
+  bool overrun = false;
+  BitReader(const uint8_t* s, size_t len) : p(s), n(len) {}
+  uint32_t bits(int k) {
+    while (nbits < k) {
+      uint32_t byte = 0;
+      if (pos < n) byte = p[pos++]; else overrun = true;
+      acc |= byte << nbits;
+      nbits += 8;
+    }
+    const uint32_t v = acc & ((k == 32) ? 0xFFFFFFFFu : ((1u << k) - 1u));
+    acc >>= k, nbits -= k;
+    return v;
+  }
+  void align() { acc = 0, nbits = 0; }
+};
+
+// canonical Huffman decoding table: count per length + symbols sorted by (length, value)
+struct Huffman {
+  uint16_t count[16];
+  uint16_t symbol[288];
+  bool build(const uint8_t* lengths, int n) {
+    std::fill(count, count + 16, 0);
+    for (int i = 0; i < n; ++i) count[lengths[i]]++;
+    count[0] = 0;
+    int left = 1;
+    for (int len = 1; len < 16; ++len) {
+      left <<= 1;
+      left -= count[len];
+      if (left < 0) return false;  // over-subscribed
+    }
+    uint16_t offs[16];
+    offs[1] = 0;
+    for (int len = 1; len < 15; ++len) offs[len + 1] = uint16_t(offs[len] + count[len]);
+    for (int i = 0; i < n; ++i)
+      if (lengths[i]) symbol[offs[lengths[i]]++] = uint16_t(i);
+    return true;
+  }
+  int decode(BitReader* br) const {
+    int code = 0, first = 0, index = 0;
+    for (int len = 1; len < 16; ++len) {
+      code |= int(br->bits(1));
+      const int c = count[len];
+      if (code - c < first) return symbol[index + (code - first)];
+      index += c, first += c;
+      first <<= 1, code <<= 1;
+      if (br->overrun) return -1;
+    }
+    return -1;
+  }
+};
+
+bool inflate_codes(BitReader* br, const Huffman& lit, const Huffman& dist, std::vector<uint8_t>* out, std::string* err) {
+  for (;;) {
+    const int sym = lit.decode(br);
+    if (sym < 0) return *err = "bad huffman code", false;
+    if (sym < 256) {
+      out->push_back(uint8_t(sym));
+    } else if (sym == 256) {
+      return true;
+    } else {
+      if (sym > 285) return *err = "bad length code", false;
+      const size_t len = kLenBase[sym - 257] + br->bits(kLenExtra[sym - 257]);
+      const int ds = dist.decode(br);
+      if (ds < 0 || ds > 29) return *err = "bad distance code", false;
+      const size_t d = kDistBase[ds] + br->bits(kDistExtra[ds]);
+      if (d > out->size()) return *err = "distance too far back", false;
+      const size_t from = out->size() - d;
+      for (size_t i = 0; i < len; ++i) out->push_back((*out)[from + i]);
+    }
+    if (br->overrun) return *err = "truncated stream", false;
+  }
+}
+
+bool inflate_raw(BitReader* br, std::vector<uint8_t>* out, std::string* err) {
+  for (;;) {
+    const uint32_t final_block = br->bits(1), type = br->bits(2);
+    if (type == 0) {
+      br->align();
+      if (br->pos + 4 > br->n) return *err = "truncated stored block", false;
+      const uint32_t len = br->p[br->pos] | (br->p[br->pos + 1] << 8), nlen = br->p[br->pos + 2] | (br->p[br->pos + 3] << 8);
+      br->pos += 4;
+      if ((len ^ 0xFFFFu) != nlen) return *err = "stored block length mismatch", false;
+      if (br->pos + len > br->n) return *err = "truncated stored block", false;
+      out->insert(out->end(), br->p + br->pos, br->p + br->pos + len);
+      br->pos += len;
+    } else if (type == 1) {
+      uint8_t l[288];
+      for (int i = 0; i < 144; ++i) l[i] = 8;
+      for (int i = 144; i < 256; ++i) l[i] = 9;
+      for (int i = 256; i < 280; ++i) l[i] = 7;
+      for (int i = 280; i < 288; ++i) l[i] = 8;
+      uint8_t d[30];
+      std::fill(d, d + 30, 5);
+      Huffman lit, dist;
+      lit.build(l, 288), dist.build(d, 30);
+      if (!inflate_codes(br, lit, dist, out, err)) return false;
+    } else if (type == 2) {
+      const int nlen = int(br->bits(5)) + 257, ndist = int(br->bits(5)) + 1, ncode = int(br->bits(4)) + 4;
+      if (nlen > 286 || ndist > 30) return *err = "bad code counts", false;
+      static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+      uint8_t lengths[320];
+      std::fill(lengths, lengths + 320, 0);
+      for (int i = 0; i < ncode; ++i) lengths[order[i]] = uint8_t(br->bits(3));
+      Huffman cl;
+      if (!cl.build(lengths, 19)) return *err = "bad code-length code", false;
+      uint8_t ll[320];
+      int i = 0;
+      while (i < nlen + ndist) {
+        const int sym = cl.decode(br);
+        if (sym < 0) return *err = "bad code-length symbol", false;
+        if (sym < 16) {
+          ll[i++] = uint8_t(sym);
+        } else {
+          uint8_t prev = 0;
+          int rep;
+          if (sym == 16) {
+            if (i == 0) return *err = "repeat without a previous length", false;
+            prev = ll[i - 1];
+            rep = 3 + int(br->bits(2));
+          } else if (sym == 17) {
+            rep = 3 + int(br->bits(3));
+          } else {
+            rep = 11 + int(br->bits(7));
+          }
+          if (i + rep > nlen + ndist) return *err = "too many code lengths", false;
+          while (rep--) ll[i++] = prev;
+        }
+      }
+      if (ll[256] == 0) return *err = "no end-of-block code", false;
+      Huffman lit, dist;
+      if (!lit.build(ll, nlen)) return *err = "bad literal/length code", false;
+      dist.build(ll + nlen, ndist);  // an incomplete distance code is legal
+      if (!inflate_codes(br, lit, dist, out, err)) return false;
+    } else {
+      return *err = "reserved block type", false;
+    }
+    if (br->overrun) return *err = "truncated stream", false;
+    if (final_block) return true;
+  }
+}
+
+// ---------------------------------------------------------------- deflate: LZ77 (hash chains) + fixed Huffman codes
+struct BitWriter {
+  std::vector<uint8_t>* out;
+  uint32_t acc = 0;
+  int nbits = 0;
+  void put(uint32_t v, int k) {  // LSB first
+    acc |= v << nbits;
+    nbits += k;
+    while (nbits >= 8) out->push_back(uint8_t(acc)), acc >>= 8, nbits -= 8;
+  }
+  void put_code(uint32_t code, int k) {  // Huffman codes go MSB first
+    uint32_t r = 0;
+    for (int i = 0; i < k; ++i) r |= ((code >> i) & 1u) << (k - 1 - i);
+    put(r, k);
+  }
+  void flush() {
+    if (nbits) out->push_back(uint8_t(acc)), acc = 0, nbits = 0;
+  }
+};
+
+void put_literal(BitWriter* bw, int sym) {  // fixed code of RFC 1951 §3.2.6
+  if (sym < 144) bw->put_code(0x30 + sym, 8);
+  else if (sym < 256) bw->put_code(0x190 + (sym - 144), 9);
+  else if (sym < 280) bw->put_code(sym - 256, 7);
+  else bw->put_code(0xC0 + (sym - 280), 8);
+}
+
+}  // namespace
+
+bool ZlibInflate(const uint8_t* src, size_t n, std::vector<uint8_t>* out, std::string* err) {
+  out->clear();
+  if (n < 6) return *err = "zlib stream too short", false;
+  if ((src[0] & 0x0F) != 8 || ((src[0] << 8) | src[1]) % 31 != 0) return *err = "bad zlib header", false;
+  if (src[1] & 0x20) return *err = "preset dictionary not supported", false;
+  BitReader br(src + 2, n - 2);
+  return inflate_raw(&br, out, err);  // (like stb_image, the Adler-32 trailer is not verified)
+}
+
+void ZlibDeflate(const uint8_t* src, size_t n, std::vector<uint8_t>* out) {
+  out->clear();
+  out->push_back(0x78), out->push_back(0x5E);
+  BitWriter bw{out};
+  bw.put(1, 1), bw.put(1, 2);  // one final block, fixed codes
+  const int kHashBits = 15, kChain = 32;
+  std::vector<int32_t> head(size_t(1) << kHashBits, -1), prev(n ? n : 1, -1);
+  auto hash = [&](size_t i) { return ((uint32_t(src[i]) << 10) ^ (uint32_t(src[i + 1]) << 5) ^ src[i + 2]) & ((1u << kHashBits) - 1u); };
+  size_t i = 0;
+  while (i < n) {
+    size_t best_len = 0, best_dist = 0;
+    if (i + 2 < n) {
+      const uint32_t h = hash(i);
+      int32_t cand = head[h];
+      int chain = kChain;
+      const size_t maxlen = std::min<size_t>(258, n - i);
+      while (cand >= 0 && chain-- && i - size_t(cand) <= 32768) {
+        size_t l = 0;
+        while (l < maxlen && src[size_t(cand) + l] == src[i + l]) ++l;
+        if (l > best_len) best_len = l, best_dist = i - size_t(cand);
+        if (l == maxlen) break;
+        cand = prev[size_t(cand)];
+      }
+    }
+    const size_t step = best_len >= 3 ? best_len : 1;
+    if (best_len >= 3) {
+      int ls = 28;
+      while (kLenBase[ls] > best_len) --ls;
+      put_literal(&bw, 257 + ls);
+      bw.put(uint32_t(best_len - kLenBase[ls]), kLenExtra[ls]);
+      int ds = 29;
+      while (kDistBase[ds] > best_dist) --ds;
+      bw.put_code(uint32_t(ds), 5);
+      bw.put(uint32_t(best_dist - kDistBase[ds]), kDistExtra[ds]);
+    } else {
+      put_literal(&bw, src[i]);
+    }
+    for (size_t k = 0; k < step; ++k, ++i) {
+      if (i + 2 < n) {
+        const uint32_t h = hash(i);
+        prev[i] = head[h];
+        head[h] = int32_t(i);
+      }
+    }
+  }
+  put_literal(&bw, 256);
+  bw.flush();
+  const uint32_t ad = adler32(src, n);
+  out->push_back(uint8_t(ad >> 24)), out->push_back(uint8_t(ad >> 16)), out->push_back(uint8_t(ad >> 8)), out->push_back(uint8_t(ad));
+}
+
+// ---------------------------------------------------------------- PNG
+namespace {
+const uint8_t kPngSig[8] = {137, 80, 78, 71, 13, 10, 26, 10};
+
+void put_chunk(std::vector<uint8_t>* f, const char* type, const uint8_t* data, size_t n) {
+  const uint32_t len = uint32_t(n);
+  f->push_back(uint8_t(len >> 24)), f->push_back(uint8_t(len >> 16)), f->push_back(uint8_t(len >> 8)), f->push_back(uint8_t(len));
+  const size_t start = f->size();
+  f->insert(f->end(), type, type + 4);
+  if (n) f->insert(f->end(), data, data + n);
+  const uint32_t crc = crc32_update(0, f->data() + start, n + 4);
+  f->push_back(uint8_t(crc >> 24)), f->push_back(uint8_t(crc >> 16)), f->push_back(uint8_t(crc >> 8)), f->push_back(uint8_t(crc));
+}
+
+inline int paeth(int a, int b, int c) {
+  const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+  if (pa <= pb && pa <= pc) return a;
+  if (pb <= pc) return b;
+  return c;
+}
+
+uint32_t be32(const uint8_t* p) { return (uint32_t(p[0]) << 24) | (uint32_t(p[1]) << 16) | (uint32_t(p[2]) << 8) | p[3]; }
+
+// undo the row filters of one (sub-)image in place; returns false on a bad filter byte
+bool unfilter(uint8_t* data, size_t rows, size_t row_bytes, size_t bpp) {
+  const size_t stride = row_bytes + 1;
+  for (size_t y = 0; y < rows; ++y) {
+    uint8_t* cur = data + y * stride + 1;
+    const uint8_t* up = y ? data + (y - 1) * stride + 1 : nullptr;
+    const int f = data[y * stride];
+    if (f > 4) return false;
+    for (size_t x = 0; x < row_bytes; ++x) {
+      const int a = x >= bpp ? cur[x - bpp] : 0, b = up ? up[x] : 0, c = (up && x >= bpp) ? up[x - bpp] : 0;
+      int add = 0;
+      switch (f) {
+        case 1: add = a; break;
+        case 2: add = b; break;
+        case 3: add = (a + b) >> 1; break;
+        case 4: add = paeth(a, b, c); break;
+      }
+      cur[x] = uint8_t(cur[x] + add);
+    }
+  }
+  return true;
+}
+}  // namespace
+
+bool EncodePng(const uint8_t* px, size_t w, size_t h, size_t ch, std::vector<uint8_t>* file) {
+  if (ch < 1 || ch > 4 || w == 0 || h == 0) return false;
+  static const uint8_t ctype[5] = {0, 0, 4, 2, 6};
+  const size_t rb = w * ch;
+  std::vector<uint8_t> raw((rb + 1) * h), cand(rb);
+  for (size_t y = 0; y < h; ++y) {  // per row: the filter with the smallest sum of |residual|
+    const uint8_t* cur = px + y * rb;
+    const uint8_t* up = y ? px + (y - 1) * rb : nullptr;
+    long best = -1;
+    for (int f = 0; f < 5; ++f) {
+      long sum = 0;
+      for (size_t x = 0; x < rb; ++x) {
+        const int a = x >= ch ? cur[x - ch] : 0, b = up ? up[x] : 0, c = (up && x >= ch) ? up[x - ch] : 0;
+        int pred = 0;
+        switch (f) {
+          case 1: pred = a; break;
+          case 2: pred = b; break;
+          case 3: pred = (a + b) >> 1; break;
+          case 4: pred = paeth(a, b, c); break;
+        }
+        cand[x] = uint8_t(cur[x] - pred);
+        sum += std::abs(int(int8_t(cand[x])));
+      }
+      if (best < 0 || sum < best) {
+        best = sum;
+        raw[y * (rb + 1)] = uint8_t(f);
+        std::copy(cand.begin(), cand.end(), raw.begin() + long(y * (rb + 1) + 1));
+      }
+    }
+  }
+  std::vector<uint8_t> z;
+  ZlibDeflate(raw.data(), raw.size(), &z);
+  file->assign(kPngSig, kPngSig + 8);
+  uint8_t ihdr[13] = {uint8_t(w >> 24), uint8_t(w >> 16), uint8_t(w >> 8), uint8_t(w), uint8_t(h >> 24), uint8_t(h >> 16),
+                      uint8_t(h >> 8),  uint8_t(h),       8,               ctype[ch],  0,               0,
+                      0};
+  put_chunk(file, "IHDR", ihdr, 13);
+  put_chunk(file, "IDAT", z.data(), z.size());
+  put_chunk(file, "IEND", nullptr, 0);
+  return true;
+}
+
+bool DecodePng(const uint8_t* file, size_t n, std::vector<uint8_t>* pixels, size_t* width, size_t* height,
+               size_t* channels, std::string* err) {
+  if (n < 8 || memcmp(file, kPngSig, 8) != 0) return *err = "not a PNG file", false;
+  size_t pos = 8;
+  uint32_t w = 0, h = 0;
+  int depth = 0, color = 0, interlace = 0;
+  bool have_ihdr = false, have_trns = false;
+  uint8_t palette[256 * 4];
+  size_t pal_len = 0;
+  uint16_t key[3] = {0, 0, 0};
+  std::vector<uint8_t> idat;
+  for (;;) {
+    if (pos + 8 > n) return *err = "truncated PNG", false;
+    const uint32_t len = be32(file + pos);
+    const uint8_t* type = file + pos + 4;
+    const uint8_t* data = file + pos + 8;
+    if (pos + 12 + size_t(len) > n) return *err = "truncated PNG chunk", false;
+    if (!have_ihdr && memcmp(type, "IHDR", 4) != 0) return *err = "first chunk is not IHDR", false;
+    if (memcmp(type, "IHDR", 4) == 0) {
+      if (len != 13) return *err = "bad IHDR", false;
+      w = be32(data), h = be32(data + 4);
+      depth = data[8], color = data[9], interlace = data[12];
+      if (w == 0 || h == 0 || w > (1u << 24) || h > (1u << 24)) return *err = "bad PNG size", false;
+      if (depth != 1 && depth != 2 && depth != 4 && depth != 8 && depth != 16) return *err = "bad PNG bit depth", false;
+      if (color > 6 || color == 1 || color == 5) return *err = "bad PNG colour type", false;
+      if (color == 3 && depth == 16) return *err = "bad PNG colour type", false;
+      if ((color == 2 || color == 4 || color == 6) && depth < 8) return *err = "bad PNG colour type", false;
+      if (data[10] || data[11] || interlace > 1) return *err = "bad PNG compression/filter/interlace method", false;
+      have_ihdr = true;
+    } else if (memcmp(type, "PLTE", 4) == 0) {
+      if (len > 256 * 3 || len % 3) return *err = "bad PLTE", false;
+      pal_len = len / 3;
+      for (size_t i = 0; i < pal_len; ++i) {
+        palette[i * 4 + 0] = data[i * 3 + 0], palette[i * 4 + 1] = data[i * 3 + 1], palette[i * 4 + 2] = data[i * 3 + 2];
+        palette[i * 4 + 3] = 255;
+      }
+    } else if (memcmp(type, "tRNS", 4) == 0) {
+      if (!idat.empty()) return *err = "tRNS after IDAT", false;
+      if (color == 3) {
+        if (pal_len == 0 || len > pal_len) return *err = "bad tRNS", false;
+        for (size_t i = 0; i < len; ++i) palette[i * 4 + 3] = data[i];
+      } else {
+        const size_t nc = (color & 2) ? 3 : 1;
+        if ((color & 4) || len != nc * 2) return *err = "bad tRNS", false;
+        for (size_t k = 0; k < nc; ++k) key[k] = uint16_t((data[2 * k] << 8) | data[2 * k + 1]);
+      }
+      have_trns = true;
+    } else if (memcmp(type, "IDAT", 4) == 0) {
+      if (color == 3 && pal_len == 0) return *err = "no PLTE", false;
+      idat.insert(idat.end(), data, data + len);
+    } else if (memcmp(type, "IEND", 4) == 0) {
+      break;
+    } else if (!(type[0] & 32)) {
+      return *err = "unknown critical PNG chunk", false;
+    }
+    pos += 12 + size_t(len);
+  }
+  if (idat.empty()) return *err = "no IDAT", false;
+  std::vector<uint8_t> raw;
+  if (!ZlibInflate(idat.data(), idat.size(), &raw, err)) return false;
+
+  const size_t file_n = (color == 3) ? 1 : ((color & 2) ? 3 : 1) + ((color & 4) ? 1 : 0);  // samples per pixel as stored
+  const size_t bits_pp = file_n * size_t(depth);
+  const size_t bpp = (bits_pp + 7) / 8;
+  // samples of the whole image, 16 bits each (value as stored; sub-byte values unscaled)
+  std::vector<uint16_t> samp(size_t(w) * h * file_n);
+  size_t rpos = 0;
+  static const int xo[7] = {0, 4, 0, 2, 0, 1, 0}, yo[7] = {0, 0, 4, 0, 2, 0, 1}, xs[7] = {8, 8, 4, 4, 2, 2, 1}, ys[7] = {8, 8, 8, 4, 4, 2, 2};
+  const int passes = interlace ? 7 : 1;
+  for (int p = 0; p < passes; ++p) {
+    const size_t x0 = interlace ? xo[p] : 0, y0 = interlace ? yo[p] : 0, dx = interlace ? xs[p] : 1, dy = interlace ? ys[p] : 1;
+    const size_t pw = (w + dx - 1 - x0) / dx, ph = (h + dy - 1 - y0) / dy;
+    if (x0 >= w || y0 >= h || pw == 0 || ph == 0) continue;
+    const size_t row_bytes = (pw * bits_pp + 7) / 8;
+    if (rpos + (row_bytes + 1) * ph > raw.size()) return *err = "not enough pixel data", false;
+    if (!unfilter(raw.data() + rpos, ph, row_bytes, bpp)) return *err = "bad PNG row filter", false;
+    for (size_t y = 0; y < ph; ++y) {
+      const uint8_t* row = raw.data() + rpos + y * (row_bytes + 1) + 1;
+      for (size_t x = 0; x < pw; ++x) {
+        uint16_t* dst = &samp[((y0 + y * dy) * w + (x0 + x * dx)) * file_n];
+        for (size_t c = 0; c < file_n; ++c) {
+          const size_t s = x * file_n + c;
+          if (depth == 16) dst[c] = uint16_t((row[2 * s] << 8) | row[2 * s + 1]);
+          else if (depth == 8) dst[c] = row[s];
+          else {
+            const size_t bit = s * size_t(depth);
+            dst[c] = uint16_t((row[bit >> 3] >> (8 - depth - int(bit & 7))) & ((1 << depth) - 1));
+          }
+        }
+      }
+    }
+    rpos += (row_bytes + 1) * ph;
+  }
+
+  // -> 8-bit output the way stb_image delivers it
+  static const int scale_tab[9] = {0, 0xff, 0x55, 0, 0x11, 0, 0, 0, 0x01};
+  const size_t npx = size_t(w) * h;
+  size_t out_n;
+  if (color == 3) {
+    out_n = have_trns ? 4 : 3;
+    pixels->resize(npx * out_n);
+    for (size_t i = 0; i < npx; ++i) {
+      const size_t idx = samp[i];  // an index beyond the palette reads zeros/255 like an untouched entry would not: reject
+      if (idx >= 256) return *err = "bad palette index", false;
+      const uint8_t* e = palette + idx * 4;
+      uint8_t zero[4] = {0, 0, 0, 255};
+      if (idx >= pal_len) e = zero;
+      for (size_t c = 0; c < out_n; ++c) (*pixels)[i * out_n + c] = e[c];
+    }
+  } else {
+    out_n = file_n + (have_trns ? 1 : 0);
+    pixels->resize(npx * out_n);
+    const int sc = depth < 8 ? scale_tab[depth] : 1;
+    uint16_t k8[3] = {0, 0, 0};
+    if (have_trns && depth < 16)
+      for (int k = 0; k < 3; ++k) k8[k] = uint16_t((key[k] & 255) * (depth < 8 ? scale_tab[depth] : 1)) & 255;
+    for (size_t i = 0; i < npx; ++i) {
+      const uint16_t* s = &samp[i * file_n];
+      uint8_t* d = &(*pixels)[i * out_n];
+      bool match = have_trns;
+      for (size_t c = 0; c < file_n; ++c) {
+        if (depth == 16) {
+          d[c] = uint8_t(s[c] >> 8);
+          if (have_trns && s[c] != key[c]) match = false;
+        } else {
+          d[c] = uint8_t(s[c] * sc);
+          if (have_trns && d[c] != uint8_t(k8[c])) match = false;
+        }
+      }
+      if (have_trns) d[file_n] = match ? 0 : 255;
+    }
+  }
+  *width = w, *height = h, *channels = out_n;
+  return true;
+}
+
+bool DecodeHdr(const uint8_t* file, size_t n, std::vector<float>* pixels, size_t* width, size_t* height, std::string* err) {
+  size_t pos = 0;
+  auto getline = [&](std::string* s) {  // stbi__hdr_gettoken: up to '\n' (at most 1023 characters are kept)
+    s->clear();
+    while (pos < n && file[pos] != '\n') {
+      if (s->size() < 1023) s->push_back(char(file[pos]));
+      ++pos;
+    }
+    if (pos < n) ++pos;
+  };
+  auto get8 = [&]() -> int { return pos < n ? file[pos++] : 0; };
+  std::string tok;
+  getline(&tok);
+  if (tok != "#?RADIANCE" && tok != "#?RGBE") return *err = "not a Radiance HDR file", false;
+  bool valid = false;
+  for (;;) {
+    getline(&tok);
+    if (tok.empty()) break;
+    if (tok == "FORMAT=32-bit_rle_rgbe") valid = true;
+    if (pos >= n) break;
+  }
+  if (!valid) return *err = "unsupported HDR format", false;
+  getline(&tok);
+  if (tok.compare(0, 3, "-Y ") != 0) return *err = "unsupported HDR data layout", false;
+  char* rest = nullptr;
+  const long hh = strtol(tok.c_str() + 3, &rest, 10);
+  while (*rest == ' ') ++rest;
+  if (strncmp(rest, "+X ", 3) != 0) return *err = "unsupported HDR data layout", false;
+  const long ww = strtol(rest + 3, nullptr, 10);
+  if (ww <= 0 || hh <= 0 || ww > (1 << 24) || hh > (1 << 24)) return *err = "bad HDR size", false;
+  const size_t w = size_t(ww), h = size_t(hh);
+  pixels->assign(w * h * 3, 0.0f);
+  auto convert = [&](float* out, const uint8_t* in) {  // stbi__hdr_convert, 3 channels
+    if (in[3] != 0) {
+      const float f1 = float(ldexp(1.0f, int(in[3]) - (128 + 8)));
+      out[0] = in[0] * f1, out[1] = in[1] * f1, out[2] = in[2] * f1;
+    } else {
+      out[0] = out[1] = out[2] = 0.0f;
+    }
+  };
+  auto flat_from = [&](size_t first) {
+    for (size_t i = first; i < w * h; ++i) {
+      uint8_t rgbe[4];
+      for (int k = 0; k < 4; ++k) rgbe[k] = uint8_t(get8());
+      convert(&(*pixels)[i * 3], rgbe);
+    }
+  };
+  if (w < 8 || w >= 32768) {
+    flat_from(0);
+  } else {
+    std::vector<uint8_t> scan(w * 4);
+    for (size_t j = 0; j < h; ++j) {
+      const int c1 = get8(), c2 = get8();
+      int len = get8();
+      if (c1 != 2 || c2 != 2 || (len & 0x80)) {  // not run-length encoded: these 4 bytes are pixel 0 of a flat file
+        uint8_t rgbe[4] = {uint8_t(c1), uint8_t(c2), uint8_t(len), uint8_t(get8())};
+        convert(&(*pixels)[0], rgbe);
+        flat_from(1);
+        break;
+      }
+      len = (len << 8) | get8();
+      if (size_t(len) != w) return *err = "corrupt HDR: bad scanline length", false;
+      for (int k = 0; k < 4; ++k) {
+        size_t i = 0;
+        while (i < w) {
+          int count = get8();
+          const size_t left = w - i;
+          if (count > 128) {
+            const uint8_t value = uint8_t(get8());
+            count -= 128;
+            if (size_t(count) > left) return *err = "corrupt HDR: bad RLE data", false;
+            for (int z = 0; z < count; ++z) scan[i++ * 4 + size_t(k)] = value;
+          } else {
+            if (size_t(count) > left) return *err = "corrupt HDR: bad RLE data", false;
+            if (count == 0 && pos >= n) return *err = "truncated HDR", false;
+            for (int z = 0; z < count; ++z) scan[i++ * 4 + size_t(k)] = uint8_t(get8());
+          }
+        }
+      }
+      for (size_t i = 0; i < w; ++i) convert(&(*pixels)[(j * w + i) * 3], &scan[i * 4]);
+    }
+  }
+  *width = w, *height = h;
+  return true;
+}
+
+// ---------------------------------------------------------------- pbrlab's image functions
+namespace {
+std::string join_path(const std::string& dir, const std::string& name) {  // fs::path(dir) / name
+  if (!name.empty() && name[0] == '/') return name;
+  if (dir.empty()) return name;
+  return dir.back() == '/' ? dir + name : dir + "/" + name;
+}
+std::string lower_ext(const std::string& name) {
+  const size_t slash = name.find_last_of('/');
+  const size_t dot = name.find_last_of('.');
+  if (dot == std::string::npos || (slash != std::string::npos && dot < slash)) return "";
+  std::string e = name.substr(dot);
+  for (char& c : e) c = char(tolower(c));
+  return e;
+}
+bool read_file(const std::string& path, std::vector<uint8_t>* out) {
+  std::ifstream f(path.c_str(), std::ios::binary);
+  if (!f) return false;
+  out->assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+  return true;
+}
+const char* sniff(const std::vector<uint8_t>& d) {
+  if (d.size() >= 3 && d[0] == 0xFF && d[1] == 0xD8) return "JPEG";
+  if (d.size() >= 2 && d[0] == 'B' && d[1] == 'M') return "BMP";
+  if (d.size() >= 4 && memcmp(d.data(), "GIF8", 4) == 0) return "GIF";
+  if (d.size() >= 4 && memcmp(d.data(), "8BPS", 4) == 0) return "PSD";
+  if (d.size() >= 2 && d[0] == 'P' && (d[1] == '5' || d[1] == '6')) return "PNM";
+  if (d.size() >= 4 && d[0] == 0x76 && d[1] == 0x2f && d[2] == 0x31 && d[3] == 0x01) return "OpenEXR";
+  return "unknown (TGA?)";
+}
+}  // namespace
+
+bool LoadImageFromFile(const std::string& filename, const std::string& asset_path, std::vector<float>* pixels,
+                       size_t* width, size_t* height, size_t* channels) {
+  if (!pixels || !width || !height || !channels) return false;
+  const std::string path = join_path(asset_path, filename);
+  const std::string ext = lower_ext(filename);
+  std::vector<uint8_t> bytes;
+  if (!read_file(path, &bytes)) {
+    std::cerr << "cannot open image file [" << path << "]" << std::endl;
+    return false;
+  }
+  std::string err;
+  if (ext == ".exr") {
+    std::cerr << "image file [" << path << "]: OpenEXR is not decoded by this build (convert to .hdr or .png)" << std::endl;
+    return false;
+  }
+  if (ext == ".hdr") {
+    if (!DecodeHdr(bytes.data(), bytes.size(), pixels, width, height, &err)) {
+      std::cerr << "image file [" << path << "]: " << err << std::endl;
+      return false;
+    }
+    *channels = 3;
+    return true;
+  }
+  if (bytes.size() >= 8 && memcmp(bytes.data(), kPngSig, 8) == 0) {
+    std::vector<uint8_t> px8;
+    if (!DecodePng(bytes.data(), bytes.size(), &px8, width, height, channels, &err)) {
+      std::cerr << "image file [" << path << "]: " << err << std::endl;
+      return false;
+    }
+    pixels->resize(px8.size());
+    for (size_t i = 0; i < px8.size(); ++i) (*pixels)[i] = float(px8[i]) / float(255);
+    return true;
+  }
+  std::cerr << "image file [" << path << "]: format " << sniff(bytes) << " is not decoded by this build (convert to .png)" << std::endl;
+  return false;
+}
+
+namespace {
+template <typename T>
+bool write_png_checked(const std::string& filename, const std::string& asset_path, const std::vector<T>& pixels,
+                       size_t width, size_t height, size_t channels, std::vector<uint8_t>* px8, std::string* path) {
+  *path = join_path(asset_path, filename);
+  const size_t slash = path->find_last_of('/'), dot = path->find_last_of('.');
+  const std::string ext = (dot == std::string::npos || (slash != std::string::npos && dot < slash)) ? "" : path->substr(dot);
+  if (ext != ".png") {
+    std::cerr << "warning! the file extension is not \"png\"" << std::endl;
+    return false;
+  }
+  if (pixels.size() == 0 || pixels.size() != width * height * channels) {
+    std::cerr << "the image data is broken" << std::endl;
+    return false;
+  }
+  px8->resize(pixels.size());
+  return true;
+}
+bool finish_png(const std::string& filename, const std::string& path, const std::vector<uint8_t>& px8, size_t width,
+                size_t height, size_t channels) {
+  std::vector<uint8_t> file;
+  bool ok = EncodePng(px8.data(), width, height, channels, &file);
+  if (ok) {
+    FILE* fp = fopen(path.c_str(), "wb");
+    ok = fp && fwrite(file.data(), 1, file.size(), fp) == file.size();
+    if (fp) ok = (fclose(fp) == 0) && ok;
+  }
+  if (!ok) {
+    std::cerr << "faild save image" << std::endl;
+    return false;
+  }
+  std::cerr << "write png file [ " << filename << " ]" << std::endl;
+  return true;
+}
+inline uint8_t to_byte(float x) {  // static_cast<unsigned char>(Clamp(x * 256.0f, 0.0f, 255.0f)), image-io.cc:37-40,203-205
+  const float s = x * 256.0f;
+  const float lo = (s < 255.0f) ? s : 255.0f;   // std::min(255, s): s when s < 255 (NaN -> 255)
+  const float v = (0.0f < lo) ? lo : 0.0f;      // std::max(0, lo)
+  return static_cast<uint8_t>(v);
+}
+}  // namespace
+
+bool WritePNG(const std::string& filename, const std::string& asset_path, const std::vector<float>& pixels, size_t width,
+              size_t height, size_t channels) {
+  std::vector<uint8_t> px8;
+  std::string path;
+  if (!write_png_checked(filename, asset_path, pixels, width, height, channels, &px8, &path)) return false;
+  for (size_t i = 0; i < pixels.size(); ++i) px8[i] = to_byte(pixels[i]);
+  return finish_png(filename, path, px8, width, height, channels);
+}
+
+bool WritePNG(const std::string& filename, const std::string& asset_path, const std::vector<uint8_t>& pixels, size_t width,
+              size_t height, size_t channels) {
+  std::vector<uint8_t> px8;
+  std::string path;
+  if (!write_png_checked(filename, asset_path, pixels, width, height, channels, &px8, &path)) return false;
+  px8 = pixels;
+  return finish_png(filename, path, px8, width, height, channels);
+}
+
+float SrgbToLiner(float c) {
+  if (c <= 0.04045f) return c / 12.92f;
+  const float a = 0.055f;
+  return powf((c + a) / (1.0f + a), 2.4f);
+}
+
+float LinerTosRGB(float c) {
+  if (c <= 0.0031308f) return 12.92f * c;
+  const float a = 0.055f;
+  return powf((1.0f + a) * c, static_cast<float>(1.0 / 2.4)) - a;
+}
+
+void SrgbToLiner(const std::vector<float>& src, size_t width, size_t height, size_t channels, std::vector<float>* out) {
+  std::vector<float> dst(width * height * channels);
+  for (size_t i = 0; i < width * height; ++i)
+    for (size_t k = 0; k < channels; ++k) dst[i * channels + k] = k < 3 ? SrgbToLiner(src[i * channels + k]) : src[i * channels + k];
+  out->swap(dst);
+}
+
+void LinerToSrgb(const std::vector<float>& src, size_t width, size_t height, size_t channels, std::vector<float>* out) {
+  std::vector<float> dst(width * height * channels);
+  for (size_t i = 0; i < width * height; ++i)
+    for (size_t k = 0; k < channels; ++k) dst[i * channels + k] = k < 3 ? LinerTosRGB(src[i * channels + k]) : src[i * channels + k];
+  out->swap(dst);
+}
+
+void ResolveLayerToSrgb8(const float* rgba, const uint32_t* count, size_t width, size_t height, std::vector<uint8_t>* out) {
+  out->resize(width * height * 4);
+  for (size_t i = 0; i < width * height; ++i) {
+    const float n = float(count[i]);
+    for (size_t k = 0; k < 4; ++k) {
+      const float c = rgba[i * 4 + k] / n;
+      (*out)[i * 4 + k] = to_byte(k < 3 ? LinerTosRGB(c) : c);
+    }
+  }
+}
+
+}  // namespace pbio

@@ -1,0 +1,52 @@
+// image_codec.h -- image input (texture files of `map_base_color` / `map_subsurface_color`) and output (rgba.png)
+// for the pbrlab scene path.  Reference: src/io/image-io.cc:98-224 (which delegates
+// to the vendored stb_image / stb_image_write), src/image-utils.cc:8-107 (sRGB transfer functions).
+//
+// Written from scratch: a zlib inflater/deflater, PNG reader (all colour types and bit depths, Adam7) and writer,
+// Radiance .hdr reader.  Decoded pixels equal stb_image's for the same file (16-bit samples keep their high byte,
+// sub-byte grey is scaled to 0..255, a tRNS colour key becomes an alpha channel).  JPEG, BMP, TGA, GIF, PSD, PNM and
+// OpenEXR are NOT decoded by this build: loading such a file fails with a message naming the format.
+#ifndef PBRLAB_AMD_IO_IMAGE_CODEC_H_
+#define PBRLAB_AMD_IO_IMAGE_CODEC_H_
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace pbio {
+
+// zlib streams (RFC 1950/1951)
+bool ZlibInflate(const uint8_t* src, size_t n, std::vector<uint8_t>* out, std::string* err);
+void ZlibDeflate(const uint8_t* src, size_t n, std::vector<uint8_t>* out);
+
+// 8-bit PNG, channels 1..4 (grey, grey+alpha, RGB, RGBA)
+bool EncodePng(const uint8_t* pixels, size_t width, size_t height, size_t channels, std::vector<uint8_t>* file);
+// -> 8 bits per channel, channel count of the file (stbi_load(..., req_comp = 0))
+bool DecodePng(const uint8_t* file, size_t n, std::vector<uint8_t>* pixels, size_t* width, size_t* height,
+               size_t* channels, std::string* err);
+// Radiance RGBE -> 3 floats per pixel (stbi_loadf on a .hdr)
+bool DecodeHdr(const uint8_t* file, size_t n, std::vector<float>* pixels, size_t* width, size_t* height,
+               std::string* err);
+
+// io::LoadImageFromFile<float> (image-io.cc:98-152): 8-bit formats are returned as value / 255
+bool LoadImageFromFile(const std::string& filename, const std::string& asset_path, std::vector<float>* pixels,
+                       size_t* width, size_t* height, size_t* channels);
+// io::WritePNG<float> (image-io.cc:172-224): only names ending in ".png"; byte = clamp(x * 256, 0, 255)
+bool WritePNG(const std::string& filename, const std::string& asset_path, const std::vector<float>& pixels,
+              size_t width, size_t height, size_t channels);
+bool WritePNG(const std::string& filename, const std::string& asset_path, const std::vector<uint8_t>& pixels,
+              size_t width, size_t height, size_t channels);
+
+// image-utils.cc:8-41 (float instantiations: std::pow(float, float))
+float SrgbToLiner(float c_srgb);
+float LinerTosRGB(float c_liner);
+// image-utils.cc:43-107: the first three channels are converted, a fourth is copied
+void SrgbToLiner(const std::vector<float>& src, size_t width, size_t height, size_t channels, std::vector<float>* out);
+void LinerToSrgb(const std::vector<float>& src, size_t width, size_t height, size_t channels, std::vector<float>* out);
+
+// pbrlab-cli.cc:47-57: rgba / count -> sRGB -> 8-bit RGBA
+void ResolveLayerToSrgb8(const float* rgba, const uint32_t* count, size_t width, size_t height, std::vector<uint8_t>* out);
+
+}  // namespace pbio
+#endif

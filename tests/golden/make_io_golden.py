@@ -1,0 +1,91 @@
+"""Generates tests/golden/io/: small OBJ/MTL/CyHair/PNG/HDR inputs and, in io_golden.npz, what the REFERENCE's own
+loaders return for them (oracle/_ref/libref_io.so = the reference's vendored tinyobjloader, cyhair.cc,
+curve-mesh-io.cc, image-io.cc + stb compiled unmodified).  Needs /root/reference (run oracle/Makefile first).
+
+    python tests/golden/make_io_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import _iofiles  # noqa: E402
+import _refio  # noqa: E402
+
+OUT = os.path.join(HERE, "io")
+OBJ_SEEDS = [0, 1, 3, 5, 7, 10, 11, 21, 35, 42]
+HAIR_CASES = [dict(), dict(segments=5), dict(thickness=False), dict(extras=True), dict(min_points=2), dict(segments=1)]
+PNG_CASES = [  # (color, depth, interlace, trns)
+    (0, 1, 0, False), (0, 4, 1, True), (0, 8, 0, False), (0, 16, 0, True), (2, 8, 0, False), (2, 8, 1, True),
+    (2, 16, 0, False), (3, 2, 0, False), (3, 8, 1, True), (4, 8, 0, False), (4, 16, 1, False), (6, 8, 0, False),
+    (6, 16, 0, False),
+]
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    g = {}
+    for seed in OBJ_SEEDS:
+        f = _iofiles.write_obj_case(os.path.join(OUT, "case%d" % seed), seed, crlf=(seed % 4 == 1))
+        r = _refio.obj_load(f, OUT)
+        assert r["ok"]
+        for k in ("vertices", "normals", "texcoords", "corners", "shape_first", "material_ids"):
+            g["obj%d_%s" % (seed, k)] = r[k]
+        g["obj%d_text" % seed] = np.frombuffer(r["text"].encode(), np.uint8)
+    for i, kw in enumerate(HAIR_CASES):
+        p = os.path.join(OUT, "strands%d.hair" % i)
+        _iofiles.write_cyhair(p, 100 + i, **kw)
+        for ms in (0, 1):
+            ok, v, idx = _refio.hair_load(p, bool(ms))
+            g["hair%d_%d_ok" % (i, ms)] = np.asarray([ok])
+            g["hair%d_%d_vertices" % (i, ms)] = v
+            g["hair%d_%d_indices" % (i, ms)] = idx
+    rng = np.random.default_rng(7)
+    for i, (color, depth, interlace, trns) in enumerate(PNG_CASES):
+        c = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[color]
+        w, h = int(rng.integers(3, 24)), int(rng.integers(3, 24))
+        img = rng.integers(0, 1 << depth, size=(h, w, c))
+        if i % 2 == 0:
+            img = (np.add.outer(np.arange(h), np.arange(w))[:, :, None] * np.ones(c, int)) % (1 << depth)
+        pal = t = None
+        if color == 3:
+            pal = rng.integers(0, 256, size=(1 << depth, 3))
+            if trns:
+                t = rng.integers(0, 256, size=(1 << depth) // 2).astype(np.uint8).tobytes()
+        elif trns:
+            t = b"".join(int(k).to_bytes(2, "big") for k in img[0, 0])
+        name = "tex%d.png" % i
+        _iofiles.write_png(os.path.join(OUT, name), img, depth=depth, color=color, interlace=interlace, palette=pal, trns=t,
+                           level=[0, 1, 6, 9][i % 4], seed=i)
+        g["png%d" % i] = _refio.image_load(name, OUT)
+    for i, (w, h, rle) in enumerate([(5, 4, True), (20, 6, True), (16, 5, False)]):
+        img = rng.random((h, w, 3)).astype(np.float32) * 10.0 ** rng.integers(-2, 3)
+        img[:, : w // 2] = 0.25
+        name = "env%d.hdr" % i
+        _iofiles.write_hdr(os.path.join(OUT, name), img, rle=rle)
+        g["hdr%d" % i] = _refio.image_load(name, OUT)
+    # output stage of pbrlab-cli (rgba/count -> sRGB -> byte(x*256) -> stb PNG), decoded back by stb
+    rgba = (rng.random((19, 23, 4)) * 40).astype(np.float32)
+    count = np.full((19, 23), 32, np.uint32)
+    count[0, 0] = 0
+    rgba[1, 1] = np.nan
+    rgba[2, 2] = -1.0
+    rgba[3, 3] = 1e9
+    assert _refio.cli_output("cli_ref.png", OUT, rgba, count)
+    g["cli_rgba"], g["cli_count"] = rgba, count
+    g["cli_png_pixels"] = (_refio.image_load("cli_ref.png", OUT) * 255 + 0.5).astype(np.uint8)
+    # texture statements
+    stmts = ["tex.png", "-colorspace linear tex.png", "-colorspace sRGB my tex.png", "-clamp on -s 1 2 3 tex.png",
+             "-bm 0.5 -blendu off -mm 0 1 -o 1 1 1 -t 0 0 0 -texres 512 -imfchan r -type sphere -boost 2 a b.png",
+             "-colorspace", "  spaced.png", "-clamp on"]
+    res = [_refio.parse_texopt(s) for s in stmts]
+    g["texopt_in"] = np.frombuffer("\n".join(stmts).encode(), np.uint8)
+    g["texopt_out"] = np.frombuffer("\n".join("%d\t%s\t%s" % (int(a), b, c) for a, b, c in res).encode(), np.uint8)
+    np.savez_compressed(os.path.join(OUT, "io_golden.npz"), **g)
+    print("wrote", len(g), "arrays,", sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT)), "bytes in", OUT)
+
+
+if __name__ == "__main__":
+    main()
