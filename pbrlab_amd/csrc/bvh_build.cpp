@@ -181,16 +181,15 @@ void build_bvh(const std::vector<float>& lo, const std::vector<float>& hi, const
 
   // flatten: internal nodes get consecutive indices in DFS order; node 0 is always internal
   const std::vector<TNode>& T = pool.nodes;
-  auto nan_box = [](float* l, float* h) {
-    for (int a = 0; a < 3; a++) l[a] = h[a] = std::numeric_limits<float>::quiet_NaN();
-  };
+  const float kNaN3[3] = {std::numeric_limits<float>::quiet_NaN(), std::numeric_limits<float>::quiet_NaN(),
+                          std::numeric_limits<float>::quiet_NaN()};
   std::vector<BvhNode>& N = out->nodes;
   uint32_t depth = 0;
   if (T[root].left < 0) {
     BvhNode nd;
     memset(&nd, 0, sizeof(nd));
-    memcpy(nd.lo0, T[root].box.lo, 12), memcpy(nd.hi0, T[root].box.hi, 12);
-    nan_box(nd.lo1, nd.hi1);
+    nd.set_box(0, T[root].box.lo, T[root].box.hi);
+    nd.set_box(1, kNaN3, kNaN3);
     nd.c0 = leaf_ref(T[root]);
     nd.c1 = kEmptyChild;
     N.push_back(nd);
@@ -211,8 +210,8 @@ void build_bvh(const std::vector<float>& lo, const std::vector<float>& hi, const
       BvhNode nd;
       memset(&nd, 0, sizeof(nd));
       const TNode &l = T[t.left], &r = T[t.right];
-      memcpy(nd.lo0, l.box.lo, 12), memcpy(nd.hi0, l.box.hi, 12);
-      memcpy(nd.lo1, r.box.lo, 12), memcpy(nd.hi1, r.box.hi, 12);
+      nd.set_box(0, l.box.lo, l.box.hi);
+      nd.set_box(1, r.box.lo, r.box.hi);
       if (l.left < 0) {
         nd.c0 = leaf_ref(l);
       } else {

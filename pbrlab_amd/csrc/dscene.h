@@ -29,11 +29,16 @@ constexpr int kMaxLeaf = PB_MAX_LEAF;
 #endif
 constexpr int kStackDepth = PB_STACK_DEPTH;
 
+// Both children's boxes, interleaved [axis][child] so that the two children's values of one bound sit in an aligned
+// register pair after the 16-byte loads: the slab test runs on v_pk_add_f32 / v_pk_mul_f32 (two children per instruction).
 struct alignas(16) BvhNode {
-  float lo0[3], hi0[3];
-  float lo1[3], hi1[3];
+  float lo[3][2];
+  float hi[3][2];
   uint32_t c0, c1;
   uint32_t pad[2];
+  void set_box(int child, const float* l, const float* h) {
+    for (int a = 0; a < 3; a++) lo[a][child] = l[a], hi[a][child] = h[a];
+  }
 };
 static_assert(sizeof(BvhNode) == 64, "node must be 64 B");
 

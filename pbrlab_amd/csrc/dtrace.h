@@ -99,19 +99,29 @@ __device__ __forceinline__ bool curve_test(const float4 cp[4], V3 o, V3 d, float
   return found;
 }
 
-// conservative slab test against [tmin, tmax]; returns entry distance in tnear
-__device__ __forceinline__ bool box_test(const float* lo, const float* hi, V3 o, V3 inv, float tmin, float tmax,
-                                         float& tnear) {
-  float t0 = (lo[0] - o.x) * inv.x, t1 = (hi[0] - o.x) * inv.x;
-  float a = fminf(t0, t1), b = fmaxf(t0, t1);
-  t0 = (lo[1] - o.y) * inv.y, t1 = (hi[1] - o.y) * inv.y;
-  a = fmaxf(a, fminf(t0, t1)), b = fminf(b, fmaxf(t0, t1));
-  t0 = (lo[2] - o.z) * inv.z, t1 = (hi[2] - o.z) * inv.z;
-  a = fmaxf(a, fminf(t0, t1)), b = fminf(b, fmaxf(t0, t1));
-  a = a - fabsf(a) * 1.52587890625e-05f;
-  b = b + fabsf(b) * 1.52587890625e-05f;
-  tnear = a;
-  return a <= b && b >= tmin && a <= tmax;
+// Conservative slab test of BOTH children of a node against [tmin, tmax] (entry distances in t0, t1).  n0..n2 are the
+// first three 16-byte words of a BvhNode: (lo.x pair, lo.y pair), (lo.z pair, hi.x pair), (hi.y pair, hi.z pair), each
+// pair = (child 0, child 1).  The interval is widened by 2^-16 relative; the test only has to be conservative (hits do
+// not depend on which boxes are visited), so the widening may use fma.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void box_test2(const float4& n0, const float4& n1, const float4& n2, V3 o, V3 inv, float tmin,
+                                          float tmax, bool& h0, bool& h1, float& t0, float& t1) {
+  const f2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
+  const f2 ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
+  const f2 lx = {n0.x, n0.y}, ly = {n0.z, n0.w}, lz = {n1.x, n1.y};
+  const f2 hx = {n1.z, n1.w}, hy = {n2.x, n2.y}, hz = {n2.z, n2.w};
+  f2 p = (lx - ox) * ix, q = (hx - ox) * ix;
+  f2 a = __builtin_elementwise_min(p, q), b = __builtin_elementwise_max(p, q);
+  p = (ly - oy) * iy, q = (hy - oy) * iy;
+  a = __builtin_elementwise_max(a, __builtin_elementwise_min(p, q)), b = __builtin_elementwise_min(b, __builtin_elementwise_max(p, q));
+  p = (lz - oz) * iz, q = (hz - oz) * iz;
+  a = __builtin_elementwise_max(a, __builtin_elementwise_min(p, q)), b = __builtin_elementwise_min(b, __builtin_elementwise_max(p, q));
+  const float e = 1.52587890625e-05f;
+  const float a0 = __builtin_fmaf(-fabsf(a.x), e, a.x), a1 = __builtin_fmaf(-fabsf(a.y), e, a.y);
+  const float b0 = __builtin_fmaf(fabsf(b.x), e, b.x), b1 = __builtin_fmaf(fabsf(b.y), e, b.y);
+  t0 = a0, t1 = a1;
+  h0 = a0 <= b0 && b0 >= tmin && a0 <= tmax;
+  h1 = a1 <= b1 && b1 >= tmin && a1 <= tmax;
 }
 
 // Leaf processing.  ANY: returns true on the first accepted hit.
@@ -160,12 +170,10 @@ __device__ __forceinline__ bool traverse(const DScene& sc, V3 o, V3 d, float tmi
     const float4* np = reinterpret_cast<const float4*>(sc.nodes + cur);
     float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
     if (STATS) st.nodes++;
-    float lo0[3] = {n0.x, n0.y, n0.z}, hi0[3] = {n0.w, n1.x, n1.y};
-    float lo1[3] = {n1.z, n1.w, n2.x}, hi1[3] = {n2.y, n2.z, n2.w};
     uint32_t c0 = __float_as_uint(n3.x), c1 = __float_as_uint(n3.y);
     float t0, t1;
-    bool h0 = box_test(lo0, hi0, o, inv, tmin, best_t, t0);
-    bool h1 = box_test(lo1, hi1, o, inv, tmin, best_t, t1);
+    bool h0, h1;
+    box_test2(n0, n1, n2, o, inv, tmin, best_t, h0, h1, t0, t1);
     uint32_t next = kEmptyChild;
     if (h0 && h1) {
       uint32_t nearc = c0, farc = c1;

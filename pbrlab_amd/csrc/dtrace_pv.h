@@ -49,8 +49,17 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
   // being walked serially by a few (a 20 k-ray launch took 1.5 ms with fixed 512-ray batches).
   uint32_t batch_cur = 0, batch_end = 0;
   const uint32_t waves_total = gridDim.x * (blockDim.x >> 6);
-  uint32_t batch = (n / waves_total) & ~63u;
-  batch = batch < 64u ? 64u : (batch > kPvBatch ? kPvBatch : batch);
+  uint32_t batch = n / waves_total;
+  if (batch >= 64u) {
+    batch &= ~63u;
+    batch = batch > kPvBatch ? kPvBatch : batch;
+  } else {
+    // fewer rays than resident lanes: spread them thin (a few lanes per wave, every SIMD busy).  A launch like this is
+    // bound by the latency of its longest ray, and a ray advances fastest when its wave has no other phase to vote for
+    // (tail launches of 10 k rays took 100-300 us with one full wave per 64 rays).
+    batch = (n + waves_total - 1u) / waves_total;
+    batch = batch < 1u ? 1u : batch;
+  }
   bool exhausted = (n == 0) || (sc.num_nodes == 0);
   if (sc.num_nodes == 0 && n != 0) {
     // empty scene: every ray misses
@@ -129,12 +138,10 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
         // ---- NODE phase
         if (state == kStNode) {
           if (STATS) (any_ray ? st.anodes : st.nodes)++;
-          float lo0[3] = {D0.x, D0.y, D0.z}, hi0[3] = {D0.w, D1.x, D1.y};
-          float lo1[3] = {D1.z, D1.w, D2.x}, hi1[3] = {D2.y, D2.z, D2.w};
           uint32_t c0 = __float_as_uint(D3.x), c1 = __float_as_uint(D3.y);
           float t0, t1;
-          bool h0 = box_test(lo0, hi0, o, inv, tmin, best_t, t0);
-          bool h1 = box_test(lo1, hi1, o, inv, tmin, best_t, t1);
+          bool h0, h1;
+          box_test2(D0, D1, D2, o, inv, tmin, best_t, h0, h1, t0, t1);
           bool swap = h1 && (!h0 || t1 < t0);
           uint32_t nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
           advance = true;

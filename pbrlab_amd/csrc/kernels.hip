@@ -772,7 +772,9 @@ void launch_generate(hipStream_t s, const PathState& P, const Camera& cam, const
                      width, first_pass, seed_seq);
 }
 void launch_trace(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, bool stats) {
-  dim3 g(grid_for(n_upper, kTraceGridCap));
+  // persistent kernel: the resident set, unless there are so few rays that 4 per wave need fewer blocks
+  uint32_t blocks = (n_upper + 15u) / 16u;
+  dim3 g(blocks < 1u ? 1u : (blocks < kTraceGridCap ? blocks : kTraceGridCap));
   const bool curves = sc.num_curves != 0;
   if (stats && curves) hipLaunchKernelGGL((k_trace<true, true>), g, dim3(kBlock), 0, s, P, sc);
   else if (stats) hipLaunchKernelGGL((k_trace<true, false>), g, dim3(kBlock), 0, s, P, sc);
