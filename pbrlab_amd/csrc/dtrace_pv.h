@@ -28,7 +28,10 @@ constexpr int kPvLdsStack = PB_LDS_STACK;  // stack entries per lane kept in LDS
 #endif
 constexpr int kPvRefillIdle = PB_REFILL;         // refill when at least this many lanes are idle
 
-enum : uint32_t { kStIdle = 0, kStNode = 1, kStTri = 2, kStCurve = 3 };
+// kStDone / kStDoneOccluded: the ray is finished, its result still sits in the lane's registers.  Results are delivered
+// (sink.done: a store, or a read-modify-write of the path's radiance) together, at the next refill, instead of by the one
+// or two lanes that happen to finish in an iteration -- the delivery code costs the same however few lanes run it.
+enum : uint32_t { kStIdle = 0, kStNode = 1, kStTri = 2, kStCurve = 3, kStDone = 4, kStDoneOccluded = 5 };
 
 // Sink: what to do with a finished ray.  closest: store the hit record; shadow: resolve the contribution.
 //   bool load(uint32_t idx, uint32_t& tag, V3& o, V3& d, float& tmin, float& tmax)   returns "any-hit ray"
@@ -92,7 +95,7 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
   float4 D0 = make_float4(0, 0, 0, 0), D1 = D0, D2 = D0, D3 = D0;  // prefetched node / primitive slot
 
   for (;;) {
-    unsigned long long idle_mask = __ballot(state == kStIdle);
+    unsigned long long idle_mask = __ballot(state == kStIdle || state >= kStDone);
     int n_idle = __popcll(idle_mask);
     // `advance`: the lane needs a new item; `next` is its reference when have_next, else it is popped
     bool advance = false, have_next = false, need_load = false;
@@ -106,6 +109,10 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
         batch_cur = base < n ? base : n;
         batch_end = (base + batch) < n ? (base + batch) : n;
         if (batch_cur >= n) exhausted = true;
+      }
+      if (state >= kStDone) {
+        sink.done(tag, hit, state == kStDoneOccluded);
+        state = kStIdle;
       }
       uint32_t avail = batch_end - batch_cur;
       uint32_t take = (uint32_t)n_idle < avail ? (uint32_t)n_idle : avail;
@@ -179,8 +186,7 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
             hit.t = t, hit.u = u, hit.v = v, hit.slot = cur;
           }
           if (any_ray && ok) {
-            sink.done(tag, hit, true);
-            state = kStIdle;
+            state = kStDoneOccluded;
           } else {
             cur++;
             if (cur < end) need_load = true;  // next primitive of the same leaf
@@ -193,8 +199,7 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
     if (advance) {
       if (!have_next) {
         if (sp == 0) {
-          sink.done(tag, hit, false);
-          state = kStIdle;
+          state = kStDone;
           advance = false;
         } else {
           sp--;
@@ -219,6 +224,7 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
       if (state != kStTri) D3 = g[3];
     }
   }
+  if (state >= kStDone) sink.done(tag, hit, state == kStDoneOccluded);  // rays that finished after the queue ran dry
 }
 
 }  // namespace pb
