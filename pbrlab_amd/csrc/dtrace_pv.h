@@ -24,9 +24,21 @@ constexpr uint32_t kPvBatch = 512;        // rays grabbed per atomicAdd
 #endif
 constexpr int kPvLdsStack = PB_LDS_STACK;  // stack entries per lane kept in LDS
 #ifndef PB_REFILL
-#define PB_REFILL 24
+#define PB_REFILL 32
 #endif
 constexpr int kPvRefillIdle = PB_REFILL;         // refill when at least this many lanes are idle
+// Weights of one lane in the phase vote.  Measured on C2 (A/B, k_trace ms per frame): node:tri = 2:1 64.1, 1:1 60.9,
+// 3:4 59.0, 1:2 57.9, 1:3 58.0 -- primitives first: a lane parked at a leaf holds a shorter tmax for its own later box
+// tests and returns to the (much more frequent) node phase, so the node phase runs with more lanes.
+#ifndef PB_W_NODE
+#define PB_W_NODE 1
+#endif
+#ifndef PB_W_TRI
+#define PB_W_TRI 2
+#endif
+#ifndef PB_W_CURVE
+#define PB_W_CURVE 1
+#endif
 
 // kStDone / kStDoneOccluded: the ray is finished, its result still sits in the lane's registers.  Results are delivered
 // (sink.done: a store, or a read-modify-write of the path's radiance) together, at the next refill, instead of by the one
@@ -135,7 +147,9 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
       unsigned long long tri_mask = __ballot(state == kStTri);
       int n_node = __popcll(node_mask), n_tri = __popcll(tri_mask);
       int n_curve = CURVES ? (64 - n_idle - n_node - n_tri) : 0;
-      const int phase = (n_node >= n_tri && n_node >= n_curve) ? 0 : ((!CURVES || n_tri >= n_curve) ? 1 : 2);
+      // vote: the phase that advances the most lanes per instruction issued (a node step is cheaper than a primitive step)
+      const int w_node = n_node * PB_W_NODE, w_tri = n_tri * PB_W_TRI, w_curve = n_curve * PB_W_CURVE;
+      const int phase = (w_node >= w_tri && w_node >= w_curve) ? 0 : ((!CURVES || w_tri >= w_curve) ? 1 : 2);
       if (STATS && lane == 0) {
         if (phase == 0) st.it_node++, st.ln_node += n_node;
         else if (phase == 1) st.it_tri++, st.ln_tri += n_tri;
