@@ -194,7 +194,7 @@ def main():
                         "avg_launch_ms": ms_step / max(launches, 1), "launches_per_step": launches,
                         "rays_per_step": sst["closest_rays"] + sst["shadow_rays"],
                         "kernel_ms_per_step": {{"trace_closest": "trace", "surface": "classify"}.get(k[3:], k[3:]): agg[k] / args.steps
-                                               for k in agg if k.startswith("ms_") and k not in ("ms_total", "ms_trace_shadow")}}
+                                               for k in agg if k.startswith("ms_") and k not in ("ms_total",)}}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

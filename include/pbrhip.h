@@ -79,7 +79,8 @@ typedef struct {
   uint32_t max_paths_in_flight;       /* 0 = default (half of the free HBM, <= 256 Mi): passes are rendered in chunks of this many paths */
   uint32_t flags;                     /* PBRHIP_RENDER_* */
   uint32_t num_streams;               /* concurrent path groups, one HIP stream each (0 = default 1, max 8) */
-  uint32_t reserved;
+  uint32_t tail_paths;                /* once a group has at most this many live paths, the rest of every path runs in ONE launch
+                                         (k_tail) instead of one set of launches per bounce; 0 = default 65536, 0xFFFFFFFF = never */
 } pbrhip_render_desc;
 
 #define PBRHIP_RENDER_STATS 1u   /* count BVH nodes / primitives visited (slower; for algorithmic bytes) */
@@ -93,9 +94,10 @@ typedef struct {
   uint64_t shadow_rays, shadow_nodes, shadow_tris, shadow_curves;
   /* PBRHIP_RENDER_TIMING: total ms and launch count per kernel */
   double ms_generate, ms_trace_closest /* = k_trace: closest + shadow rays */, ms_surface /* = k_classify */, ms_shade_principled, ms_shade_hair, ms_sss_step,
-      ms_trace_shadow, ms_accumulate, ms_compact;
-  uint64_t n_trace_closest, n_trace_shadow, n_surface, n_shade_principled, n_shade_hair, n_sss_step;
+      ms_tail /* = k_tail */, ms_accumulate, ms_compact;
+  uint64_t n_trace_closest, n_tail, n_surface, n_shade_principled, n_shade_hair, n_sss_step;
   double ms_total; /* wall time of the call measured on the host */
+  uint64_t tail_closest_rays, tail_shadow_rays; /* PBRHIP_RENDER_STATS: rays traced inside k_tail (not part of the k_trace counts above) */
 } pbrhip_render_stats;
 
 const char* pbrhip_last_error(void);

@@ -43,7 +43,7 @@ class RenderDesc(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("num_sample", C.c_uint32),
                 ("first_pass", C.c_uint32), ("seed_seq", C.c_uint64), ("tile_rank", C.c_uint32),
                 ("tile_world", C.c_uint32), ("max_paths_in_flight", C.c_uint32), ("flags", C.c_uint32),
-                ("num_streams", C.c_uint32), ("reserved", C.c_uint32)]
+                ("num_streams", C.c_uint32), ("tail_paths", C.c_uint32)]
 
 
 class RenderStats(C.Structure):
@@ -51,9 +51,10 @@ class RenderStats(C.Structure):
                                            "closest_tris", "closest_curves", "shadow_rays", "shadow_nodes",
                                            "shadow_tris", "shadow_curves")] +
                 [(n, C.c_double) for n in ("ms_generate", "ms_trace_closest", "ms_surface", "ms_shade_principled",
-                                           "ms_shade_hair", "ms_sss_step", "ms_trace_shadow", "ms_accumulate", "ms_compact")] +
-                [(n, C.c_uint64) for n in ("n_trace_closest", "n_trace_shadow", "n_surface", "n_shade_principled",
-                                           "n_shade_hair", "n_sss_step")] + [("ms_total", C.c_double)])
+                                           "ms_shade_hair", "ms_sss_step", "ms_tail", "ms_accumulate", "ms_compact")] +
+                [(n, C.c_uint64) for n in ("n_trace_closest", "n_tail", "n_surface", "n_shade_principled",
+                                           "n_shade_hair", "n_sss_step")] + [("ms_total", C.c_double)] +
+                [(n, C.c_uint64) for n in ("tail_closest_rays", "tail_shadow_rays")])
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -269,7 +270,7 @@ class Scene:
 
 def Render(scene, width, height, num_sample, cancel_render_flag=None, layer=None, finish_pass=None, *,
            first_pass=0, seed_seq=1234567890, tile_rank=0, tile_world=1, max_paths_in_flight=0, flags=0,
-           device_out=None, num_streams=0):
+           device_out=None, num_streams=0, tail_paths=0):
     """pbrlab::Render (src/render.h:14-17).  Resizes and clears `layer`, renders `num_sample` passes, and
     returns (True, stats) -- the reference always returns true (render.cc:240).
 
@@ -279,7 +280,7 @@ def Render(scene, width, height, num_sample, cancel_render_flag=None, layer=None
     nothing is copied to the host (used with torch tensors + RCCL reduce)."""
     L = _lib.lib()
     desc = RenderDesc(width, height, num_sample, first_pass, seed_seq, tile_rank, tile_world, max_paths_in_flight,
-                      flags, num_streams, 0)
+                      flags, num_streams, tail_paths)
     st = RenderStats()
     fin = finish_pass if finish_pass is not None else C.c_size_t(0)
     cancel = C.byref(cancel_render_flag) if cancel_render_flag is not None else None

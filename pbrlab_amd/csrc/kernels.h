@@ -42,7 +42,8 @@ enum : uint32_t {
 enum : uint32_t {
   kStatClosestRays = 0, kStatClosestNodes, kStatClosestTris, kStatClosestCurves,
   kStatShadowRays, kStatShadowNodes, kStatShadowTris, kStatShadowCurves,
-  kStatPvItNode, kStatPvItTri, kStatPvItCurve, kStatPvItRefill, kStatPvLnNode, kStatPvLnTri, kStatPvLnCurve, kStatNum
+  kStatPvItNode, kStatPvItTri, kStatPvItCurve, kStatPvItRefill, kStatPvLnNode, kStatPvLnTri, kStatPvLnCurve,
+  kStatTailClosestRays, kStatTailShadowRays, kStatNum
 };
 
 #ifndef PB_TRACE_BLOCKS
@@ -62,6 +63,7 @@ struct HookHit {  // == pbrhip_hit == TraceResult (raytracer.h:9-17)
 void launch_generate(hipStream_t s, const PathState& P, const Camera& cam, const uint32_t* pix_index, uint32_t npix,
                      uint32_t npaths, uint32_t slot0, uint32_t width, uint32_t first_pass, uint64_t seed_seq);
 void launch_trace(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, bool stats);
+void launch_tail(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc, bool stats);
 void launch_classify(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper);
 void launch_compact(hipStream_t s, const PathState& P, uint32_t n_upper);
 void launch_shade_principled(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc);

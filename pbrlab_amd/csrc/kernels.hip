@@ -316,12 +316,10 @@ __device__ __forceinline__ void put_shadow(const PathState& P, V3 pos, const Nee
 
 // ------------------------------------------------------------------ k_shade_principled
 // CyclesPrincipledShader (cycles-principled-shader.cc:414-484) + the tail of GetRadiance (render.cc:76-87).
-__global__ __launch_bounds__(kBlock) void k_shade_principled(PathState P, DScene sc, uint64_t rng_inc) {
-  const uint32_t n = P.counts[kCntPrincipled];
-  const uint32_t n_round = (n + kBlock - 1) / kBlock * kBlock;
-  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_round; i += gridDim.x * kBlock) {
-    bool active = i < n;
-    uint32_t p = active ? P.q_principled[i] : 0u;
+// One path; returns the result bits (kRShadow | kRAlive | kQSssBit) its caller stores or acts on.
+__device__ __forceinline__ uint32_t shade_principled_path(const PathState& P, const DScene& sc, uint32_t p, uint64_t rng_inc) {
+  {
+    const bool active = true;
     bool alive = false, shadow = false;
     V3 sh_pos(0.f), c_vis(0.f);
     Nee nee;
@@ -450,17 +448,21 @@ __global__ __launch_bounds__(kBlock) void k_shade_principled(PathState P, DScene
       }
     }
     if (shadow) put_shadow(P, sh_pos, nee, c_vis, V3(0.f), p, sh_mode);
-    if (active) P.q_principled[i] = p | (shadow ? kRShadow : 0u) | (alive ? kRAlive : 0u) | qbit;
+    return (shadow ? kRShadow : 0u) | (alive ? kRAlive : 0u) | qbit;
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_shade_principled(PathState P, DScene sc, uint64_t rng_inc) {
+  const uint32_t n = P.counts[kCntPrincipled];
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const uint32_t p = P.q_principled[i];
+    P.q_principled[i] = p | shade_principled_path(P, sc, p, rng_inc);
   }
 }
 
 // ------------------------------------------------------------------ k_shade_hair (hair-shader.cc:153-229)
-__global__ __launch_bounds__(kBlock) void k_shade_hair(PathState P, DScene sc, uint64_t rng_inc) {
-  const uint32_t n = P.counts[kCntHair];
-  const uint32_t n_round = (n + kBlock - 1) / kBlock * kBlock;
-  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_round; i += gridDim.x * kBlock) {
-    bool active = i < n;
-    uint32_t p = active ? P.q_hair[i] : 0u;
+__device__ __forceinline__ uint32_t shade_hair_path(const PathState& P, const DScene& sc, uint32_t p, uint64_t rng_inc) {
+  {
+    const bool active = true;
     bool alive = false, shadow = false;
     V3 sh_pos(0.f), c_vis(0.f);
     Nee nee;
@@ -515,7 +517,14 @@ __global__ __launch_bounds__(kBlock) void k_shade_hair(PathState P, DScene sc, u
       }
     }
     if (shadow) put_shadow(P, sh_pos, nee, c_vis, V3(0.f), p, kShNormal);
-    if (active) P.q_hair[i] = p | (shadow ? kRShadow : 0u) | (alive ? kRAlive : 0u);
+    return (shadow ? kRShadow : 0u) | (alive ? kRAlive : 0u);
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_shade_hair(PathState P, DScene sc, uint64_t rng_inc) {
+  const uint32_t n = P.counts[kCntHair];
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const uint32_t p = P.q_hair[i];
+    P.q_hair[i] = p | shade_hair_path(P, sc, p, rng_inc);
   }
 }
 
@@ -523,12 +532,9 @@ __global__ __launch_bounds__(kBlock) void k_shade_hair(PathState P, DScene sc, u
 // One iteration of RandomWalkSubsurface's loop after its TraceFirstHit1 (random-walk-sss.h:314-405),
 // then either the next step's direction/distance sampling (:287-311) or the exit: second NEE + diffuse
 // re-sample (cycles-principled-shader.cc:197-216) and the tail of CyclesPrincipledShader (:467-483).
-__global__ __launch_bounds__(kBlock) void k_sss_step(PathState P, DScene sc, uint64_t rng_inc) {
-  const uint32_t n = P.counts[kCntSss];
-  const uint32_t n_round = (n + kBlock - 1) / kBlock * kBlock;
-  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_round; i += gridDim.x * kBlock) {
-    bool active = i < n;
-    uint32_t p = active ? P.q_sss[i] : 0u;
+__device__ __forceinline__ uint32_t sss_step_path(const PathState& P, const DScene& sc, uint32_t p, uint64_t rng_inc) {
+  {
+    const bool active = true;
     bool alive = false, shadow = false;
     uint32_t qbit = 0u;
     V3 sh_pos(0.f), c_vis(0.f), c_occ(0.f);
@@ -653,7 +659,74 @@ __global__ __launch_bounds__(kBlock) void k_sss_step(PathState P, DScene sc, uin
       }
     }
     if (shadow) put_shadow(P, sh_pos, nee, c_vis, c_occ, p, kShSssExit);
-    if (active) P.q_sss[i] = p | (shadow ? kRShadow : 0u) | (alive ? kRAlive : 0u) | qbit;
+    return (shadow ? kRShadow : 0u) | (alive ? kRAlive : 0u) | qbit;
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_sss_step(PathState P, DScene sc, uint64_t rng_inc) {
+  const uint32_t n = P.counts[kCntSss];
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const uint32_t p = P.q_sss[i];
+    P.q_sss[i] = p | sss_step_path(P, sc, p, rng_inc);
+  }
+}
+
+// ------------------------------------------------------------------ k_tail
+// The tail of a chunk -- few live paths, many bounces left -- is bound by latency, not throughput: every wavefront
+// iteration costs ~0.2 ms of launches and drains however few paths it moves (91 iterations on C2, 70 of them with
+// < 64 Ki paths).  Below pbrhip_render_desc.tail_paths live paths the remaining bounces of every path therefore run in
+// ONE launch: a lane owns a path and loops  shade -> (its shadow ray, resolved at once) -> closest-hit trace  until the
+// path ends, calling the very functions the wavefront kernels call, in the order the wavefront applies them to that
+// path (the shadow ray of bounce k is resolved before anything of bounce k+1 touches L), so results are unchanged.
+// Input: q_in = the paths just traced by k_trace (their hit records are in P.hit).  Traversal is the plain per-lane
+// one (dtrace.h::traverse): with a handful of lanes per wave there is nothing to vote on.
+template <bool CURVES, bool STATS>
+__global__ __launch_bounds__(kBlock) void k_tail(PathState P, DScene sc, uint64_t rng_inc) {
+  __shared__ uint32_t stk[kStackDepth * kBlock];
+  const uint32_t n = P.counts[kCntIn];
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, nwaves = gridDim.x * (kBlock >> 6);
+  uint32_t per_wave = (n + nwaves - 1u) / nwaves;  // spread thin: every SIMD busy, little divergence per wave
+  per_wave = per_wave < 1u ? 1u : (per_wave > 64u ? 64u : per_wave);
+  TravStats st = {};
+  uint32_t overflow = 0u, n_closest = 0u, n_shadow = 0u;  // rays traced here (STATS)
+  const TraceSink sink = {P, 0u};
+  uint32_t* const stack = stk + threadIdx.x;
+  for (uint32_t base = wave * per_wave; base < n; base += nwaves * per_wave) {
+    const uint32_t i = base + lane;
+    if (lane >= per_wave || i >= n) continue;
+    const uint32_t e = P.q_in[i];
+    const uint32_t p = e & kQPathMask;
+    bool in_medium = (e & kQSssBit) != 0u;
+    for (;;) {
+      uint32_t r;
+      if (in_medium) {
+        r = sss_step_path(P, sc, p, rng_inc);
+      } else {
+        const uint32_t slot = __float_as_uint(P.hit[p].w);
+        if (slot == kNone) break;  // miss: the path ends (render.cc:34)
+        r = (sc.shade[slot].flags & kSlotMatHair) ? shade_hair_path(P, sc, p, rng_inc) : shade_principled_path(P, sc, p, rng_inc);
+      }
+      if (r & kRShadow) {
+        const float4 o4 = P.sh_o[p], d4 = P.sh_d[p];
+        Hit h;
+        const bool occluded = traverse<true, false, CURVES>(sc, ld3(o4), ld3(d4), o4.w, d4.w, h, stack, kBlock, st, &overflow);
+        sink.done(p | 0x80000000u, h, occluded);
+        n_shadow++;
+      }
+      if (!(r & kRAlive)) break;
+      in_medium = (r & kQSssBit) != 0u;
+      const float4 o4 = P.ray_o[p], d4 = P.ray_d[p];
+      Hit h;
+      traverse<false, false, CURVES>(sc, ld3(o4), ld3(d4), o4.w, d4.w, h, stack, kBlock, st, &overflow);
+      P.hit[p] = make_float4(h.t, h.u, h.v, __uint_as_float(h.slot));
+      n_closest++;
+    }
+  }
+  if (overflow) P.counts[kCntOverflow] = 1u;
+  if (STATS) {
+    const uint32_t a = wave_sum(n_closest), b = wave_sum(n_shadow);
+    if (lane == 0 && a) atomicAdd(&P.stats[kStatTailClosestRays], (unsigned long long)a);
+    if (lane == 0 && b) atomicAdd(&P.stats[kStatTailShadowRays], (unsigned long long)b);
   }
 }
 
@@ -803,6 +876,15 @@ void launch_sss_step(hipStream_t s, const PathState& P, const DScene& sc, uint32
 void launch_accumulate(hipStream_t s, const PathState& P, const uint32_t* pix_index, uint32_t npix, uint32_t npass,
                        float* rgba, uint32_t* count) {
   hipLaunchKernelGGL(k_accumulate, dim3(grid_for(npix, 8192)), dim3(kBlock), 0, s, P, pix_index, npix, npass, rgba, count);
+}
+void launch_tail(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc, bool stats) {
+  uint32_t blocks = (n_upper + 3u) / 4u;  // one path per wave while that fits, at most 2 blocks per CU
+  dim3 g(blocks < 1u ? 1u : (blocks < 512u ? blocks : 512u));
+  const bool curves = sc.num_curves != 0;
+  if (stats && curves) hipLaunchKernelGGL((k_tail<true, true>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
+  else if (stats) hipLaunchKernelGGL((k_tail<false, true>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
+  else if (curves) hipLaunchKernelGGL((k_tail<true, false>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
+  else hipLaunchKernelGGL((k_tail<false, false>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
 }
 void launch_advance(hipStream_t s, const PathState& P) { hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, s, P.counts); }
 // counts: kCntNum zeroed words (queue head + overflow flag); spill: traversal-stack spill area

@@ -845,6 +845,8 @@ static int render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volat
     // its own queues, counters and HIP stream.  Every wavefront iteration ends in a latency-bound drain (the
     // slowest ray's dependent-load chain: 0.1-0.4 ms with the GPU almost idle); with several groups in flight
     // one group's drain overlaps the others' bulk work.  Path slots stay global, so results are unchanged.
+    uint32_t tail_paths = d->tail_paths == 0xFFFFFFFFu ? 0u : (d->tail_paths ? d->tail_paths : 65536u);
+    if (const char* e = getenv("PBRHIP_TAIL_PATHS")) tail_paths = (uint32_t)strtoul(e, nullptr, 10);  // 0 = never
     uint32_t want_groups = d->num_streams ? d->num_streams : 1u;
     if (const char* e = getenv("PBRHIP_STREAMS")) want_groups = (uint32_t)atoi(e);
     want_groups = std::max(1u, std::min(want_groups, (uint32_t)kMaxGroups));
@@ -879,6 +881,19 @@ static int render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volat
         // are queued per host round trip (kernels read their counts on the device and fall through when empty).
         const int burst = gr.n < (1u << 18) ? 8 : 1;
         const uint32_t n = std::max(gr.n, 1u);
+        if (gr.n <= tail_paths) {
+          // few live paths: trace this bounce (and the pending shadow rays), then finish every path in one launch
+          HIPCHK(gr.tm.begin(&S.ms_trace_closest));
+          launch_trace(gr.st, gr.P, sc, 2 * n, want_stats);
+          HIPCHK(gr.tm.end());
+          HIPCHK(gr.tm.begin(&S.ms_tail));
+          launch_tail(gr.st, gr.P, sc, n, rng_inc, want_stats);
+          HIPCHK(gr.tm.end());
+          launch_advance(gr.st, gr.P);  // nothing was queued: both "in" counts become 0
+          S.n_trace_closest++, S.n_tail++, S.iterations++;
+          HIPCHK(hipMemcpyAsync(gr.h_counts, gr.P.counts, sizeof(uint32_t) * kCntNum, hipMemcpyDeviceToHost, gr.st));
+          return PBRHIP_OK;
+        }
         for (int it = 0; it < burst; it++) {
           HIPCHK(gr.tm.begin(&S.ms_trace_closest));
           launch_trace(gr.st, gr.P, sc, 2 * n, want_stats);  // this bounce's closest rays + last bounce's shadow rays
@@ -956,6 +971,7 @@ static int render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volat
       S.closest_rays = hs[kStatClosestRays], S.closest_nodes = hs[kStatClosestNodes];
       S.closest_tris = hs[kStatClosestTris], S.closest_curves = hs[kStatClosestCurves];
       S.shadow_rays = hs[kStatShadowRays], S.shadow_nodes = hs[kStatShadowNodes];
+      S.tail_closest_rays = hs[kStatTailClosestRays], S.tail_shadow_rays = hs[kStatTailShadowRays];
       S.shadow_tris = hs[kStatShadowTris], S.shadow_curves = hs[kStatShadowCurves];
       if (getenv("PBRHIP_PV_STATS"))
         fprintf(stderr, "pv closest: it node %llu tri %llu curve %llu refill %llu | lanes/iter node %.1f tri %.1f curve %.1f\n",

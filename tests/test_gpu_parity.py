@@ -88,15 +88,19 @@ def test_trace_edge_cases(pa, pairs):
     assert_hits_equal(sg.trace_closest(z), so.trace_closest(z))
 
 
+# tail: 0xFFFFFFFF = every bounce goes through the wavefront kernels; 0 = default (these small frames switch to
+# k_tail right after the first trace); 3000 = a switch in the middle of the render
+@pytest.mark.parametrize("tail", [0xFFFFFFFF, 0, 3000])
 @pytest.mark.parametrize("name", ["lambert", "ggx", "sss", "hair", "textured"])
-def test_render_matches_oracle_and_fixture(pa, pairs, name):
+def test_render_matches_oracle_and_fixture(pa, pairs, name, tail):
     desc, sg, so = pairs[name]
     layer = pa.RenderLayer()
-    ok, st = pa.Render(sg, 64, 64, 4, layer=layer, flags=pa.api.RENDER_STATS)
+    ok, st = pa.Render(sg, 64, 64, 4, layer=layer, flags=pa.api.RENDER_STATS, tail_paths=tail)
+    assert (st["n_tail"] == 0) == (tail == 0xFFFFFFFF)
     assert ok is True and (layer.count == 4).all() and np.array_equal(layer.rgba[..., 3], np.full((64, 64), 4, np.float32))
     rgba, cnt, ost = so.render(64, 64, 4, threads=4, math_mode=O.MATH_F64R)
     ndiff, rel = image_check(layer.rgba, rgba)
-    assert (st["closest_rays"], st["shadow_rays"]) == (ost["closest_rays"], ost["shadow_rays"])
+    assert (st["closest_rays"] + st["tail_closest_rays"], st["shadow_rays"] + st["tail_shadow_rays"]) == (ost["closest_rays"], ost["shadow_rays"])
     fx = np.load(os.path.join(G, "oracle_images.npz"))
     image_check(layer.rgba, fx[f"{name}_f64r_rgba"])
     # against the reference's libm arithmetic: tolerance only
@@ -109,7 +113,7 @@ def test_render_odd_size_and_larger(pa, pairs):
     desc, sg, so = pairs["sss"]
     for (w, h, spp) in [(130, 70, 3), (1, 1, 5), (65, 63, 2), (200, 150, 6)]:
         layer = pa.RenderLayer()
-        pa.Render(sg, w, h, spp, layer=layer)
+        pa.Render(sg, w, h, spp, layer=layer, tail_paths=0xFFFFFFFF if w == 130 else 0)
         rgba, cnt, _ = so.render(w, h, spp, threads=8, math_mode=O.MATH_F64R)
         assert np.array_equal(layer.count, cnt)
         image_check(layer.rgba, rgba)
