@@ -80,7 +80,7 @@ typedef struct {
   uint32_t flags;                     /* PBRHIP_RENDER_* */
   uint32_t num_streams;               /* concurrent path groups, one HIP stream each (0 = default 1, max 8) */
   uint32_t tail_paths;                /* once a group has at most this many live paths, the rest of every path runs in ONE launch
-                                         (k_tail) instead of one set of launches per bounce; 0 = default 65536, 0xFFFFFFFF = never */
+                                         (k_tail) instead of one set of launches per bounce; 0 = default 262144, 0xFFFFFFFF = never */
 } pbrhip_render_desc;
 
 #define PBRHIP_RENDER_STATS 1u   /* count BVH nodes / primitives visited (slower; for algorithmic bytes) */

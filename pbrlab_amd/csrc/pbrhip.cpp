@@ -845,7 +845,7 @@ static int render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volat
     // its own queues, counters and HIP stream.  Every wavefront iteration ends in a latency-bound drain (the
     // slowest ray's dependent-load chain: 0.1-0.4 ms with the GPU almost idle); with several groups in flight
     // one group's drain overlaps the others' bulk work.  Path slots stay global, so results are unchanged.
-    uint32_t tail_paths = d->tail_paths == 0xFFFFFFFFu ? 0u : (d->tail_paths ? d->tail_paths : 65536u);
+    uint32_t tail_paths = d->tail_paths == 0xFFFFFFFFu ? 0u : (d->tail_paths ? d->tail_paths : 262144u);
     if (const char* e = getenv("PBRHIP_TAIL_PATHS")) tail_paths = (uint32_t)strtoul(e, nullptr, 10);  // 0 = never
     uint32_t want_groups = d->num_streams ? d->num_streams : 1u;
     if (const char* e = getenv("PBRHIP_STREAMS")) want_groups = (uint32_t)atoi(e);
