@@ -28,8 +28,7 @@ __device__ __forceinline__ Surface make_surface(const DScene& sc, V3 org, V3 dir
   if (instance_id) *instance_id = __float_as_uint(r5.z);
   s.tu = 0.f, s.tv = 0.f;  // curves: (0,0) (scene.cc:243-245)
   if (s.flags & kSlotIsCurve) {
-    const float4* g = sc.slots + (size_t)h.slot * 4;
-    float4 cp[4] = {g[0], g[1], g[2], g[3]};
+    float4 cp[4] = {r0, r1, r2, r3};  // the cubic's control points (xyzr) live in words 0..15 of a curve piece's record
     s.n_g = normalize_raw(bezier_tangent(cp, h.u));
     s.n_s = s.n_g;  // scene.cc:222-223
   } else {

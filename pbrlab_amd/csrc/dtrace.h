@@ -46,14 +46,6 @@ __device__ __forceinline__ bool tri_test(V3 v0, V3 v1, V3 v2, V3 o, V3 d, float 
   return true;
 }
 
-__device__ __forceinline__ void bezier_eval(const float4 cp[4], float u, float out[4]) {
-  float s = 1.0f - u;
-  float b0 = s * s * s, b1 = 3.0f * u * s * s, b2 = 3.0f * u * u * s, b3 = u * u * u;
-  out[0] = ((cp[0].x * b0 + cp[1].x * b1) + cp[2].x * b2) + cp[3].x * b3;
-  out[1] = ((cp[0].y * b0 + cp[1].y * b1) + cp[2].y * b2) + cp[3].y * b3;
-  out[2] = ((cp[0].z * b0 + cp[1].z * b1) + cp[2].z * b2) + cp[3].z * b3;
-  out[3] = ((cp[0].w * b0 + cp[1].w * b1) + cp[2].w * b2) + cp[3].w * b3;
-}
 // dP/du of the cubic: what Embree reports as Ng for flat curves (hair-shader.cc:165-166 uses it as tangent)
 __device__ __forceinline__ V3 bezier_tangent(const float4 cp[4], float u) {
   float s = 1.0f - u;
@@ -62,41 +54,30 @@ __device__ __forceinline__ V3 bezier_tangent(const float4 cp[4], float u) {
   return (p1 - p0) * c0 + (p2 - p1) * c1 + (p3 - p2) * c2;
 }
 
-// Ray-facing flat ribbon, 4 linear sub-segments per cubic (RTC_GEOMETRY_TYPE_FLAT_BEZIER_CURVE,
-// raytracer_impl.cc:158-159): u = curve parameter, v in [-1,1] across the width.
-__device__ __forceinline__ bool curve_test(const float4 cp[4], V3 o, V3 d, float tmin, float tmax, float& t, float& u,
-                                           float& v) {
+// Ray-facing flat ribbon, 4 linear pieces per cubic (RTC_GEOMETRY_TYPE_FLAT_BEZIER_CURVE, raytracer_impl.cc:158-159);
+// every piece is its own traversal primitive: a = B(i/4), b = B((i+1)/4) (xyz + radius, evaluated at commit).
+// u = curve parameter, v in [-1,1] across the width.
+__device__ __forceinline__ bool segment_test(const float4& a, const float4& b, uint32_t i, V3 o, V3 d, float tmin, float tmax,
+                                             float& t, float& u, float& v) {
   float inv_len = 1.0f / sqrtf(dot(d, d));
   V3 dn = d * inv_len;
   V3 bx, by;
   branchless_onb(dn, bx, by);
-  float px[5], py[5], pz[5], pr[5];
-#pragma unroll
-  for (int i = 0; i < 5; i++) {
-    float c[4];
-    bezier_eval(cp, (float)i * 0.25f, c);
-    V3 rel = V3(c[0], c[1], c[2]) - o;
-    px[i] = dot(rel, bx), py[i] = dot(rel, by), pz[i] = dot(rel, dn), pr[i] = c[3];
-  }
-  bool found = false;
-  float best = tmax;
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    float ex = px[i + 1] - px[i], ey = py[i + 1] - py[i];
-    float len2 = ex * ex + ey * ey;
-    if (!(len2 > 0.0f)) continue;
-    float s = -(px[i] * ex + py[i] * ey) / len2;
-    if (!(s >= 0.0f && s <= 1.0f)) continue;
-    float dist = (ey * px[i] - ex * py[i]) / sqrtf(len2);
-    float r = pr[i] + s * (pr[i + 1] - pr[i]);
-    if (!(r > 0.0f && fabsf(dist) <= r)) continue;
-    float tt = (pz[i] + s * (pz[i + 1] - pz[i])) * inv_len;
-    if (!(tt > tmin)) continue;
-    if (found ? !(tt < best) : !(tt <= best)) continue;
-    best = tt, found = true;
-    t = tt, u = ((float)i + s) * 0.25f, v = dist / r;
-  }
-  return found;
+  V3 ra = V3(a.x, a.y, a.z) - o, rb = V3(b.x, b.y, b.z) - o;
+  float pxa = dot(ra, bx), pya = dot(ra, by), pza = dot(ra, dn);
+  float pxb = dot(rb, bx), pyb = dot(rb, by), pzb = dot(rb, dn);
+  float ex = pxb - pxa, ey = pyb - pya;
+  float len2 = ex * ex + ey * ey;
+  if (!(len2 > 0.0f)) return false;
+  float s = -(pxa * ex + pya * ey) / len2;
+  if (!(s >= 0.0f && s <= 1.0f)) return false;
+  float dist = (ey * pxa - ex * pya) / sqrtf(len2);
+  float r = a.w + s * (b.w - a.w);
+  if (!(r > 0.0f && fabsf(dist) <= r)) return false;
+  float tt = (pza + s * (pzb - pza)) * inv_len;
+  if (!(tt > tmin && tt <= tmax)) return false;
+  t = tt, u = ((float)i + s) * 0.25f, v = dist / r;
+  return true;
 }
 
 // Conservative slab test of BOTH children of a node against [tmin, tmax] (entry distances in t0, t1).  n0..n2 are the
@@ -139,9 +120,9 @@ __device__ __forceinline__ bool leaf_test(const DScene& sc, uint32_t leaf, V3 o,
       if (STATS) st.tris++;
       ok = tri_test(ld3(a), ld3(b), ld3(c), o, d, tmin, t, u, v) && (t <= best_t);
     } else {
-      float4 cp[4] = {g[0], g[1], g[2], g[3]};
+      float4 a = g[0], b = g[1], c = g[2];
       if (STATS) st.curves++;
-      ok = curve_test(cp, o, d, tmin, best_t, t, u, v);
+      ok = segment_test(a, b, __float_as_uint(c.x), o, d, tmin, best_t, t, u, v);
     }
     if (!ok) continue;
     if (ANY) return true;

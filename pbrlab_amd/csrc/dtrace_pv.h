@@ -191,8 +191,7 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
             ok = tri_test(ld3(D0), ld3(D1), ld3(D2), o, d, tmin, t, u, v) && (t <= best_t);
           } else {
             if (STATS) (any_ray ? st.acurves : st.curves)++;
-            float4 cp[4] = {D0, D1, D2, D3};
-            ok = curve_test(cp, o, d, tmin, best_t, t, u, v);
+            ok = segment_test(D0, D1, __float_as_uint(D2.x), o, d, tmin, best_t, t, u, v);
           }
           if (ok && !any_ray && t == best_t && hit.slot != kNone) ok = sc.shade[cur].gid < sc.shade[hit.slot].gid;
           if (ok) {
@@ -235,7 +234,7 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
     if (need_load) {
       const float4* g = (state == kStNode) ? reinterpret_cast<const float4*>(sc.nodes + cur) : (sc.slots + (size_t)cur * 4);
       D0 = g[0], D1 = g[1], D2 = g[2];
-      if (state != kStTri) D3 = g[3];
+      if (state == kStNode) D3 = g[3];
     }
   }
   if (state >= kStDone) sink.done(tag, hit, state == kStDoneOccluded);  // rays that finished after the queue ran dry

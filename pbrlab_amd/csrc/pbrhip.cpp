@@ -413,6 +413,19 @@ static Material make_material(const HostMaterial& hm) {
   return m;
 }
 
+// End points of linear piece `sub` of a cubic Bezier (control points xyzr): B(sub/4) and B((sub+1)/4), evaluated with
+// the arithmetic of the intersection contract (Bernstein weights, products summed left to right, single precision,
+// no contraction) so that every back end tests the same segment.
+static void bezier_point(const float* cp, float u, float out[4]) {
+  const float s = 1.0f - u;
+  const float b0 = s * s * s, b1 = 3.0f * u * s * s, b2 = 3.0f * u * u * s, b3 = u * u * u;
+  for (int k = 0; k < 4; k++) out[k] = ((cp[k] * b0 + cp[4 + k] * b1) + cp[8 + k] * b2) + cp[12 + k] * b3;
+}
+static void curve_piece(const float* cp, uint32_t sub, float a[4], float b[4]) {
+  bezier_point(cp, (float)sub * 0.25f, a);
+  bezier_point(cp, (float)(sub + 1) * 0.25f, b);
+}
+
 extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
   if (!s) return fail(PBRHIP_EINVAL, "scene is NULL");
   HIPCHK(hipSetDevice(s->device));
@@ -426,7 +439,8 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
       const HostMesh& m = *inst_mesh(s, i, g);
       if (s->instances[i].material_ids[g].size() != m.num_prims())
         return fail(PBRHIP_ESIZE, "material param error (instance %u geom %u)", i, g);
-      for (uint32_t p = 0; p < m.num_prims(); p++) prims.push_back({i, g, p, (uint32_t)m.kind});
+      for (uint32_t p = 0; p < m.num_prims(); p++)
+        for (uint32_t sub = 0; sub < (m.kind == 1 ? 4u : 1u); sub++) prims.push_back({i, g, p, (uint32_t)m.kind, sub});
     }
   uint32_t np = (uint32_t)prims.size();
   if (np >= (1u << 27)) return fail(PBRHIP_EUNSUPPORTED, "too many primitives (%u)", np);
@@ -446,18 +460,28 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
         for (int k = 0; k < 3; k++) l[k] = std::min(l[k], a[k]), h[k] = std::max(h[k], a[k]);
       }
     } else {
-      // convex hull of the control points widened by the largest control radius
-      float r = 0.f;
-      for (int c = 0; c < 4; c++) {
-        const float* cp = m.cverts.data() + ((size_t)m.cidx[pr.prim_id] + c) * 4;
-        r = std::max(r, fabsf(cp[3]));
-        for (int k = 0; k < 3; k++) l[k] = std::min(l[k], cp[k]), h[k] = std::max(h[k], cp[k]);
+      // scene bounds (they place the camera): convex hull of the control points widened by the largest control radius,
+      // per whole curve -- the intersection contract shared with the checker
+      const float* cps = m.cverts.data() + (size_t)m.cidx[pr.prim_id] * 4;
+      if (pr.sub == 0) {
+        float r = 0.f, cl[3] = {inf, inf, inf}, ch[3] = {-inf, -inf, -inf};
+        for (int c = 0; c < 4; c++) {
+          const float* cp = cps + c * 4;
+          r = std::max(r, fabsf(cp[3]));
+          for (int k = 0; k < 3; k++) cl[k] = std::min(cl[k], cp[k]), ch[k] = std::max(ch[k], cp[k]);
+        }
+        for (int k = 0; k < 3; k++) bmin[k] = std::min(bmin[k], cl[k] - r), bmax[k] = std::max(bmax[k], ch[k] + r);
       }
-      for (int k = 0; k < 3; k++) l[k] -= r, h[k] += r;
+      // BVH box of this piece: its two end points widened by the larger end radius (the ribbon between them never
+      // leaves that box, and a hit is reported at the depth of the axis point)
+      float a[4], b[4];
+      curve_piece(cps, pr.sub, a, b);
+      const float r = std::max(fabsf(a[3]), fabsf(b[3]));
+      for (int k = 0; k < 3; k++) l[k] = std::min(a[k], b[k]) - r, h[k] = std::max(a[k], b[k]) + r;
     }
     for (int k = 0; k < 3; k++) {
       lo[3 * g + k] = l[k], hi[3 * g + k] = h[k];
-      bmin[k] = std::min(bmin[k], l[k]), bmax[k] = std::max(bmax[k], h[k]);
+      if (pr.kind == 0) bmin[k] = std::min(bmin[k], l[k]), bmax[k] = std::max(bmax[k], h[k]);
     }
   }
   memcpy(s->bmin, bmin, sizeof(bmin));
@@ -547,10 +571,15 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
       }
     } else {
       flags |= kSlotIsCurve;
-      for (int c = 0; c < 4; c++) {
-        const float* cp = m.cverts.data() + ((size_t)m.cidx[pr.prim_id] + c) * 4;
-        sl[c] = make_float4(cp[0], cp[1], cp[2], cp[3]);
-      }
+      const float* cps = m.cverts.data() + (size_t)m.cidx[pr.prim_id] * 4;
+      float a[4], b[4];
+      curve_piece(cps, pr.sub, a, b);
+      sl[0] = make_float4(a[0], a[1], a[2], a[3]);
+      sl[1] = make_float4(b[0], b[1], b[2], b[3]);
+      sl[2] = make_float4(__builtin_bit_cast(float, pr.sub), 0.f, 0.f, 0.f);
+      // shading needs the cubic itself (tangent = dP/du at the hit): control points xyzr in words 0..15 of the record
+      float* w = reinterpret_cast<float*>(&sr);
+      for (int c = 0; c < 16; c++) w[c] = cps[c];
     }
     sr.gid = g, sr.material = mat, sr.lightrec = lightrec, sr.flags = flags;
     sr.instance_id = pr.instance_id, sr.geom_id = pr.geom_id, sr.prim_id = pr.prim_id;
