@@ -149,6 +149,14 @@ int pbrhip_scene_attach_material_ids(pbrhip_scene*, uint32_t instance_id, uint32
  * light-manager.cc:29-184), BVH build + flatten (replaces Embree's rtcCommitScene, raytracer_impl.cc:93-197),
  * upload to HBM, scene bounds (rtcGetSceneBounds, raytracer_impl.cc:199-211) */
 int pbrhip_scene_commit(pbrhip_scene*);
+/* Which builder pbrhip_scene_commit uses for the acceleration structure (the reference has one: Embree's, behind
+ * rtcCommitScene, raytracer_impl.cc:136-147,181-192).  HOST_SAH (default): binned SAH on the host cores, the best tree.
+ * GPU_LBVH: Morton-order linear BVH built on the GPU -- commit in milliseconds for edit -> re-render loops and
+ * multi-million-primitive hair, at a higher traversal cost.  Rendered images do not depend on the choice.
+ * Call before pbrhip_scene_commit.  (Environment override: PBRHIP_BVH=gpu|host.) */
+#define PBRHIP_BVH_HOST_SAH 0
+#define PBRHIP_BVH_GPU_LBVH 1
+int pbrhip_scene_set_bvh_builder(pbrhip_scene*, int builder);
 /* Scene::FetchSceneAABB (scene.cc:251-259) */
 int pbrhip_scene_aabb(const pbrhip_scene*, float bmin[3], float bmax[3]);
 /* Scene::FetchMeshMaterialParameters + EditQueue edits between renders (pc/pc-common.cc:57-84): replace one

@@ -15,7 +15,7 @@ EXPORTS = [
     "pbrhip_scene_add_triangle_mesh", "pbrhip_scene_add_curve_mesh", "pbrhip_scene_add_principled_material",
     "pbrhip_scene_add_hair_material", "pbrhip_scene_add_texture", "pbrhip_scene_add_area_light", "pbrhip_scene_create_local_scene",
     "pbrhip_scene_add_mesh_to_local_scene", "pbrhip_scene_create_instance", "pbrhip_scene_attach_light_ids",
-    "pbrhip_scene_attach_material_ids", "pbrhip_scene_commit", "pbrhip_scene_aabb",
+    "pbrhip_scene_attach_material_ids", "pbrhip_scene_commit", "pbrhip_scene_set_bvh_builder", "pbrhip_scene_aabb",
     "pbrhip_scene_update_principled_material", "pbrhip_scene_update_hair_material", "pbrhip_scene_info",
     "pbrhip_render", "pbrhip_render_device", "pbrhip_trace_closest", "pbrhip_trace_any", "pbrhip_create_tiles",
 ]

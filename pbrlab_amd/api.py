@@ -46,6 +46,9 @@ class RenderDesc(C.Structure):
                 ("num_streams", C.c_uint32), ("tail_paths", C.c_uint32)]
 
 
+BVH_HOST_SAH, BVH_GPU_LBVH = 0, 1
+
+
 class RenderStats(C.Structure):
     _fields_ = ([(n, C.c_uint64) for n in ("samples", "iterations", "chunks", "closest_rays", "closest_nodes",
                                            "closest_tris", "closest_curves", "shadow_rays", "shadow_nodes",
@@ -241,6 +244,10 @@ class Scene:
     def CommitScene(self):
         _chk(self.L.pbrhip_scene_commit(self.h))
 
+    def SetBvhBuilder(self, builder):
+        """BVH_HOST_SAH (default) or BVH_GPU_LBVH; before CommitScene (pbrhip_scene_set_bvh_builder)"""
+        _chk(self.L.pbrhip_scene_set_bvh_builder(self.h, int(builder)))
+
     def FetchSceneAABB(self):
         lo, hi = np.zeros(3, np.float32), np.zeros(3, np.float32)
         _chk(self.L.pbrhip_scene_aabb(self.h, _ptr(lo), _ptr(hi)))
@@ -297,8 +304,10 @@ def Render(scene, width, height, num_sample, cancel_render_flag=None, layer=None
     return True, st.as_dict()
 
 
-def scene_from_desc(desc):
+def scene_from_desc(desc, bvh_builder=BVH_HOST_SAH):
     from . import scenes
     s = Scene()
+    if bvh_builder != BVH_HOST_SAH:
+        s.SetBvhBuilder(bvh_builder)
     scenes.build_scene(s, desc, make_principled, make_hair)
     return s

@@ -70,4 +70,10 @@ struct FlatBvh {
 void build_bvh(const std::vector<float>& lo, const std::vector<float>& hi, const std::vector<uint8_t>& kinds,
                FlatBvh* out);
 
+// The same tree format built on the GPU (bvh_gpu.hip: Morton-order linear BVH).  nodes_out: DEVICE array of
+// max(n - 1, 1) nodes; order_out: slot -> primitive index; depth_out: traversal stack depth needed.
+hipError_t build_bvh_gpu(hipStream_t st, const std::vector<float>& lo, const std::vector<float>& hi,
+                         const std::vector<uint8_t>& kinds, BvhNode* nodes_out, std::vector<uint32_t>* order_out,
+                         uint32_t* depth_out);
+
 }  // namespace pb

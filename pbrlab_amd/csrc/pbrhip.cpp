@@ -109,6 +109,8 @@ struct pbrhip_scene {
   bool committed = false, has_hair = false, has_sss = false;
   float bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0};
   uint32_t bvh_depth = 0;
+  int bvh_builder = PBRHIP_BVH_HOST_SAH;
+  bool bvh_built_on_gpu = false;
   // device scene
   DevBuf<BvhNode> d_nodes;
   DevBuf<float4> d_slots;
@@ -488,7 +490,27 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
   memcpy(s->bmax, bmax, sizeof(bmax));
 
   FlatBvh bvh;
-  build_bvh(lo, hi, kinds, &bvh);
+  bool gpu_built = false;
+  uint32_t num_nodes = 0;
+  int builder = s->bvh_builder;
+  if (const char* e = getenv("PBRHIP_BVH")) builder = (strcmp(e, "gpu") == 0) ? PBRHIP_BVH_GPU_LBVH : PBRHIP_BVH_HOST_SAH;
+  if (builder == PBRHIP_BVH_GPU_LBVH && np > 0) {
+    HIPCHK(s->d_nodes.reserve(std::max<size_t>(np > 1 ? np - 1 : 1, 1)));
+    HIPCHK(build_bvh_gpu(s->stream, lo, hi, kinds, s->d_nodes.p, &bvh.slot_gid, &bvh.depth));
+    if (bvh.depth > (uint32_t)kStackDepth) {
+      // a Morton-order tree over badly distributed primitives can be deeper than the traversal stack: use the SAH tree
+      fprintf(stderr, "pbrhip: GPU-built BVH is %u deep (stack %d): building on the host instead\n", bvh.depth, kStackDepth);
+      bvh = FlatBvh();
+    } else {
+      gpu_built = true;
+      num_nodes = np > 1 ? np - 1 : 1;
+    }
+  }
+  if (!gpu_built) {
+    build_bvh(lo, hi, kinds, &bvh);
+    num_nodes = (uint32_t)bvh.nodes.size();
+  }
+  s->bvh_built_on_gpu = gpu_built;
   if (bvh.depth > (uint32_t)kStackDepth)
     return fail(PBRHIP_EOVERFLOW, "BVH depth %u exceeds the traversal stack (%d)", bvh.depth, kStackDepth);
   s->bvh_depth = bvh.depth;
@@ -598,7 +620,7 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
   }
 
   hipStream_t st = s->stream;
-  HIPCHK(s->d_nodes.upload(bvh.nodes, st));
+  if (!gpu_built) HIPCHK(s->d_nodes.upload(bvh.nodes, st));
   HIPCHK(s->d_slots.upload(slots, st));
   HIPCHK(s->d_shade.upload(shade, st));
   HIPCHK(s->d_materials.upload(mats, st));
@@ -613,12 +635,20 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
   d.nodes = s->d_nodes.p, d.slots = s->d_slots.p, d.shade = s->d_shade.p;
   d.materials = s->d_materials.p, d.light_cdf = s->d_light_cdf.p;
   d.light_heads = s->d_heads.p, d.lprim_cdf = s->d_lprim_cdf.p, d.lrecs = s->d_lrecs.p;
-  d.num_nodes = (uint32_t)bvh.nodes.size(), d.num_slots = ns, d.num_lights = (uint32_t)s->lights.size();
+  d.num_nodes = num_nodes, d.num_slots = ns, d.num_lights = (uint32_t)s->lights.size();
   d.num_materials = (uint32_t)mats.size();
   d.tex_pixels = s->d_tex_pixels.p, d.textures = s->d_tex_descs.p, d.num_textures = (uint32_t)s->tex_descs.size();
   d.num_curves = 0;
   for (uint8_t kd : kinds) d.num_curves += kd ? 1u : 0u;
   s->committed = true;
+  return PBRHIP_OK;
+}
+
+extern "C" int pbrhip_scene_set_bvh_builder(pbrhip_scene* s, int builder) {
+  if (!s) return fail(PBRHIP_EINVAL, "scene is NULL");
+  if (builder != PBRHIP_BVH_HOST_SAH && builder != PBRHIP_BVH_GPU_LBVH) return fail(PBRHIP_EINVAL, "unknown BVH builder %d", builder);
+  if (s->committed) return fail(PBRHIP_ESTATE, "scene already committed");
+  s->bvh_builder = builder;
   return PBRHIP_OK;
 }
 

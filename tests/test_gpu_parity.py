@@ -232,3 +232,55 @@ def test_full_size_properties(pa):
             rad, _, _, _ = so.sample_trace(W, H, x, y, p, math_mode=O.MATH_F64R)
             tot = tot + rad
         assert np.array_equal(tot.view(np.uint32), a.rgba[y, x, :3].view(np.uint32)), (x, y)
+
+
+@pytest.mark.parametrize("name", ["lambert", "sss", "hair", "textured"])
+def test_gpu_built_bvh_gives_identical_results(pa, pairs, name):
+    """Row N3: the acceleration structure built on the GPU (Morton-order linear BVH).  Hits, and therefore images, do not
+    depend on the tree: everything must equal the oracle (and the host-SAH scene) bit for bit."""
+    from pbrlab_amd import scenes
+    desc, sg, so = pairs[name]
+    s2 = pa.scene_from_desc(desc, bvh_builder=pa.api.BVH_GPU_LBVH)
+    i1, i2 = sg.info(), s2.info()
+    assert i2["num_slots"] == i1["num_slots"] and i2["num_nodes"] == max(i2["num_slots"] - 1, 1)
+    assert 1 <= i2["depth"] <= 40
+    lo, hi = so.FetchSceneAABB()
+    glo, ghi = s2.FetchSceneAABB()
+    assert np.array_equal(np.asarray(lo, np.float32), glo) and np.array_equal(np.asarray(hi, np.float32), ghi)
+    rays = scenes.random_rays((lo, hi), 20000, seed=5)
+    assert_hits_equal(s2.trace_closest(rays), so.trace_closest(rays))
+    assert np.array_equal(s2.trace_any(rays), so.trace_any(rays))
+    for tail in (0, 0xFFFFFFFF):
+        layer = pa.RenderLayer()
+        pa.Render(s2, 64, 64, 4, layer=layer, tail_paths=tail)
+        rgba, cnt, _ = so.render(64, 64, 4, threads=4, math_mode=O.MATH_F64R)
+        assert np.array_equal(layer.count, cnt)
+        assert np.array_equal(layer.rgba.view(np.uint32), rgba.view(np.uint32))
+
+
+def test_gpu_bvh_builder_errors_and_tiny_scenes(pa):
+    s = pa.Scene()
+    with pytest.raises(pa.PbrHipError):
+        s.SetBvhBuilder(7)
+    # one triangle, two triangles: degenerate hierarchies
+    for ntri in (1, 2, 3):
+        s = pa.Scene()
+        s.SetBvhBuilder(pa.api.BVH_GPU_LBVH)
+        v = np.array([[0, 0, 0, 1], [1, 0, 0, 1], [0, 1, 0, 1], [1, 1, 0.5, 1], [2, 0, 1, 1]], np.float32)
+        f = np.array([[0, 1, 2], [1, 3, 2], [1, 4, 3]], np.uint32)[:ntri]
+        m = s.AddMaterialParam(pa.make_principled(dict(base_color=(0.8, 0.8, 0.8), subsurface=0.0, subsurface_radius=(1, 1, 1), subsurface_color=(0.7, 0.1, 0.1), metallic=0.0, specular=0.5, specular_tint=0.0, roughness=0.5, anisotropic=0.0, anisotropic_rotation=0.0, sheen=0.0, sheen_tint=0.5, clearcoat=0.0, clearcoat_roughness=0.03, ior=1.45, transmission=0.0, transmission_roughness=0.0, base_color_tex_id=0xFFFFFFFF, subsurface_color_tex_id=0xFFFFFFFF)))
+        mesh = s.AddTriangleMesh(v, None, None, f, None, None, np.full(ntri, m, np.uint32))
+        ls = s.CreateLocalScene()
+        s.AddMeshToLocalScene(ls, mesh)
+        s.CreateInstance(ls, None)
+        s.CommitScene()
+        rays = np.zeros(ntri, pa.api.RAY_DT)
+        for k in range(ntri):
+            c = v[f[k], :3].mean(axis=0)
+            rays[k]["org"] = c + np.array([0, 0, 5], np.float32)
+            rays[k]["dir"] = (0, 0, -1)
+            rays[k]["tmin"], rays[k]["tmax"] = 0.0, 100.0
+        h = s.trace_closest(rays)
+        assert list(h["prim_id"]) == list(range(ntri))
+        with pytest.raises(pa.PbrHipError):
+            s.SetBvhBuilder(pa.api.BVH_HOST_SAH)     # after commit
