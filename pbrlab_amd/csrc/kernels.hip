@@ -877,9 +877,12 @@ void launch_accumulate(hipStream_t s, const PathState& P, const uint32_t* pix_in
                        float* rgba, uint32_t* count) {
   hipLaunchKernelGGL(k_accumulate, dim3(grid_for(npix, 8192)), dim3(kBlock), 0, s, P, pix_index, npix, npass, rgba, count);
 }
+#ifndef PB_TAIL_BLOCKS
+#define PB_TAIL_BLOCKS 768u  // 3 blocks per CU (40 KB LDS stack each); A/B on C2: 256 -> 6.4 ms, 512 -> 5.4, 768 -> 4.8, 1024 -> 5.5
+#endif
 void launch_tail(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc, bool stats) {
   uint32_t blocks = (n_upper + 3u) / 4u;  // one path per wave while that fits, at most 2 blocks per CU
-  dim3 g(blocks < 1u ? 1u : (blocks < 512u ? blocks : 512u));
+  dim3 g(blocks < 1u ? 1u : (blocks < PB_TAIL_BLOCKS ? blocks : PB_TAIL_BLOCKS));
   const bool curves = sc.num_curves != 0;
   if (stats && curves) hipLaunchKernelGGL((k_tail<true, true>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
   else if (stats) hipLaunchKernelGGL((k_tail<false, true>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
