@@ -37,6 +37,8 @@ WORKLOADS = {
                scene="hair", variant="", width=1920, height=1080, spp=128),
     "c1": dict(desc="S-cornell Lambert-only, 256x256, 4 spp (plumbing config)", scene="cornell", variant="lambert",
                width=256, height=256, spp=4),
+    "c5": dict(desc="S-cornell (SSS) + S-hair, 3840x2160, 1024 spp (BASELINE configs[4]; 8.5 G samples: meant for 8 GPUs)",
+               scene="cornell_hair", variant="sss", width=3840, height=2160, spp=1024),
 }
 
 # algorithmic bytes of the traversal kernel k_trace: 64 B per BVH node visited, 48 B per
@@ -62,6 +64,8 @@ def make_desc(w):
     from pbrlab_amd import scenes
     if w["scene"] == "cornell":
         return scenes.cornell_scene(w["variant"], seed=1)
+    if w["scene"] == "cornell_hair":
+        return scenes.cornell_hair_scene(w["variant"], seed=1)
     return scenes.hair_scene(seed=1)
 
 
