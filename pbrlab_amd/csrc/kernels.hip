@@ -451,7 +451,10 @@ __device__ __forceinline__ uint32_t shade_principled_path(const PathState& P, co
     return (shadow ? kRShadow : 0u) | (alive ? kRAlive : 0u) | qbit;
   }
 }
-__global__ __launch_bounds__(kBlock) void k_shade_principled(PathState P, DScene sc, uint64_t rng_inc) {
+#ifndef PB_SHADE_WAVES
+#define PB_SHADE_WAVES 3  // min waves per SIMD: <= 168 VGPRs (A/B on C2: 1 -> 20.5 ms, 2 -> 20.3, 3 -> 19.3, 4 spills -> 25.5)
+#endif
+__global__ __launch_bounds__(kBlock, PB_SHADE_WAVES) void k_shade_principled(PathState P, DScene sc, uint64_t rng_inc) {
   const uint32_t n = P.counts[kCntPrincipled];
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
     const uint32_t p = P.q_principled[i];
