@@ -49,8 +49,8 @@ constexpr uint32_t kSlotMatNone = 8u;   // touching the material table (shader.c
 constexpr uint32_t kSlotHasUV = 16u;
 
 struct alignas(128) ShadeRec {
-  float v[9];   // triangle corners xyz (world); unused for curves (their control points live in `slots`)
-  float n[9];   // corner shading normals xyz (kSlotHasNormals)
+  float v[9];   // triangle corners xyz (world).  Curve piece: words 0..15 of the record (v[0..8], n[0..6]) hold the cubic's
+  float n[9];   // four control points xyzr instead.  Triangle: corner shading normals xyz (kSlotHasNormals)
   uint32_t gid, material, lightrec, flags;
   uint32_t instance_id, geom_id, prim_id;
   float uv[6];  // corner texcoords (kSlotHasUV), mesh/triangle-mesh.cc:126-156

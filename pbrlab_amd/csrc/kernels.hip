@@ -1,18 +1,21 @@
 // kernels.hip -- the wavefront path tracer's device kernels (gfx950, wave64).
 //
 // One path = one (pixel, pass) sample.  Path state lives in HBM as float4-packed SoA indexed by the
-// path slot; stages exchange *queues of slot ids* that are compacted with wave ballots
-// (one atomicAdd per wave).  One iteration of the host loop (render.cpp) =
+// path slot; stages exchange *queues of slot ids*, compacted tile-wise (2048 entries, one atomic per
+// tile and queue).  One iteration of the host loop (pbrhip.cpp::render_impl) =
 //
-//   k_trace_closest   rtcIntersect1          (raytracer_impl.cc:268-278)  active paths -> hit records
-//   k_classify        routes each path to its closure queue by the material kind stored in the hit code
+//   k_trace           rtcIntersect1 (raytracer_impl.cc:268-278) for the live paths' rays AND rtcOccluded1 + the tail of
+//                     DirectIllumination (shader-utils.h:192-208) for the shadow rays of the previous bounce
+//   k_classify        routes each traced path to its closure queue (in-medium / principled / hair), drops misses
 //   k_shade_principled GetRadiance head (render.cc:31-68: implicit light + MIS, Russian roulette) +
 //                     CyclesPrincipledShader (cycles-principled-shader.cc:414-484) incl. SSS entry
 //   k_shade_hair      HairShader             (hair-shader.cc:153-229)
 //   k_sss_step        RandomWalkSubsurface loop body + exit (random-walk-sss.h:287-405)
-//   k_trace_shadow    rtcOccluded1 + tail of DirectIllumination (shader-utils.h:192-208)
+//   k_compact         result words of the shade kernels -> next ray queue + shadow-ray queue
+//   k_advance         queue flip
 //
-// and k_generate (render.cc:160-171) / k_accumulate (render.cc:175-183) bracket a chunk of passes.
+// k_tail runs the same per-path functions in a loop once few paths are left; k_generate (render.cc:160-171) and
+// k_accumulate (render.cc:175-183) bracket a chunk of passes.
 #include "dshade.h"
 #include "dtrace_pv.h"
 #include "kernels.h"
@@ -414,7 +417,7 @@ __device__ __forceinline__ uint32_t shade_principled_path(const PathState& P, co
               alive = true;
               qbit = kQSssBit;
               sh_mode = kShSssEntry;
-              c_vis = d1;  // raw: resolved into A by k_trace_shadow
+              c_vis = d1;  // raw: resolved into A when the shadow ray is traced (TraceSink::done)
             }
           }
           // failed entry: omega_in = f = pdf = 0 -> 0*0/0 = NaN -> throughput 0 (:217-220, :474-483)
