@@ -24,20 +24,6 @@ namespace pb {
 
 constexpr int kBlock = 256;
 
-// ------------------------------------------------------------------ wave-ballot stream compaction
-// Every lane of the wave must reach this call; returns the output index for lanes with pred.
-__device__ __forceinline__ uint32_t queue_append(uint32_t* counter, bool pred) {
-  unsigned long long mask = __ballot(pred);
-  if (mask == 0ull) return 0u;
-  uint32_t lane = __lane_id();
-  uint32_t prefix = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-  int leader = __ffsll((long long)mask) - 1;
-  uint32_t base = 0;
-  if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-  base = (uint32_t)__shfl((int)base, leader);
-  return base + prefix;
-}
-
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
