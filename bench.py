@@ -104,6 +104,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--max-paths", type=int, default=0)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = spp x N (per-GPU work fixed, default); strong = the fixed 64-spp frame split over N GPUs")
     args = ap.parse_args()
 
     import numpy as np
@@ -133,7 +135,8 @@ def main():
     if args.spp:
         w["spp"] = args.spp
     W, H = w["width"], w["height"]
-    spp = w["spp"] * world          # weak scaling: per-GPU work fixed (W*H/N pixels x 64*N spp)
+    weak = args.scaling == "weak"
+    spp = w["spp"] * (world if weak else 1)   # weak scaling: per-GPU work fixed (W*H/N pixels x 64*N spp)
     desc = make_desc(w)
     scene = pa.scene_from_desc(desc)          # upload + BVH: outside the timed region
     info = scene.info()
@@ -216,9 +219,9 @@ def main():
         out = {
             "metric": "Msamples/s (paths x spp / s), 1920x1080 Cornell-box-Suzanne render", "value": samples / elapsed / 1e6,
             "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": w["desc"] + (f" x {world} (spp scaled with the GPU count)" if world > 1 else ""), "width": W, "height": H, "spp": spp,
+            "config": {"workload": w["desc"] + (f" x {world} (spp scaled with the GPU count)" if (world > 1 and weak) else ""), "width": W, "height": H, "spp": spp,
                        "triangles": desc.num_triangles(), "curve_segments": desc.num_segments(),
                        "bvh_nodes": info["num_nodes"], "bvh_depth": info["depth"], "scene_bytes": info["device_bytes"],
                        "parallelism": f"tiles%{world}" if world > 1 else "1gpu",
