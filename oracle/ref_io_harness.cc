@@ -5,6 +5,7 @@
 //   io/tiny_obj_loader.{h,cc}  (vendored tinyobjloader 2.0.0: what io/triangle-mesh-io.cc:216-255 calls)
 //   io/cyhair.{h,cc}, io/curve-mesh-io.{h,cc}, curve-util.{h,cc}, mesh/cubic-bezier-curve-mesh.{h,cc}
 //   io/image-io.{h,cc} (+ vendored io/stb_image*.{h,cc}, io/tinyexr.{h,cc}, miniz.{h,c}), image-utils.{h,cc}
+//   (tinyexr's writer is also exposed, as a generator of .exr test files)
 // Built by oracle/Makefile into oracle/_ref/libref_io.so.  io/triangle-mesh-io.cc itself is NOT built: it needs
 // material-param.h -> mpark/variant.hpp (absent; no stand-ins are written), so the MTL-key -> parameter conversion
 // (triangle-mesh-io.cc:34-212) is checked against a restatement in the tests, not against this library.
@@ -18,6 +19,7 @@
 #include "io/curve-mesh-io.h"
 #include "io/image-io.h"
 #include "io/tiny_obj_loader.h"
+#include "io/tinyexr.h"
 
 namespace {
 struct ObjResult {
@@ -152,6 +154,39 @@ int refio_cli_output(const char* filename, const char* dir, const float* rgba, c
   }
   pbrlab::LinerToSrgb(color, width, height, 4, &color);
   return pbrlab::io::WritePNG(std::string(filename), std::string(dir), color, width, height, 4) ? 1 : 0;
+}
+
+// test-file generator: tinyexr's own writer.  planes: nchan planes of w*h floats, names: nchan strings separated by '\0'
+// (must be in alphabetical order, as the format requires); half != 0 stores HALF channels; compression = TINYEXR_COMPRESSIONTYPE_*
+int refio_save_exr(const char* filename, const float* planes, const char* names, int nchan, int w, int h, int half,
+                   int compression, int line_order) {
+  EXRHeader header;
+  InitEXRHeader(&header);
+  EXRImage image;
+  InitEXRImage(&image);
+  image.num_channels = nchan;
+  std::vector<const float*> ptrs;
+  for (int c = 0; c < nchan; c++) ptrs.push_back(planes + size_t(c) * w * h);
+  image.images = reinterpret_cast<unsigned char**>(const_cast<float**>(ptrs.data()));
+  image.width = w, image.height = h;
+  header.num_channels = nchan;
+  header.channels = static_cast<EXRChannelInfo*>(malloc(sizeof(EXRChannelInfo) * size_t(nchan)));
+  header.pixel_types = static_cast<int*>(malloc(sizeof(int) * size_t(nchan)));
+  header.requested_pixel_types = static_cast<int*>(malloc(sizeof(int) * size_t(nchan)));
+  const char* nm = names;
+  for (int c = 0; c < nchan; c++) {
+    memset(&header.channels[c], 0, sizeof(EXRChannelInfo));
+    strncpy(header.channels[c].name, nm, 255);
+    nm += strlen(nm) + 1;
+    header.pixel_types[c] = TINYEXR_PIXELTYPE_FLOAT;
+    header.requested_pixel_types[c] = half ? TINYEXR_PIXELTYPE_HALF : TINYEXR_PIXELTYPE_FLOAT;
+  }
+  header.compression_type = compression;
+  header.line_order = line_order;
+  const char* err = nullptr;
+  const int ret = SaveEXRImageToFile(&image, &header, filename, &err);
+  free(header.channels), free(header.pixel_types), free(header.requested_pixel_types);
+  return ret == TINYEXR_SUCCESS ? 1 : 0;
 }
 
 int refio_write_png_u8(const char* filename, const char* dir, const unsigned char* px, size_t width, size_t height,

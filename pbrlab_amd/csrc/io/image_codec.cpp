@@ -593,6 +593,202 @@ bool DecodeHdr(const uint8_t* file, size_t n, std::vector<float>* pixels, size_t
   return true;
 }
 
+// ---------------------------------------------------------------- OpenEXR (what tinyexr's LoadEXR returns)
+namespace {
+float half_to_float(uint16_t h) {  // tinyexr.h:928-950
+  union { uint32_t u; float f; } o, magic;
+  magic.u = 113u << 23;
+  const uint32_t shifted_exp = 0x7c00u << 13;
+  o.u = (h & 0x7fffu) << 13;
+  const uint32_t e = shifted_exp & o.u;
+  o.u += (127 - 15) << 23;
+  if (e == shifted_exp) o.u += (128 - 16) << 23;  // Inf / NaN
+  else if (e == 0) {                               // zero / denormal
+    o.u += 1 << 23;
+    o.f -= magic.f;
+  }
+  o.u |= (h & 0x8000u) << 16;
+  return o.f;
+}
+
+struct ExrChannel {
+  std::string name;
+  int type = 0;  // 0 UINT, 1 HALF, 2 FLOAT
+  size_t offset = 0;  // byte offset of this channel inside one pixel's worth of a scanline (x width)
+};
+
+// OpenEXR's RLE (ImfRle.cpp, as in tinyexr.h:1524-1556)
+bool rle_uncompress(const uint8_t* in, size_t in_len, std::vector<uint8_t>* out, size_t max_len) {
+  out->clear();
+  size_t i = 0;
+  while (i < in_len) {
+    const int8_t c = int8_t(in[i++]);
+    if (c < 0) {
+      const size_t count = size_t(-int(c));
+      if (i + count > in_len || out->size() + count > max_len) return false;
+      out->insert(out->end(), in + i, in + i + count);
+      i += count;
+    } else {
+      const size_t count = size_t(c) + 1;
+      if (i >= in_len || out->size() + count > max_len) return false;
+      out->insert(out->end(), count, in[i++]);
+    }
+  }
+  return true;
+}
+
+// predictor + de-interleave applied to ZIP / RLE blocks (ImfZipCompressor.cpp, tinyexr.h:1404-1437)
+void exr_unfilter(std::vector<uint8_t>* buf) {
+  std::vector<uint8_t>& t = *buf;
+  for (size_t i = 1; i < t.size(); ++i) t[i] = uint8_t(int(t[i - 1]) + int(t[i]) - 128);
+  std::vector<uint8_t> out(t.size());
+  const size_t half = (t.size() + 1) / 2;
+  size_t a = 0, b = half;
+  for (size_t s = 0; s < out.size();) {
+    out[s++] = t[a++];
+    if (s < out.size()) out[s++] = t[b++];
+  }
+  t.swap(out);
+}
+}  // namespace
+
+// Single-part scanline OpenEXR -> RGBA float (LoadEXR, tinyexr.h:6004-6260): one channel is replicated into all
+// four; otherwise R, G, B are required and A defaults to 1.  Compression NONE / RLE / ZIPS / ZIP; HALF and FLOAT channels.
+bool DecodeExr(const uint8_t* file, size_t n, std::vector<float>* pixels, size_t* width, size_t* height, std::string* err) {
+  auto rd32 = [&](size_t at) { return uint32_t(file[at]) | (uint32_t(file[at + 1]) << 8) | (uint32_t(file[at + 2]) << 16) | (uint32_t(file[at + 3]) << 24); };
+  if (n < 8 || rd32(0) != 0x01312f76u) return *err = "not an OpenEXR file", false;
+  if (file[4] != 2) return *err = "unsupported OpenEXR version", false;
+  if (file[5] & 0x02) return *err = "tiled OpenEXR files are not decoded by this build", false;
+  if (file[5] & 0x18) return *err = "multipart / deep OpenEXR files are not decoded (LoadEXR rejects them too)", false;
+  size_t pos = 8;
+  std::vector<ExrChannel> ch;
+  int compression = -1, line_order = -1;
+  int32_t dw[4] = {0, 0, -1, -1};
+  bool have_dw = false, have_disp = false, have_par = false, have_swc = false, have_sww = false;
+  for (;;) {
+    if (pos >= n) return *err = "truncated OpenEXR header", false;
+    if (file[pos] == 0) {
+      ++pos;
+      break;
+    }
+    std::string name, type;
+    while (pos < n && file[pos]) name.push_back(char(file[pos++]));
+    ++pos;
+    while (pos < n && file[pos]) type.push_back(char(file[pos++]));
+    ++pos;
+    if (pos + 4 > n) return *err = "truncated OpenEXR header", false;
+    const size_t size = rd32(pos);
+    pos += 4;
+    if (pos + size > n) return *err = "truncated OpenEXR header", false;
+    const size_t at = pos;
+    pos += size;
+    if (name == "channels") {
+      size_t q = at;
+      while (q < at + size && file[q]) {
+        ExrChannel c;
+        while (q < at + size && file[q]) c.name.push_back(char(file[q++]));
+        ++q;
+        if (q + 16 > at + size) return *err = "bad OpenEXR channel list", false;
+        c.type = int(rd32(q));
+        const uint32_t xs = rd32(q + 8), ys = rd32(q + 12);
+        if (xs != 1 || ys != 1) return *err = "subsampled OpenEXR channels are not decoded", false;
+        q += 16;
+        ch.push_back(c);
+      }
+    } else if (name == "compression" && size >= 1) {
+      compression = file[at];
+    } else if (name == "dataWindow" && size >= 16) {
+      for (int k = 0; k < 4; ++k) dw[k] = int32_t(rd32(at + 4 * size_t(k)));
+      have_dw = true;
+    } else if (name == "displayWindow") {
+      have_disp = true;
+    } else if (name == "lineOrder" && size >= 1) {
+      line_order = file[at];
+    } else if (name == "pixelAspectRatio") {
+      have_par = true;
+    } else if (name == "screenWindowCenter") {
+      have_swc = true;
+    } else if (name == "screenWindowWidth") {
+      have_sww = true;
+    }
+  }
+  if (ch.empty() || compression < 0 || !have_dw || !have_disp || line_order < 0 || !have_par || !have_swc || !have_sww)
+    return *err = "OpenEXR header lacks a required attribute", false;
+  if (compression > 3) return *err = "OpenEXR compression PIZ / PXR24 / B44 is not decoded by this build (use ZIP)", false;
+  if (dw[2] < dw[0] || dw[3] < dw[1]) return *err = "bad OpenEXR data window", false;
+  const size_t w = size_t(dw[2] - dw[0]) + 1, h = size_t(dw[3] - dw[1]) + 1;
+  if (w > (1u << 24) || h > (1u << 24)) return *err = "bad OpenEXR data window", false;
+  size_t pixel_bytes = 0;
+  for (ExrChannel& c : ch) {
+    if (c.type != 1 && c.type != 2) return *err = "UINT OpenEXR channels are not decoded", false;
+    c.offset = pixel_bytes;
+    pixel_bytes += c.type == 1 ? 2 : 4;
+  }
+  const size_t block_lines = compression == 3 ? 16 : 1;
+  const size_t nblocks = (h + block_lines - 1) / block_lines;
+  if (pos + nblocks * 8 > n) return *err = "truncated OpenEXR offset table", false;
+  std::vector<std::vector<float>> img(ch.size(), std::vector<float>(w * h, 0.0f));
+  std::vector<uint8_t> block;
+  for (size_t b = 0; b < nblocks; ++b) {
+    uint64_t off = 0;
+    for (int k = 7; k >= 0; --k) off = (off << 8) | file[pos + b * 8 + size_t(k)];
+    if (off + 8 > n) return *err = "bad OpenEXR chunk offset", false;
+    const int32_t line = int32_t(rd32(size_t(off)));
+    const uint32_t len = rd32(size_t(off) + 4);
+    if (len == 0 || off + 8 + len > n) return *err = "bad OpenEXR chunk", false;
+    const int64_t first = int64_t(line) - dw[1];
+    if (first < 0 || first >= int64_t(h)) return *err = "bad OpenEXR chunk", false;
+    const size_t lines = std::min<size_t>(block_lines, h - size_t(first));
+    const size_t raw = w * lines * pixel_bytes;
+    const uint8_t* src = file + off + 8;
+    if (compression == 0 || len == raw) {  // stored (a block that did not shrink is stored raw too)
+      if (len < raw) return *err = "short OpenEXR chunk", false;
+      block.assign(src, src + raw);
+    } else if (compression == 1) {
+      if (!rle_uncompress(src, len, &block, raw) || block.size() != raw) return *err = "bad RLE data in OpenEXR chunk", false;
+      exr_unfilter(&block);
+    } else {
+      std::string zerr;
+      if (!ZlibInflate(src, len, &block, &zerr) || block.size() != raw) return *err = "bad zlib data in OpenEXR chunk", false;
+      exr_unfilter(&block);
+    }
+    for (size_t c = 0; c < ch.size(); ++c)
+      for (size_t v = 0; v < lines; ++v) {
+        const uint8_t* lp = block.data() + v * pixel_bytes * w + ch[c].offset * w;
+        const size_t y = size_t(first) + v;
+        const size_t row = line_order == 0 ? y : h - 1 - y;  // tinyexr stores decreasing-Y files upside down
+        float* dst = &img[c][row * w];
+        for (size_t u = 0; u < w; ++u) {
+          if (ch[c].type == 1) {
+            dst[u] = half_to_float(uint16_t(lp[2 * u] | (lp[2 * u + 1] << 8)));
+          } else {
+            uint32_t bits = uint32_t(lp[4 * u]) | (uint32_t(lp[4 * u + 1]) << 8) | (uint32_t(lp[4 * u + 2]) << 16) | (uint32_t(lp[4 * u + 3]) << 24);
+            memcpy(&dst[u], &bits, 4);
+          }
+        }
+      }
+  }
+  pixels->assign(w * h * 4, 0.0f);
+  if (ch.size() == 1) {
+    for (size_t i = 0; i < w * h; ++i)
+      for (int k = 0; k < 4; ++k) (*pixels)[4 * i + size_t(k)] = img[0][i];
+  } else {
+    int idx[4] = {-1, -1, -1, -1};
+    static const char* names[4] = {"R", "G", "B", "A"};
+    for (size_t c = 0; c < ch.size() && c < 4; ++c)  // LoadEXR looks at the first four channels only
+      for (int k = 0; k < 4; ++k)
+        if (ch[c].name == names[k]) idx[k] = int(c);
+    for (int k = 0; k < 3; ++k)
+      if (idx[k] < 0) return *err = std::string(names[k]) + " channel not found in the OpenEXR file", false;
+    for (size_t i = 0; i < w * h; ++i) {
+      for (int k = 0; k < 3; ++k) (*pixels)[4 * i + size_t(k)] = img[size_t(idx[k])][i];
+      (*pixels)[4 * i + 3] = idx[3] >= 0 ? img[size_t(idx[3])][i] : 1.0f;
+    }
+  }
+  *width = w, *height = h;
+  return true;
+}
+
 // ---------------------------------------------------------------- pbrlab's image functions
 namespace {
 std::string join_path(const std::string& dir, const std::string& name) {  // fs::path(dir) / name
@@ -637,8 +833,12 @@ bool LoadImageFromFile(const std::string& filename, const std::string& asset_pat
   }
   std::string err;
   if (ext == ".exr") {
-    std::cerr << "image file [" << path << "]: OpenEXR is not decoded by this build (convert to .hdr or .png)" << std::endl;
-    return false;
+    if (!DecodeExr(bytes.data(), bytes.size(), pixels, width, height, &err)) {
+      std::cerr << "image file [" << path << "]: " << err << std::endl;
+      return false;
+    }
+    *channels = 4;
+    return true;
   }
   if (ext == ".hdr") {
     if (!DecodeHdr(bytes.data(), bytes.size(), pixels, width, height, &err)) {

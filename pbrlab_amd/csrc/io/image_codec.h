@@ -3,9 +3,10 @@
 // to the vendored stb_image / stb_image_write), src/image-utils.cc:8-107 (sRGB transfer functions).
 //
 // Written from scratch: a zlib inflater/deflater, PNG reader (all colour types and bit depths, Adam7) and writer,
-// Radiance .hdr reader.  Decoded pixels equal stb_image's for the same file (16-bit samples keep their high byte,
-// sub-byte grey is scaled to 0..255, a tRNS colour key becomes an alpha channel).  JPEG, BMP, TGA, GIF, PSD, PNM and
-// OpenEXR are NOT decoded by this build: loading such a file fails with a message naming the format.
+// Radiance .hdr reader, scanline OpenEXR reader.  Decoded pixels equal stb_image's / tinyexr's for the same file (16-bit
+// PNG samples keep their high byte, sub-byte grey is scaled to 0..255, a tRNS colour key becomes an alpha channel).
+// JPEG, BMP, TGA, GIF, PSD, PNM and tiled / PIZ-compressed OpenEXR are NOT decoded by this build: loading such a file
+// fails with a message naming the format.
 #ifndef PBRLAB_AMD_IO_IMAGE_CODEC_H_
 #define PBRLAB_AMD_IO_IMAGE_CODEC_H_
 
@@ -28,6 +29,10 @@ bool DecodePng(const uint8_t* file, size_t n, std::vector<uint8_t>* pixels, size
 // Radiance RGBE -> 3 floats per pixel (stbi_loadf on a .hdr)
 bool DecodeHdr(const uint8_t* file, size_t n, std::vector<float>* pixels, size_t* width, size_t* height,
                std::string* err);
+
+// single-part scanline OpenEXR (NONE / RLE / ZIPS / ZIP; HALF and FLOAT channels) -> RGBA float as tinyexr's LoadEXR
+// returns it (one channel replicated; A = 1 when absent).  Tiled, multipart, PIZ/PXR24/B44 files are refused.
+bool DecodeExr(const uint8_t* file, size_t n, std::vector<float>* pixels, size_t* width, size_t* height, std::string* err);
 
 // io::LoadImageFromFile<float> (image-io.cc:98-152): 8-bit formats are returned as value / 255
 bool LoadImageFromFile(const std::string& filename, const std::string& asset_path, std::vector<float>* pixels,

@@ -42,6 +42,7 @@ def lib():
         L.refio_image_free.argtypes = [C.c_void_p]
         L.refio_cli_output.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]
         L.refio_write_png_u8.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t]
+        L.refio_save_exr.argtypes = [C.c_char_p, C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.refio_parse_texopt.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
         _L = L
     return _L
@@ -107,3 +108,12 @@ def parse_texopt(value):
     cs = C.create_string_buffer(256)
     ok = lib().refio_parse_texopt(value.encode(), name, 1024, cs, 256)
     return bool(ok), name.value.decode(), cs.value.decode()
+
+
+def save_exr(path, planes, names, half=False, compression=3, line_order=0):
+    """tinyexr's writer (test-file generator).  planes: (nchan, h, w) float32; names: alphabetical channel names"""
+    planes = np.ascontiguousarray(planes, np.float32)
+    nchan, h, w = planes.shape
+    assert list(names) == sorted(names)
+    blob = b"".join(n.encode() + b"\0" for n in names)
+    return bool(lib().refio_save_exr(os.fsencode(path), planes.ctypes.data, blob, nchan, w, h, int(half), compression, line_order))

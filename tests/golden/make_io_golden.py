@@ -24,6 +24,10 @@ PNG_CASES = [  # (color, depth, interlace, trns)
 ]
 
 
+EXR_CASES = [(["A", "B", "G", "R"], False, 3, 0), (["B", "G", "R"], True, 3, 0), (["Y"], True, 2, 0), (["A", "B", "G", "R"], True, 1, 0),
+             (["B", "G", "R"], False, 0, 0), (["A", "B", "G", "R"], True, 3, 1)]
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     g = {}
@@ -66,6 +70,17 @@ def main():
         name = "env%d.hdr" % i
         _iofiles.write_hdr(os.path.join(OUT, name), img, rle=rle)
         g["hdr%d" % i] = _refio.image_load(name, OUT)
+    # OpenEXR (written by tinyexr itself): compression NONE/RLE/ZIPS/ZIP, HALF/FLOAT, RGBA / RGB / one channel, both line orders
+    for i, (names, half, comp, lo) in enumerate(EXR_CASES):
+        w, h = int(rng.integers(5, 40)), int(rng.integers(17, 40))
+        planes = (rng.random((len(names), h, w)) * 10.0 ** rng.integers(-2, 3)).astype(np.float32)
+        planes[:, : h // 2] = 0.5
+        if half:
+            planes[0, 0, 0], planes[-1, -1, -1] = 1e-7, 70000.0     # half denormal / overflow to inf
+        name = "env%d.exr" % i
+        assert _refio.save_exr(os.path.join(OUT, name), planes, names, half, comp, lo)
+        g["exr%d" % i] = _refio.image_load(name, OUT)
+        assert g["exr%d" % i] is not None
     # output stage of pbrlab-cli (rgba/count -> sRGB -> byte(x*256) -> stb PNG), decoded back by stb
     rgba = (rng.random((19, 23, 4)) * 40).astype(np.float32)
     count = np.full((19, 23), 32, np.uint32)
