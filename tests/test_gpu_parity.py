@@ -205,10 +205,13 @@ def test_cancel_and_finish_pass(pa, pairs):
     assert fin.value == 4 and (lay.count == 4).all()
 
 
-def test_full_size_properties(pa):
-    """BASELINE config C2 geometry at full resolution, low spp: size-independent properties."""
+@pytest.mark.parametrize("config", ["c2", "c3", "c4"])
+def test_full_size_properties(pa, config):
+    """BASELINE configs C2 (GGX), C3 (random-walk SSS), C4 (hair + head) at full geometry and resolution, low spp:
+    size-independent properties + spot parity with the oracle."""
     from pbrlab_amd import scenes
-    desc = scenes.cornell_scene("ggx", seed=1)
+    desc = {"c2": lambda: scenes.cornell_scene("ggx", seed=1), "c3": lambda: scenes.cornell_scene("sss", seed=1),
+            "c4": lambda: scenes.hair_scene(seed=1)}[config]()
     sg = pa.scene_from_desc(desc)
     W, H, SPP = 1920, 1080, 2
     a, b = pa.RenderLayer(), pa.RenderLayer()
@@ -222,6 +225,9 @@ def test_full_size_properties(pa):
         pa.Render(sg, W, H, SPP, layer=p, tile_rank=r, tile_world=2)
         acc += p.rgba
     assert acc.tobytes() == a.rgba.tobytes()                         # sharded sum == whole
+    c = pa.RenderLayer()
+    pa.Render(sg, W, H, SPP, layer=c, tail_paths=0xFFFFFFFF)          # every bounce through the wavefront kernels
+    assert c.rgba.tobytes() == a.rgba.tobytes()
     # spot parity with the oracle at full size: 3 tiles' worth of pixels through per-sample traces
     so = O.oracle_scene_from_desc(desc)
     rng = np.random.RandomState(0)
