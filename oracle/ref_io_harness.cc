@@ -20,6 +20,7 @@
 #include "io/image-io.h"
 #include "io/tiny_obj_loader.h"
 #include "io/tinyexr.h"
+#include "io/stb_image_write.h"
 
 namespace {
 struct ObjResult {
@@ -187,6 +188,11 @@ int refio_save_exr(const char* filename, const float* planes, const char* names,
   const int ret = SaveEXRImageToFile(&image, &header, filename, &err);
   free(header.channels), free(header.pixel_types), free(header.requested_pixel_types);
   return ret == TINYEXR_SUCCESS ? 1 : 0;
+}
+
+// test-file generator: stb_image_write's JPEG writer (baseline, YCbCr, 4:2:0 when quality <= 90 else 4:4:4)
+int refio_write_jpg(const char* filename, const unsigned char* px, int w, int h, int comp, int quality) {
+  return stbi_write_jpg(filename, w, h, comp, px, quality) ? 1 : 0;
 }
 
 int refio_write_png_u8(const char* filename, const char* dir, const unsigned char* px, size_t width, size_t height,

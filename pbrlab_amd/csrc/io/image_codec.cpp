@@ -8,6 +8,7 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <memory>
 #include <sstream>
 
 namespace pbio {
@@ -593,6 +594,547 @@ bool DecodeHdr(const uint8_t* file, size_t n, std::vector<float>* pixels, size_t
   return true;
 }
 
+// ---------------------------------------------------------------- JPEG (baseline / extended sequential Huffman)
+// Decodes to what stb_image returns for the same file (stbi_load, req_comp = 0): its integer IDCT, its "3:1" upsampling
+// filters across block boundaries, its fixed-point YCbCr -> RGB, CMYK / YCCK through the Adobe transform flag.
+namespace {
+const uint8_t kZigzag[64 + 15] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48, 41, 34, 27, 20,
+                                  13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45,
+                                  38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63};
+
+struct JpegHuff {
+  uint8_t size[257];
+  uint16_t code[256];
+  uint8_t values[256];
+  uint32_t maxcode[18];
+  int delta[17];
+  bool build(const int* count) {  // JPEG spec C.2 (stbi__build_huffman)
+    int k = 0;
+    for (int i = 0; i < 16; ++i)
+      for (int j = 0; j < count[i]; ++j) {
+        if (k >= 256) return false;
+        size[k++] = uint8_t(i + 1);
+      }
+    size[k] = 0;
+    uint32_t c = 0;
+    k = 0;
+    int j;
+    for (j = 1; j <= 16; ++j) {
+      delta[j] = k - int(c);
+      if (size[k] == j) {
+        while (size[k] == j) code[k++] = uint16_t(c++);
+        if (c - 1 >= (1u << j)) return false;
+      }
+      maxcode[j] = c << (16 - j);
+      c <<= 1;
+    }
+    maxcode[j] = 0xffffffffu;
+    return true;
+  }
+};
+
+struct JpegComp {
+  int id = 0, h = 0, v = 0, tq = 0, hd = 0, ha = 0, dc_pred = 0;
+  int x = 0, y = 0, w2 = 0, h2 = 0;
+  std::vector<uint8_t> data;
+};
+
+struct JpegDecoder {
+  const uint8_t* p;
+  size_t n, pos = 0;
+  uint32_t code_buffer = 0;
+  int code_bits = 0, nomore = 0;
+  int marker = 0xff;  // 0xff = none
+  int restart_interval = 0, todo = 0;
+  JpegHuff huff_dc[4], huff_ac[4];
+  uint16_t dequant[4][64];
+  JpegComp comp[4];
+  int img_x = 0, img_y = 0, img_n = 0, h_max = 1, v_max = 1, mcu_x = 0, mcu_y = 0;
+  int scan_n = 0, order[4] = {0, 0, 0, 0};
+  int rgb = 0, jfif = 0, app14 = -1;
+  bool progressive = false;
+  std::string err;
+
+  int get8() { return pos < n ? p[pos++] : 0; }
+  int get16() {
+    const int a = get8();
+    return (a << 8) | get8();
+  }
+  bool eof() const { return pos >= n; }
+  bool fail(const char* m) {
+    err = m;
+    return false;
+  }
+  void grow() {  // stbi__grow_buffer_unsafe: byte stuffing, a marker ends the entropy data (zero bits follow)
+    do {
+      uint32_t b = nomore ? 0u : uint32_t(get8());
+      if (b == 0xff) {
+        int c = get8();
+        while (c == 0xff) c = get8();
+        if (c != 0) {
+          marker = c;
+          nomore = 1;
+          return;
+        }
+      }
+      code_buffer |= b << (24 - code_bits);
+      code_bits += 8;
+    } while (code_bits <= 24);
+  }
+  int huff_decode(const JpegHuff& h) {
+    if (code_bits < 16) grow();
+    const uint32_t temp = code_buffer >> 16;
+    int k;
+    for (k = 1;; ++k)
+      if (temp < h.maxcode[k]) break;
+    if (k == 17) {
+      code_bits -= 16;
+      return -1;
+    }
+    if (k > code_bits) return -1;
+    const int c = int((code_buffer >> (32 - k)) & ((1u << k) - 1u)) + h.delta[k];
+    if (c < 0 || c > 255) return -1;
+    code_bits -= k;
+    code_buffer <<= k;
+    return h.values[c];
+  }
+  int extend_receive(int nb) {
+    if (code_bits < nb) grow();
+    const int sgn = int32_t(code_buffer) >> 31;
+    uint32_t k = (code_buffer << nb) | (code_buffer >> (32 - nb));
+    const uint32_t mask = (1u << nb) - 1u;
+    code_buffer = k & ~mask;
+    k &= mask;
+    code_bits -= nb;
+    static const int bias[16] = {0, -1, -3, -7, -15, -31, -63, -127, -255, -511, -1023, -2047, -4095, -8191, -16383, -32767};
+    return int(k) + (bias[nb] & ~sgn);
+  }
+  bool decode_block(short data[64], int b) {
+    JpegComp& c = comp[b];
+    const uint16_t* dq = dequant[c.tq];
+    if (code_bits < 16) grow();
+    const int t = huff_decode(huff_dc[c.hd]);
+    if (t < 0 || t > 15) return fail("bad huffman code in JPEG");
+    memset(data, 0, 64 * sizeof(short));
+    const int diff = t ? extend_receive(t) : 0;
+    const int dc = c.dc_pred + diff;
+    c.dc_pred = dc;
+    data[0] = short(dc * dq[0]);
+    int k = 1;
+    do {
+      if (code_bits < 16) grow();
+      const int rs = huff_decode(huff_ac[c.ha]);
+      if (rs < 0) return fail("bad huffman code in JPEG");
+      const int sbits = rs & 15, r = rs >> 4;
+      if (sbits == 0) {
+        if (rs != 0xf0) break;
+        k += 16;
+      } else {
+        k += r;
+        const unsigned zig = kZigzag[k++];
+        data[zig] = short(extend_receive(sbits) * dq[zig]);
+      }
+    } while (k < 64);
+    return true;
+  }
+  void reset() {
+    code_bits = 0, code_buffer = 0, nomore = 0;
+    for (JpegComp& c : comp) c.dc_pred = 0;
+    marker = 0xff;
+    todo = restart_interval ? restart_interval : 0x7fffffff;
+  }
+  int get_marker() {
+    if (marker != 0xff) {
+      const int x = marker;
+      marker = 0xff;
+      return x;
+    }
+    int x = get8();
+    if (x != 0xff) return 0xff;
+    while (x == 0xff) x = get8();
+    return x;
+  }
+};
+
+inline uint8_t clamp255(int x) { return uint8_t(unsigned(x) > 255u ? (x < 0 ? 0 : 255) : x); }
+
+// jidctint-derived integer IDCT, 12-bit constants (stbi__idct_block)
+void jpeg_idct(uint8_t* out, int stride, const short d[64]) {
+  auto f2f = [](double x) { return int(x * 4096 + 0.5); };
+  static const int c0 = f2f(0.5411961f), c1 = f2f(-1.847759065f), c2 = f2f(0.765366865f), c3 = f2f(1.175875602f),
+                   c4 = f2f(0.298631336f), c5 = f2f(2.053119869f), c6 = f2f(3.072711026f), c7 = f2f(1.501321110f),
+                   c8 = f2f(-0.899976223f), c9 = f2f(-2.562915447f), c10 = f2f(-1.961570560f), c11 = f2f(-0.390180644f);
+  int val[64];
+  auto pass = [&](int s0, int s1, int s2, int s3, int s4, int s5, int s6, int s7, int& x0, int& x1, int& x2, int& x3, int& t0,
+                  int& t1, int& t2, int& t3) {
+    int p1, p2, p3, p4, p5;
+    p2 = s2, p3 = s6;
+    p1 = (p2 + p3) * c0;
+    t2 = p1 + p3 * c1;
+    t3 = p1 + p2 * c2;
+    p2 = s0, p3 = s4;
+    t0 = (p2 + p3) * 4096;
+    t1 = (p2 - p3) * 4096;
+    x0 = t0 + t3, x3 = t0 - t3, x1 = t1 + t2, x2 = t1 - t2;
+    t0 = s7, t1 = s5, t2 = s3, t3 = s1;
+    p3 = t0 + t2, p4 = t1 + t3, p1 = t0 + t3, p2 = t1 + t2;
+    p5 = (p3 + p4) * c3;
+    t0 = t0 * c4, t1 = t1 * c5, t2 = t2 * c6, t3 = t3 * c7;
+    p1 = p5 + p1 * c8, p2 = p5 + p2 * c9, p3 = p3 * c10, p4 = p4 * c11;
+    t3 += p1 + p4, t2 += p2 + p3, t1 += p2 + p4, t0 += p1 + p3;
+  };
+  for (int i = 0; i < 8; ++i) {
+    const short* c = d + i;
+    int* v = val + i;
+    if (c[8] == 0 && c[16] == 0 && c[24] == 0 && c[32] == 0 && c[40] == 0 && c[48] == 0 && c[56] == 0) {
+      const int dc = c[0] * 4;
+      v[0] = v[8] = v[16] = v[24] = v[32] = v[40] = v[48] = v[56] = dc;
+    } else {
+      int x0, x1, x2, x3, t0, t1, t2, t3;
+      pass(c[0], c[8], c[16], c[24], c[32], c[40], c[48], c[56], x0, x1, x2, x3, t0, t1, t2, t3);
+      x0 += 512, x1 += 512, x2 += 512, x3 += 512;
+      v[0] = (x0 + t3) >> 10, v[56] = (x0 - t3) >> 10, v[8] = (x1 + t2) >> 10, v[48] = (x1 - t2) >> 10;
+      v[16] = (x2 + t1) >> 10, v[40] = (x2 - t1) >> 10, v[24] = (x3 + t0) >> 10, v[32] = (x3 - t0) >> 10;
+    }
+  }
+  for (int i = 0; i < 8; ++i) {
+    const int* v = val + i * 8;
+    uint8_t* o = out + i * stride;
+    int x0, x1, x2, x3, t0, t1, t2, t3;
+    pass(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], x0, x1, x2, x3, t0, t1, t2, t3);
+    const int bias = 65536 + (128 << 17);
+    x0 += bias, x1 += bias, x2 += bias, x3 += bias;
+    o[0] = clamp255((x0 + t3) >> 17), o[7] = clamp255((x0 - t3) >> 17), o[1] = clamp255((x1 + t2) >> 17), o[6] = clamp255((x1 - t2) >> 17);
+    o[2] = clamp255((x2 + t1) >> 17), o[5] = clamp255((x2 - t1) >> 17), o[3] = clamp255((x3 + t0) >> 17), o[4] = clamp255((x3 - t0) >> 17);
+  }
+}
+
+// one output row of an upsampled component (stbi__resample_row_*): `near` / `far` are the two source rows
+const uint8_t* jpeg_resample(uint8_t* out, const uint8_t* nr, const uint8_t* fr, int w, int hs, int vs) {
+  if (hs == 1 && vs == 1) return nr;
+  if (hs == 1 && vs == 2) {
+    for (int i = 0; i < w; ++i) out[i] = uint8_t((3 * nr[i] + fr[i] + 2) >> 2);
+    return out;
+  }
+  if (hs == 2 && vs == 1) {
+    if (w == 1) {
+      out[0] = out[1] = nr[0];
+      return out;
+    }
+    out[0] = nr[0];
+    out[1] = uint8_t((nr[0] * 3 + nr[1] + 2) >> 2);
+    int i;
+    for (i = 1; i < w - 1; ++i) {
+      const int m = 3 * nr[i] + 2;
+      out[i * 2 + 0] = uint8_t((m + nr[i - 1]) >> 2);
+      out[i * 2 + 1] = uint8_t((m + nr[i + 1]) >> 2);
+    }
+    out[i * 2 + 0] = uint8_t((nr[w - 2] * 3 + nr[w - 1] + 2) >> 2);
+    out[i * 2 + 1] = nr[w - 1];
+    return out;
+  }
+  if (hs == 2 && vs == 2) {
+    if (w == 1) {
+      out[0] = out[1] = uint8_t((3 * nr[0] + fr[0] + 2) >> 2);
+      return out;
+    }
+    int t1 = 3 * nr[0] + fr[0];
+    out[0] = uint8_t((t1 + 2) >> 2);
+    for (int i = 1; i < w; ++i) {
+      const int t0 = t1;
+      t1 = 3 * nr[i] + fr[i];
+      out[i * 2 - 1] = uint8_t((3 * t0 + t1 + 8) >> 4);
+      out[i * 2] = uint8_t((3 * t1 + t0 + 8) >> 4);
+    }
+    out[w * 2 - 1] = uint8_t((t1 + 2) >> 2);
+    return out;
+  }
+  for (int i = 0; i < w; ++i)
+    for (int j = 0; j < hs; ++j) out[i * hs + j] = nr[i];
+  return out;
+}
+
+void jpeg_ycc_row(uint8_t* out, const uint8_t* y, const uint8_t* pcb, const uint8_t* pcr, int count, int step) {
+  auto fx = [](float x) { return int(x * 4096.0f + 0.5f) << 8; };
+  static const int k_r = fx(1.40200f), k_g1 = fx(0.71414f), k_g2 = fx(0.34414f), k_b = fx(1.77200f);
+  for (int i = 0; i < count; ++i) {
+    const int yf = (y[i] << 20) + (1 << 19);
+    const int cr = pcr[i] - 128, cb = pcb[i] - 128;
+    int r = yf + cr * k_r;
+    int g = yf + (cr * -k_g1) + int(uint32_t(cb * -k_g2) & 0xffff0000u);
+    int b = yf + cb * k_b;
+    r >>= 20, g >>= 20, b >>= 20;
+    out[0] = clamp255(r), out[1] = clamp255(g), out[2] = clamp255(b);
+    out += step;
+  }
+}
+
+inline uint8_t blinn8(uint8_t x, uint8_t y) {
+  const unsigned t = unsigned(x) * y + 128;
+  return uint8_t((t + (t >> 8)) >> 8);
+}
+}  // namespace
+
+bool DecodeJpeg(const uint8_t* file, size_t n, std::vector<uint8_t>* pixels, size_t* width, size_t* height, size_t* channels,
+                std::string* err) {
+  std::unique_ptr<JpegDecoder> zp(new JpegDecoder());
+  JpegDecoder& z = *zp;
+  z.p = file, z.n = n;
+  auto bail = [&](const char* m) {
+    *err = m;
+    return false;
+  };
+  if (z.get_marker() != 0xd8) return bail("not a JPEG file");
+  auto process_marker = [&](int m) -> bool {
+    switch (m) {
+      case 0xff: return z.fail("expected a JPEG marker");
+      case 0xdd:
+        if (z.get16() != 4) return z.fail("bad DRI length");
+        z.restart_interval = z.get16();
+        return true;
+      case 0xdb: {
+        int L = z.get16() - 2;
+        while (L > 0) {
+          const int q = z.get8(), pq = q >> 4, t = q & 15;
+          if (pq != 0 && pq != 1) return z.fail("bad DQT type");
+          if (t > 3) return z.fail("bad DQT table");
+          for (int i = 0; i < 64; ++i) z.dequant[t][kZigzag[i]] = uint16_t(pq ? z.get16() : z.get8());
+          L -= pq ? 129 : 65;
+        }
+        return L == 0 ? true : z.fail("bad DQT length");
+      }
+      case 0xc4: {
+        int L = z.get16() - 2;
+        while (L > 0) {
+          const int q = z.get8(), tc = q >> 4, th = q & 15;
+          if (tc > 1 || th > 3) return z.fail("bad DHT header");
+          int sizes[16], total = 0;
+          for (int i = 0; i < 16; ++i) sizes[i] = z.get8(), total += sizes[i];
+          if (total > 256) return z.fail("bad DHT table");
+          L -= 17;
+          JpegHuff& h = tc == 0 ? z.huff_dc[th] : z.huff_ac[th];
+          if (!h.build(sizes)) return z.fail("bad code lengths in JPEG");
+          for (int i = 0; i < total; ++i) h.values[i] = uint8_t(z.get8());
+          L -= total;
+        }
+        return L == 0 ? true : z.fail("bad DHT length");
+      }
+    }
+    if ((m >= 0xe0 && m <= 0xef) || m == 0xfe) {
+      int L = z.get16();
+      if (L < 2) return z.fail("bad APP / COM length");
+      L -= 2;
+      if (m == 0xe0 && L >= 5) {
+        static const uint8_t tag[5] = {'J', 'F', 'I', 'F', 0};
+        bool ok = true;
+        for (int i = 0; i < 5; ++i)
+          if (z.get8() != tag[i]) ok = false;
+        L -= 5;
+        if (ok) z.jfif = 1;
+      } else if (m == 0xee && L >= 12) {
+        static const uint8_t tag[6] = {'A', 'd', 'o', 'b', 'e', 0};
+        bool ok = true;
+        for (int i = 0; i < 6; ++i)
+          if (z.get8() != tag[i]) ok = false;
+        L -= 6;
+        if (ok) {
+          z.get8(), z.get16(), z.get16();
+          z.app14 = z.get8();
+          L -= 6;
+        }
+      }
+      z.pos = std::min(z.n, z.pos + size_t(L));
+      return true;
+    }
+    return z.fail("unknown JPEG marker");
+  };
+  // header: everything up to SOF
+  int m = z.get_marker();
+  while (!(m == 0xc0 || m == 0xc1 || m == 0xc2)) {
+    if (!process_marker(m)) return bail(z.err.c_str());
+    m = z.get_marker();
+    while (m == 0xff) {
+      if (z.eof()) return bail("no SOF in JPEG");
+      m = z.get_marker();
+    }
+  }
+  if (m == 0xc2) return bail("progressive JPEG is not decoded by this build (re-save as baseline, or as PNG)");
+  {
+    const int Lf = z.get16();
+    if (Lf < 11) return bail("bad SOF length");
+    if (z.get8() != 8) return bail("JPEG: only 8 bits per sample");
+    z.img_y = z.get16(), z.img_x = z.get16();
+    if (z.img_y == 0 || z.img_x == 0) return bail("bad JPEG size");
+    const int c = z.get8();
+    if (c != 3 && c != 1 && c != 4) return bail("bad JPEG component count");
+    z.img_n = c;
+    if (Lf != 8 + 3 * c) return bail("bad SOF length");
+    for (int i = 0; i < c; ++i) {
+      static const uint8_t rgb[3] = {'R', 'G', 'B'};
+      JpegComp& k = z.comp[i];
+      k.id = z.get8();
+      if (c == 3 && k.id == rgb[i]) ++z.rgb;
+      const int q = z.get8();
+      k.h = q >> 4, k.v = q & 15;
+      if (!k.h || k.h > 4 || !k.v || k.v > 4) return bail("bad JPEG sampling factors");
+      k.tq = z.get8();
+      if (k.tq > 3) return bail("bad JPEG quantisation table index");
+    }
+    for (int i = 0; i < c; ++i) z.h_max = std::max(z.h_max, z.comp[i].h), z.v_max = std::max(z.v_max, z.comp[i].v);
+    const int mw = z.h_max * 8, mh = z.v_max * 8;
+    z.mcu_x = (z.img_x + mw - 1) / mw, z.mcu_y = (z.img_y + mh - 1) / mh;
+    for (int i = 0; i < c; ++i) {
+      JpegComp& k = z.comp[i];
+      k.x = (z.img_x * k.h + z.h_max - 1) / z.h_max;
+      k.y = (z.img_y * k.v + z.v_max - 1) / z.v_max;
+      k.w2 = z.mcu_x * k.h * 8, k.h2 = z.mcu_y * k.v * 8;
+      k.data.assign(size_t(k.w2) * size_t(k.h2), 0);
+    }
+  }
+  // scans
+  m = z.get_marker();
+  while (m != 0xd9) {
+    if (m == 0xda) {
+      const int Ls = z.get16();
+      z.scan_n = z.get8();
+      if (z.scan_n < 1 || z.scan_n > 4 || z.scan_n > z.img_n) return bail("bad SOS component count");
+      if (Ls != 6 + 2 * z.scan_n) return bail("bad SOS length");
+      for (int i = 0; i < z.scan_n; ++i) {
+        const int id = z.get8(), q = z.get8();
+        int which = 0;
+        for (; which < z.img_n; ++which)
+          if (z.comp[which].id == id) break;
+        if (which == z.img_n) return bail("bad SOS component");
+        z.comp[which].hd = q >> 4, z.comp[which].ha = q & 15;
+        if (z.comp[which].hd > 3 || z.comp[which].ha > 3) return bail("bad SOS huffman table index");
+        z.order[i] = which;
+      }
+      const int ss = z.get8();
+      z.get8();
+      const int aa = z.get8();
+      if (ss != 0 || aa != 0) return bail("bad SOS");
+      // entropy-coded data
+      z.reset();
+      short data[64];
+      bool stop = false;
+      if (z.scan_n == 1) {
+        const int c = z.order[0];
+        JpegComp& k = z.comp[c];
+        const int bw = (k.x + 7) >> 3, bh = (k.y + 7) >> 3;
+        for (int j = 0; j < bh && !stop; ++j)
+          for (int i = 0; i < bw; ++i) {
+            if (!z.decode_block(data, c)) return bail(z.err.c_str());
+            jpeg_idct(k.data.data() + size_t(k.w2) * size_t(j) * 8 + size_t(i) * 8, k.w2, data);
+            if (--z.todo <= 0) {
+              if (z.code_bits < 24) z.grow();
+              if (!(z.marker >= 0xd0 && z.marker <= 0xd7)) {
+                stop = true;  // not a restart: keep what was decoded
+                break;
+              }
+              z.reset();
+            }
+          }
+      } else {
+        for (int j = 0; j < z.mcu_y && !stop; ++j)
+          for (int i = 0; i < z.mcu_x; ++i) {
+            for (int s = 0; s < z.scan_n; ++s) {
+              const int c = z.order[s];
+              JpegComp& k = z.comp[c];
+              for (int y = 0; y < k.v; ++y)
+                for (int x = 0; x < k.h; ++x) {
+                  const int x2 = (i * k.h + x) * 8, y2 = (j * k.v + y) * 8;
+                  if (!z.decode_block(data, c)) return bail(z.err.c_str());
+                  jpeg_idct(k.data.data() + size_t(k.w2) * size_t(y2) + size_t(x2), k.w2, data);
+                }
+            }
+            if (--z.todo <= 0) {
+              if (z.code_bits < 24) z.grow();
+              if (!(z.marker >= 0xd0 && z.marker <= 0xd7)) {
+                stop = true;
+                break;
+              }
+              z.reset();
+            }
+          }
+      }
+      if (z.marker == 0xff) {  // skip stray bytes up to the next marker
+        while (!z.eof()) {
+          if (z.get8() == 255) {
+            z.marker = z.get8();
+            break;
+          }
+        }
+      }
+    } else if (m == 0xdc) {
+      const int Ld = z.get16(), NL = z.get16();
+      if (Ld != 4 || NL != z.img_y) return bail("bad DNL");
+    } else {
+      if (!process_marker(m)) return bail(z.err.c_str());
+    }
+    m = z.get_marker();
+  }
+  // upsample + colour conversion (load_jpeg_image)
+  const int out_n = z.img_n >= 3 ? 3 : 1;
+  const bool is_rgb = z.img_n == 3 && (z.rgb == 3 || (z.app14 == 0 && !z.jfif));
+  struct Res {
+    int hs, vs, w_lores, ystep, ypos;
+    const uint8_t *line0, *line1;
+    std::vector<uint8_t> buf;
+  } res[4];
+  for (int k = 0; k < z.img_n; ++k) {
+    Res& r = res[k];
+    r.hs = z.h_max / z.comp[k].h, r.vs = z.v_max / z.comp[k].v;
+    r.ystep = r.vs >> 1;
+    r.w_lores = (z.img_x + r.hs - 1) / r.hs;
+    r.ypos = 0;
+    r.line0 = r.line1 = z.comp[k].data.data();
+    r.buf.assign(size_t(z.img_x) + 3 + 8, 0);
+  }
+  pixels->assign(size_t(out_n) * size_t(z.img_x) * size_t(z.img_y), 0);
+  const uint8_t* co[4] = {nullptr, nullptr, nullptr, nullptr};
+  std::vector<uint8_t> tmp(size_t(z.img_x) * 3);
+  for (int j = 0; j < z.img_y; ++j) {
+    uint8_t* out = pixels->data() + size_t(out_n) * size_t(z.img_x) * size_t(j);
+    for (int k = 0; k < z.img_n; ++k) {
+      Res& r = res[k];
+      const bool y_bot = r.ystep >= (r.vs >> 1);
+      co[k] = jpeg_resample(r.buf.data(), y_bot ? r.line1 : r.line0, y_bot ? r.line0 : r.line1, r.w_lores, r.hs, r.vs);
+      if (++r.ystep >= r.vs) {
+        r.ystep = 0;
+        r.line0 = r.line1;
+        if (++r.ypos < z.comp[k].y) r.line1 += z.comp[k].w2;
+      }
+    }
+    if (z.img_n == 3) {
+      if (is_rgb) {
+        for (int i = 0; i < z.img_x; ++i) out[3 * i] = co[0][i], out[3 * i + 1] = co[1][i], out[3 * i + 2] = co[2][i];
+      } else {
+        jpeg_ycc_row(out, co[0], co[1], co[2], z.img_x, 3);
+      }
+    } else if (z.img_n == 4) {
+      if (z.app14 == 0) {  // CMYK
+        for (int i = 0; i < z.img_x; ++i) {
+          const uint8_t mk = co[3][i];
+          out[3 * i] = blinn8(co[0][i], mk), out[3 * i + 1] = blinn8(co[1][i], mk), out[3 * i + 2] = blinn8(co[2][i], mk);
+        }
+      } else if (z.app14 == 2) {  // YCCK
+        jpeg_ycc_row(out, co[0], co[1], co[2], z.img_x, 3);
+        for (int i = 0; i < z.img_x; ++i) {
+          const uint8_t mk = co[3][i];
+          out[3 * i] = blinn8(uint8_t(255 - out[3 * i]), mk), out[3 * i + 1] = blinn8(uint8_t(255 - out[3 * i + 1]), mk);
+          out[3 * i + 2] = blinn8(uint8_t(255 - out[3 * i + 2]), mk);
+        }
+      } else {
+        jpeg_ycc_row(out, co[0], co[1], co[2], z.img_x, 3);
+      }
+    } else {
+      for (int i = 0; i < z.img_x; ++i) out[i] = co[0][i];
+    }
+  }
+  *width = size_t(z.img_x), *height = size_t(z.img_y), *channels = size_t(out_n);
+  return true;
+}
+
 // ---------------------------------------------------------------- OpenEXR (what tinyexr's LoadEXR returns)
 namespace {
 float half_to_float(uint16_t h) {  // tinyexr.h:928-950
@@ -851,6 +1393,16 @@ bool LoadImageFromFile(const std::string& filename, const std::string& asset_pat
   if (bytes.size() >= 8 && memcmp(bytes.data(), kPngSig, 8) == 0) {
     std::vector<uint8_t> px8;
     if (!DecodePng(bytes.data(), bytes.size(), &px8, width, height, channels, &err)) {
+      std::cerr << "image file [" << path << "]: " << err << std::endl;
+      return false;
+    }
+    pixels->resize(px8.size());
+    for (size_t i = 0; i < px8.size(); ++i) (*pixels)[i] = float(px8[i]) / float(255);
+    return true;
+  }
+  if (bytes.size() >= 3 && bytes[0] == 0xFF && bytes[1] == 0xD8) {
+    std::vector<uint8_t> px8;
+    if (!DecodeJpeg(bytes.data(), bytes.size(), &px8, width, height, channels, &err)) {
       std::cerr << "image file [" << path << "]: " << err << std::endl;
       return false;
     }

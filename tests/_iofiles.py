@@ -385,3 +385,188 @@ def write_strands_as_cyhair(path, strands, thickness):
     hdr = struct.pack("<4sIIIIff3f88s", b"HAIR", len(strands), len(pts), 0x1 | 0x2 | 0x4, 0, 0.01, 1.0, 0.5, 0.5, 0.5, b"")
     with open(path, "wb") as f:
         f.write(hdr + segs.tobytes() + pts.tobytes() + th.tobytes())
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# A small baseline JPEG ENCODER (test-file generator): what stb_image_write cannot produce -- grey, 4:2:2 / 4:4:0 / 4:1:1
+# sampling, restart intervals, 16-bit quantisation tables, non-interleaved scans, Adobe CMYK / YCCK, RGB component ids.
+_STD_DC_L = ([0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0], list(range(12)))
+_STD_DC_C = ([0, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0], list(range(12)))
+_STD_AC_L = ([0, 2, 1, 3, 3, 2, 4, 3, 5, 5, 4, 4, 0, 0, 1, 0x7d],
+             [0x01, 0x02, 0x03, 0x00, 0x04, 0x11, 0x05, 0x12, 0x21, 0x31, 0x41, 0x06, 0x13, 0x51, 0x61, 0x07, 0x22, 0x71, 0x14, 0x32, 0x81,
+              0x91, 0xa1, 0x08, 0x23, 0x42, 0xb1, 0xc1, 0x15, 0x52, 0xd1, 0xf0, 0x24, 0x33, 0x62, 0x72, 0x82, 0x09, 0x0a, 0x16, 0x17, 0x18,
+              0x19, 0x1a, 0x25, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x34, 0x35, 0x36, 0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48,
+              0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75,
+              0x76, 0x77, 0x78, 0x79, 0x7a, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99,
+              0x9a, 0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3,
+              0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe1, 0xe2, 0xe3, 0xe4, 0xe5,
+              0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf1, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa])
+_ZZ = [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49, 56,
+       57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63]
+
+
+def _huff_codes(bits, vals):
+    codes, code, k = {}, 0, 0
+    for ln in range(1, 17):
+        for _ in range(bits[ln - 1]):
+            codes[vals[k]] = (code, ln)
+            code += 1
+            k += 1
+        code <<= 1
+    return codes
+
+
+class _Bits:
+    def __init__(self):
+        self.out, self.acc, self.n = bytearray(), 0, 0
+
+    def put(self, code, ln):
+        self.acc = (self.acc << ln) | code
+        self.n += ln
+        while self.n >= 8:
+            b = (self.acc >> (self.n - 8)) & 0xFF
+            self.out.append(b)
+            if b == 0xFF:
+                self.out.append(0)
+            self.n -= 8
+        self.acc &= (1 << self.n) - 1
+
+    def flush(self):
+        if self.n:
+            self.put((1 << (8 - self.n)) - 1, 8 - self.n)
+
+
+def write_jpeg(path, planes, sampling, *, quant=None, restart=0, quant16=False, interleaved=True, ids=None, adobe=None,
+               jfif=True, sof=0xC0, fill_bytes=False):
+    """planes[i]: (h_i, w_i) uint8 at component resolution = ceil(H * v_i / vmax) x ceil(W * h_i / hmax); sampling: [(h, v)]."""
+    nc = len(planes)
+    hmax, vmax = max(s[0] for s in sampling), max(s[1] for s in sampling)
+    H = max(-(-p.shape[0] * vmax // s[1]) for p, s in zip(planes, sampling))
+    W = max(-(-p.shape[1] * hmax // s[0]) for p, s in zip(planes, sampling))
+    # true image size: the largest size consistent with every plane
+    H = min(p.shape[0] * vmax // s[1] for p, s in zip(planes, sampling) if s[1] == vmax) if any(s[1] == vmax for s in sampling) else H
+    W = min(p.shape[1] * hmax // s[0] for p, s in zip(planes, sampling) if s[0] == hmax) if any(s[0] == hmax for s in sampling) else W
+    q = np.asarray(quant if quant is not None else np.full(64, 8), np.int64).reshape(64)
+    ids = ids or list(range(1, nc + 1))
+    dcl, acl = _huff_codes(*_STD_DC_L), _huff_codes(*_STD_AC_L)
+    # DCT basis
+    x = np.arange(8)
+    Cm = np.cos((2 * x[None, :] + 1) * x[:, None] * np.pi / 16) * np.where(x[:, None] == 0, np.sqrt(1 / 8), np.sqrt(2 / 8))
+    mcux, mcuy = -(-W // (8 * hmax)), -(-H // (8 * vmax))
+
+    def blocks_of(ci):
+        p = planes[ci].astype(np.float64)
+        hh, ww = mcuy * sampling[ci][1] * 8, mcux * sampling[ci][0] * 8
+        pad = np.zeros((hh, ww))
+        ph, pw = p.shape
+        pad[:ph, :pw] = p
+        pad[:ph, pw:] = p[:, -1:]
+        pad[ph:, :] = pad[ph - 1:ph, :]
+        coef = {}
+        for by in range(hh // 8):
+            for bx in range(ww // 8):
+                blk = pad[by * 8:by * 8 + 8, bx * 8:bx * 8 + 8] - 128.0
+                d = Cm @ blk @ Cm.T
+                coef[(by, bx)] = np.rint(d.reshape(64) / q).astype(np.int64)
+        return coef
+
+    coefs = [blocks_of(ci) for ci in range(nc)]
+
+    def emit_block(bw, c, pred):
+        diff = int(c[0]) - pred
+        mag = abs(diff).bit_length()
+        bw.put(*dcl[mag])
+        if mag:
+            bw.put(diff if diff >= 0 else diff + (1 << mag) - 1, mag)
+        run = 0
+        zz = [int(c[_ZZ[k]]) for k in range(64)]
+        last = max([k for k in range(1, 64) if zz[k]], default=0)
+        for k in range(1, last + 1):
+            if zz[k] == 0:
+                run += 1
+                continue
+            while run > 15:
+                bw.put(*acl[0xF0])
+                run -= 16
+            mag = abs(zz[k]).bit_length()
+            bw.put(*acl[(run << 4) | mag])
+            bw.put(zz[k] if zz[k] >= 0 else zz[k] + (1 << mag) - 1, mag)
+            run = 0
+        if last < 63:
+            bw.put(*acl[0])
+        return int(c[0])
+
+    def seg(marker, payload):
+        return bytes([0xFF, marker]) + struct.pack(">H", len(payload) + 2) + payload
+
+    out = bytearray(b"\xFF\xD8")
+    if jfif:
+        out += seg(0xE0, b"JFIF\x00\x01\x01\x00\x00\x01\x00\x01\x00\x00")
+    if adobe is not None:
+        out += seg(0xEE, b"Adobe\x00\x64\x00\x00\x00\x00" + bytes([adobe]))
+    zq = bytes([int(q[_ZZ[k]]) for k in range(64)]) if not quant16 else b"".join(struct.pack(">H", int(q[_ZZ[k]])) for k in range(64))
+    out += seg(0xDB, bytes([0x10 if quant16 else 0x00]) + zq)
+    out += seg(sof, bytes([8]) + struct.pack(">HH", H, W) + bytes([nc]) + b"".join(bytes([ids[i], (sampling[i][0] << 4) | sampling[i][1], 0]) for i in range(nc)))
+    for tc, th, (bits, vals) in ((0, 0, _STD_DC_L), (1, 0, _STD_AC_L)):
+        out += seg(0xC4, bytes([(tc << 4) | th]) + bytes(bits) + bytes(vals))
+    if restart:
+        out += seg(0xDD, struct.pack(">H", restart))
+    if fill_bytes:
+        out += b"\xFF\xFF"          # fill bytes before a marker are legal
+
+    def scan(comp_list):
+        hdr = bytes([len(comp_list)]) + b"".join(bytes([ids[c], 0x00]) for c in comp_list) + bytes([0, 63, 0])
+        data = bytearray(seg(0xDA, hdr))
+        bw = _Bits()
+        pred = {c: 0 for c in comp_list}
+        count, rst = 0, 0
+
+        def unit_done():
+            nonlocal count, rst, bw
+            count += 1
+            if restart and count % restart == 0:
+                return True
+            return False
+
+        units = []
+        if len(comp_list) == 1:
+            c = comp_list[0]
+            bwid, bhei = -(-planes[c].shape[1] // 8), -(-planes[c].shape[0] // 8)
+            # non-interleaved: blocks covering the component's own size
+            eff_w = -(-(W * sampling[c][0]) // hmax)
+            eff_h = -(-(H * sampling[c][1]) // vmax)
+            bwid, bhei = (eff_w + 7) // 8, (eff_h + 7) // 8
+            for by in range(bhei):
+                for bx in range(bwid):
+                    units.append([(c, by, bx)])
+        else:
+            for my in range(mcuy):
+                for mx in range(mcux):
+                    u = []
+                    for c in comp_list:
+                        for y in range(sampling[c][1]):
+                            for xx in range(sampling[c][0]):
+                                u.append((c, my * sampling[c][1] + y, mx * sampling[c][0] + xx))
+                    units.append(u)
+        for ui, u in enumerate(units):
+            for (c, by, bx) in u:
+                pred[c] = emit_block(bw, coefs[c][(by, bx)], pred[c])
+            if restart and (ui + 1) % restart == 0 and ui + 1 < len(units):
+                bw.flush()
+                data += bw.out + bytes([0xFF, 0xD0 + (rst & 7)])
+                rst += 1
+                bw = _Bits()
+                pred = {c: 0 for c in comp_list}
+        bw.flush()
+        data += bw.out
+        return data
+
+    if interleaved or nc == 1:
+        out += scan(list(range(nc)))
+    else:
+        for c in range(nc):
+            out += scan([c])
+    out += b"\xFF\xD9"
+    with open(path, "wb") as f:
+        f.write(out)
+    return W, H

@@ -43,6 +43,7 @@ def lib():
         L.refio_cli_output.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]
         L.refio_write_png_u8.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t]
         L.refio_save_exr.argtypes = [C.c_char_p, C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.refio_write_jpg.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.refio_parse_texopt.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
         _L = L
     return _L
@@ -117,3 +118,10 @@ def save_exr(path, planes, names, half=False, compression=3, line_order=0):
     assert list(names) == sorted(names)
     blob = b"".join(n.encode() + b"\0" for n in names)
     return bool(lib().refio_save_exr(os.fsencode(path), planes.ctypes.data, blob, nchan, w, h, int(half), compression, line_order))
+
+
+def write_jpg(path, pixels, quality=90):
+    """stb_image_write's JPEG writer (test-file generator).  pixels: (h, w, c) uint8"""
+    px = np.ascontiguousarray(pixels, np.uint8)
+    h, w, c = px.shape
+    return bool(lib().refio_write_jpg(os.fsencode(path), px.ctypes.data, w, h, c, quality))

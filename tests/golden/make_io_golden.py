@@ -24,6 +24,10 @@ PNG_CASES = [  # (color, depth, interlace, trns)
 ]
 
 
+JPEG_CASES = [(33, 17, [(1, 1)], {}), (45, 30, [(2, 1), (1, 1), (1, 1)], dict(restart=2)),
+              (31, 29, [(1, 2), (1, 1), (1, 1)], dict(interleaved=False)), (40, 24, [(4, 1), (1, 1), (1, 1)], dict(quant16=True)),
+              (20, 20, [(1, 1)] * 4, dict(adobe=0, jfif=False)), (26, 22, [(2, 2), (1, 1), (1, 1), (2, 2)], dict(adobe=2, jfif=False)),
+              (19, 23, [(1, 1)] * 3, dict(ids=[82, 71, 66]))]
 EXR_CASES = [(["A", "B", "G", "R"], False, 3, 0), (["B", "G", "R"], True, 3, 0), (["Y"], True, 2, 0), (["A", "B", "G", "R"], True, 1, 0),
              (["B", "G", "R"], False, 0, 0), (["A", "B", "G", "R"], True, 3, 1)]
 
@@ -81,6 +85,19 @@ def main():
         assert _refio.save_exr(os.path.join(OUT, name), planes, names, half, comp, lo)
         g["exr%d" % i] = _refio.image_load(name, OUT)
         assert g["exr%d" % i] is not None
+    # JPEG: two files from stb_image_write (4:4:4, 4:2:0) and the variants only the test encoder can make
+    def plane(h, w, k):
+        yy, xx = np.mgrid[0:h, 0:w]
+        return np.clip(128 + 90 * np.sin(xx / (3.0 + k)) * np.cos(yy / (4.0 + k)) + rng.normal(0, 8, (h, w)), 0, 255).astype(np.uint8)
+    img = np.stack([plane(37, 53, k) for k in range(3)], -1)
+    assert _refio.write_jpg(os.path.join(OUT, "photo0.jpg"), img, 95) and _refio.write_jpg(os.path.join(OUT, "photo1.jpg"), img, 60)
+    for i, (W, H, samp, kw) in enumerate(JPEG_CASES):
+        hmax, vmax = max(s[0] for s in samp), max(s[1] for s in samp)
+        planes = [plane(-(-H * s[1] // vmax), -(-W * s[0] // hmax), k) for k, s in enumerate(samp)]
+        _iofiles.write_jpeg(os.path.join(OUT, "photo%d.jpg" % (i + 2)), planes, samp, **kw)
+    for i in range(len(JPEG_CASES) + 2):
+        g["jpg%d" % i] = _refio.image_load("photo%d.jpg" % i, OUT)
+        assert g["jpg%d" % i] is not None
     # output stage of pbrlab-cli (rgba/count -> sRGB -> byte(x*256) -> stb PNG), decoded back by stb
     rgba = (rng.random((19, 23, 4)) * 40).astype(np.float32)
     count = np.full((19, 23), 32, np.uint32)

@@ -239,6 +239,52 @@ def test_hdr_decode_golden(i, capfd):
     assert got.shape == want.shape and np.array_equal(bits(got), bits(want))
 
 
+@pytest.mark.parametrize("i", range(9))
+def test_jpeg_decode_golden(i, capfd):
+    """baseline JPEG: 4:4:4 / 4:2:0 from stb_image_write; grey, 4:2:2 + restarts, 4:4:0 non-interleaved, 4:1:1 + 16-bit
+    tables, Adobe CMYK, YCCK 4:2:0, RGB component ids from the test encoder == stb_image's pixels"""
+    got = io_api.LoadImageFromFile("photo%d.jpg" % i, GOLD_DIR)
+    want = GOLD["jpg%d" % i]
+    assert got.shape == want.shape and np.array_equal(bits(got), bits(want))
+
+
+def _jpeg_plane(rng, h, w, k):
+    yy, xx = np.mgrid[0:h, 0:w]
+    return np.clip(128 + 90 * np.sin(xx / (3.0 + k)) * np.cos(yy / (4.0 + k)) + rng.normal(0, 8, (h, w)), 0, 255).astype(np.uint8)
+
+
+@needs_ref
+def test_jpeg_decode_fuzz_vs_reference(tmp_path, capfd):
+    d = str(tmp_path)
+    rng = np.random.default_rng(31)
+    for case in range(40):                      # stb_image_write's files
+        w, h, c = int(rng.integers(1, 90)), int(rng.integers(1, 70)), [3, 3, 4, 1][case % 4]
+        img = np.stack([_jpeg_plane(rng, h, w, k) for k in range(c)], -1) if case % 3 else rng.integers(0, 256, size=(h, w, c)).astype(np.uint8)
+        name = "s%d.jpg" % case
+        assert _refio.write_jpg(os.path.join(d, name), img, [95, 90, 50, 10, 100][case % 5])
+        want, got = _refio.image_load(name, d), io_api.LoadImageFromFile(name, d)
+        assert want is not None and got.shape == want.shape and np.array_equal(bits(got), bits(want)), case
+    variants = [("gray", [(1, 1)], {}), ("422", [(2, 1), (1, 1), (1, 1)], {}), ("440", [(1, 2), (1, 1), (1, 1)], {}),
+                ("420rst", [(2, 2), (1, 1), (1, 1)], dict(restart=2)), ("411", [(4, 1), (1, 1), (1, 1)], {}),
+                ("444rst1", [(1, 1)] * 3, dict(restart=1)), ("q16", [(2, 2), (1, 1), (1, 1)], dict(quant16=True, quant=np.arange(1, 65) * 3)),
+                ("nonint", [(2, 1), (1, 1), (1, 1)], dict(interleaved=False)), ("nonint_rst", [(2, 2), (1, 1), (1, 1)], dict(interleaved=False, restart=3)),
+                ("rgbids", [(1, 1)] * 3, dict(ids=[82, 71, 66])), ("adobe_rgb", [(1, 1)] * 3, dict(adobe=0, jfif=False)),
+                ("adobe_rgb_jfif", [(1, 1)] * 3, dict(adobe=0)), ("cmyk", [(1, 1)] * 4, dict(adobe=0, jfif=False)),
+                ("ycck", [(2, 2), (1, 1), (1, 1), (2, 2)], dict(adobe=2, jfif=False)), ("four", [(1, 1)] * 4, {}),
+                ("sof1", [(1, 1)] * 3, dict(sof=0xC1)), ("fill", [(2, 2), (1, 1), (1, 1)], dict(fill_bytes=True)),
+                ("mixed", [(2, 2), (2, 1), (1, 2)], {})]
+    n = 0
+    for (W, H) in [(1, 1), (7, 5), (33, 17), (45, 70)]:
+        for name, samp, kw in variants:
+            hmax, vmax = max(s[0] for s in samp), max(s[1] for s in samp)
+            planes = [_jpeg_plane(rng, -(-H * s[1] // vmax), -(-W * s[0] // hmax), k) for k, s in enumerate(samp)]
+            f = "v%d_%s.jpg" % (n, name)
+            _iofiles.write_jpeg(os.path.join(d, f), planes, samp, **kw)
+            want, got = _refio.image_load(f, d), io_api.LoadImageFromFile(f, d)
+            assert want is not None and got.shape == want.shape and np.array_equal(bits(got), bits(want)), (W, H, name)
+            n += 1
+
+
 @pytest.mark.parametrize("i", range(6))
 def test_exr_decode_golden(i, capfd):
     """scanline OpenEXR written by tinyexr (NONE/RLE/ZIPS/ZIP, HALF/FLOAT, 1/3/4 channels, both line orders) == tinyexr's LoadEXR"""
@@ -303,17 +349,19 @@ def test_png_decode_fuzz_vs_reference(tmp_path, capfd):
 
 def test_unsupported_image_formats_fail_loudly(tmp_path, capfd):
     d = str(tmp_path)
-    with open(os.path.join(d, "a.jpg"), "wb") as f:
-        f.write(b"\xff\xd8\xff\xe0" + bytes(64))
+    rng = np.random.default_rng(0)
+    _iofiles.write_jpeg(os.path.join(d, "a.jpg"), [rng.integers(0, 256, size=(8, 8)).astype(np.uint8)], [(1, 1)], sof=0xC2)  # progressive SOF
+    with open(os.path.join(d, "a.bmp"), "wb") as f:
+        f.write(b"BM" + bytes(64))
     with open(os.path.join(d, "a.exr"), "wb") as f:
         f.write(b"\x76\x2f\x31\x01\x02\x02\x00\x00" + bytes(64))     # tiled flag set
     with open(os.path.join(d, "trunc.png"), "wb") as f:
         f.write(open(os.path.join(GOLD_DIR, "tex4.png"), "rb").read()[:60])
-    for name in ("a.jpg", "a.exr", "trunc.png", "missing.png"):
+    for name in ("a.jpg", "a.bmp", "a.exr", "trunc.png", "missing.png"):
         with pytest.raises(io_api.PbrIoError):
             io_api.LoadImageFromFile(name, d)
     err = capfd.readouterr().err
-    assert "JPEG" in err and "tiled OpenEXR" in err
+    assert "progressive JPEG" in err and "BMP" in err and "tiled OpenEXR" in err
 
 
 def _png_decode_python(data):
