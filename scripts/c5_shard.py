@@ -1,0 +1,21 @@
+"""BASELINE configs[4] (3840x2160 x 1024 spp, S-cornell SSS + S-hair) on ONE GPU: the whole frame vs rank 0's share of an
+8-rank run (tiles i % 8 == 0) -- the single-GPU proxy for strong scaling of the configuration the multi-GPU target names."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import pbrlab_amd as pa
+from pbrlab_amd import scenes, api
+desc = scenes.cornell_hair_scene("sss", seed=1)
+s = pa.scene_from_desc(desc)
+W, H = 3840, 2160
+SPP = int(os.environ.get("SPP", "1024"))
+rgba = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda"); cnt = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+torch.cuda.synchronize()
+res = {}
+for world in (8, 1):
+    t = time.perf_counter()
+    _, st = api.Render(s, W, H, SPP, tile_rank=0, tile_world=world, device_out=(rgba.data_ptr(), cnt.data_ptr()))
+    dt = time.perf_counter() - t
+    res[world] = dt
+    print(f"world {world}: {dt*1e3:.0f} ms, {st['samples']/dt/1e6:.0f} Msamples/s on this GPU, chunks {st['chunks']}, iterations {st['iterations']}", flush=True)
+print(f"strong-scaling proxy at 8 ranks: {res[1]/res[8]:.2f}x")
