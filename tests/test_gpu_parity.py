@@ -290,3 +290,46 @@ def test_gpu_bvh_builder_errors_and_tiny_scenes(pa):
         assert list(h["prim_id"]) == list(range(ntri))
         with pytest.raises(pa.PbrHipError):
             s.SetBvhBuilder(pa.api.BVH_HOST_SAH)     # after commit
+
+
+def _random_material_scene(seed, with_hair):
+    """the small Cornell scene with EVERY parameter of every material drawn at random (closure branches the demo .mtl never
+    reaches: clearcoat, anisotropy + rotation, metallic, tints, sheen, partial subsurface, odd ior / transmission values)"""
+    from pbrlab_amd import scenes
+    rng = np.random.RandomState(seed)
+    desc = scenes.cornell_hair_scene("sss", n_strands=200, n_segments=5, monkey_subdiv=2, lucy_nu=64, lucy_nv=12) if with_hair \
+        else scenes.cornell_scene("sss", monkey_subdiv=2, lucy_nu=64, lucy_nv=12)
+    for i, m in enumerate(desc.materials):
+        if m.get("kind", "principled") != "principled" or m["name"] == "Light":
+            continue
+        m = dict(m)
+        u = lambda: float(rng.rand())                                     # noqa: E731
+        pick = lambda p: u() if rng.rand() < p else 0.0                   # noqa: E731
+        m.update(base_color=(u(), u(), u()), subsurface=pick(0.35), subsurface_radius=(0.05 + u(), 0.05 + u(), 0.05 + u()),
+                 subsurface_color=(u(), u(), u()), metallic=pick(0.5), specular=pick(0.7), specular_tint=pick(0.5),
+                 roughness=float(rng.choice([0.0, 0.01, 0.2, 0.5, 1.0, u()])), anisotropic=pick(0.5), anisotropic_rotation=pick(0.5),
+                 sheen=pick(0.5), sheen_tint=u(), clearcoat=pick(0.6), clearcoat_roughness=float(rng.choice([0.0, 0.03, 0.3, u()])),
+                 ior=float(rng.choice([1.0, 1.45, 2.5, 1.0 + u()])), transmission=pick(0.3), transmission_roughness=u())
+        desc.materials[i] = m
+    for c in desc.curves:
+        h = dict(c.material)
+        h.update(coloring_hair=int(rng.randint(2)), base_color=(float(rng.rand()), float(rng.rand()), float(rng.rand())),
+                 melanin=float(rng.rand()), melanin_redness=float(rng.rand()), melanin_randomize=float(rng.rand()),
+                 roughness=float(0.05 + 0.9 * rng.rand()), azimuthal_roughness=float(0.05 + 0.9 * rng.rand()),
+                 ior=float(1.2 + rng.rand()), shift=float(rng.rand() * 5))
+        c.material = h
+    return desc
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_materials_parity(pa, seed):
+    desc = _random_material_scene(100 + seed, with_hair=(seed % 2 == 1))
+    sg, so = pa.scene_from_desc(desc), O.oracle_scene_from_desc(desc)
+    rgba, cnt, _ = so.render(64, 48, 6, threads=4, math_mode=O.MATH_F64R)
+    assert np.isfinite(rgba).all() and rgba[..., :3].max() > 0
+    for tail in (0, 0xFFFFFFFF):
+        layer = pa.RenderLayer()
+        pa.Render(sg, 64, 48, 6, layer=layer, tail_paths=tail)
+        assert np.array_equal(layer.count, cnt)
+        nd = int((layer.rgba.view(np.uint32) != rgba.view(np.uint32)).any(axis=2).sum())
+        assert nd == 0, (seed, tail, nd)
