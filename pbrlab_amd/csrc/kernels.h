@@ -46,11 +46,17 @@ enum : uint32_t {
   kStatTailClosestRays, kStatTailShadowRays, kStatNum
 };
 
+// Resident 256-thread blocks per CU of the persistent traversal kernel = waves per SIMD (VGPR budget 512 / waves).
+// Triangle-only scenes: 7 (<= 72 VGPRs; A/B on C2: 6 -> 48.4 ms, 7 -> 45.2, 8 spills -> 62.3).  Scenes with curves need
+// more registers: 6 (7 spills: C4 254 -> 434 ms).
 #ifndef PB_TRACE_BLOCKS
-#define PB_TRACE_BLOCKS 6
+#define PB_TRACE_BLOCKS 7
 #endif
-constexpr uint32_t kTraceBlocksPerCU = PB_TRACE_BLOCKS;  // resident 256-thread blocks per CU (VGPR/LDS budget)
-constexpr uint32_t kTraceGridCap = 256 * kTraceBlocksPerCU;        // persistent traversal: exactly the resident blocks
+#ifndef PB_TRACE_BLOCKS_CURVES
+#define PB_TRACE_BLOCKS_CURVES 6
+#endif
+constexpr uint32_t kTraceBlocksPerCU = PB_TRACE_BLOCKS, kTraceBlocksPerCUCurves = PB_TRACE_BLOCKS_CURVES;
+constexpr uint32_t kTraceGridCap = 256 * (kTraceBlocksPerCU > kTraceBlocksPerCUCurves ? kTraceBlocksPerCU : kTraceBlocksPerCUCurves);  // persistent traversal: at most the resident blocks (sizes the spill area)
 constexpr uint32_t kShadeGridCap = 256 * 8;
 constexpr int kMaxGroups = 8;  // concurrent path groups (one HIP stream each)
 

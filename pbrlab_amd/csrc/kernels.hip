@@ -102,7 +102,7 @@ struct TraceSink {
 };
 
 template <bool STATS, bool CURVES>
-__global__ __launch_bounds__(kBlock) void k_trace(PathState P, DScene sc) {
+__global__ __launch_bounds__(kBlock, (CURVES ? kTraceBlocksPerCUCurves : kTraceBlocksPerCU)) void k_trace(PathState P, DScene sc) {
   __shared__ uint32_t stk[kPvLdsStack * kBlock];
   const uint32_t n_closest = P.counts[kCntIn], n_shadow = P.counts[kCntShadowIn];
   TravStats st = {};
@@ -839,8 +839,9 @@ void launch_generate(hipStream_t s, const PathState& P, const Camera& cam, const
 void launch_trace(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, bool stats) {
   // persistent kernel: the resident set, unless there are so few rays that 4 per wave need fewer blocks
   uint32_t blocks = (n_upper + 15u) / 16u;
-  dim3 g(blocks < 1u ? 1u : (blocks < kTraceGridCap ? blocks : kTraceGridCap));
   const bool curves = sc.num_curves != 0;
+  const uint32_t cap = 256u * (curves ? kTraceBlocksPerCUCurves : kTraceBlocksPerCU);
+  dim3 g(blocks < 1u ? 1u : (blocks < cap ? blocks : cap));
   if (stats && curves) hipLaunchKernelGGL((k_trace<true, true>), g, dim3(kBlock), 0, s, P, sc);
   else if (stats) hipLaunchKernelGGL((k_trace<true, false>), g, dim3(kBlock), 0, s, P, sc);
   else if (curves) hipLaunchKernelGGL((k_trace<false, true>), g, dim3(kBlock), 0, s, P, sc);
