@@ -100,11 +100,12 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
   uint32_t state = kStIdle, tag = 0;
   bool any_ray = (MODE == 1);
   V3 o(0.f), d(0.f), inv(0.f);
-  float tmin = 0.f, best_t = 0.f;
+  float tmin = 0.f;  // (the current tmax of the ray is hit.t)
   Hit hit = {0.f, 0.f, 0.f, kNone};
   int sp = 0;
   uint32_t cur = 0, end = 0;  // TRI/CURVE: slot cursor and end of the leaf
-  float4 D0 = make_float4(0, 0, 0, 0), D1 = D0, D2 = D0, D3 = D0;  // prefetched node / primitive slot
+  float4 D0 = make_float4(0, 0, 0, 0), D1 = D0, D2 = D0;  // prefetched node / primitive slot
+  float2 D3 = make_float2(0, 0);                           // a node's two child references
 
   for (;;) {
     unsigned long long idle_mask = __ballot(state == kStIdle || state >= kStDone);
@@ -134,7 +135,6 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
         bool a = sink.load(batch_cur + rank, tag, o, d, tmin, tmax);
         any_ray = (MODE == 1) || (MODE == 2 && a);
         inv = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-        best_t = tmax;
         hit.t = tmax, hit.u = 0.f, hit.v = 0.f, hit.slot = kNone;
         sp = 0;
         advance = true, have_next = true, next = 0u;  // root is always an internal node
@@ -162,7 +162,7 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
           uint32_t c0 = __float_as_uint(D3.x), c1 = __float_as_uint(D3.y);
           float t0, t1;
           bool h0, h1;
-          box_test2(D0, D1, D2, o, inv, tmin, best_t, h0, h1, t0, t1);
+          box_test2(D0, D1, D2, o, inv, tmin, hit.t, h0, h1, t0, t1);
           bool swap = h1 && (!h0 || t1 < t0);
           uint32_t nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
           advance = true;
@@ -188,14 +188,13 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
           bool ok;
           if (!CURVES || phase == 1) {
             if (STATS) (any_ray ? st.atris : st.tris)++;
-            ok = tri_test(ld3(D0), ld3(D1), ld3(D2), o, d, tmin, t, u, v) && (t <= best_t);
+            ok = tri_test(ld3(D0), ld3(D1), ld3(D2), o, d, tmin, t, u, v) && (t <= hit.t);
           } else {
             if (STATS) (any_ray ? st.acurves : st.curves)++;
-            ok = segment_test(D0, D1, __float_as_uint(D2.x), o, d, tmin, best_t, t, u, v);
+            ok = segment_test(D0, D1, __float_as_uint(D2.x), o, d, tmin, hit.t, t, u, v);
           }
-          if (ok && !any_ray && t == best_t && hit.slot != kNone) ok = sc.shade[cur].gid < sc.shade[hit.slot].gid;
+          if (ok && !any_ray && t == hit.t && hit.slot != kNone) ok = sc.shade[cur].gid < sc.shade[hit.slot].gid;
           if (ok) {
-            best_t = t;
             hit.t = t, hit.u = u, hit.v = v, hit.slot = cur;
           }
           if (any_ray && ok) {
@@ -234,7 +233,7 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
     if (need_load) {
       const float4* g = (state == kStNode) ? reinterpret_cast<const float4*>(sc.nodes + cur) : (sc.slots + (size_t)cur * 4);
       D0 = g[0], D1 = g[1], D2 = g[2];
-      if (state == kStNode) D3 = g[3];
+      if (state == kStNode) D3 = *reinterpret_cast<const float2*>(g + 3);
     }
   }
   if (state >= kStDone) sink.done(tag, hit, state == kStDoneOccluded);  // rays that finished after the queue ran dry
