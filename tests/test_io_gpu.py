@@ -95,6 +95,12 @@ def test_cli_end_to_end(pa, name, with_hair, tmp_path):
                         "--gpus", "2"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert np.array_equal(io_api.png_decode(open(out2, "rb").read()), got)
+    # --bvh gpu: the tree built on the GPU renders the same file contents
+    out3 = os.path.join(d, "out3.png")
+    r = subprocess.run([io_api.CLI_PATH] + files + ["--width", str(W), "--height", str(H), "--spp", str(SPP), "--out", out3,
+                        "--bvh", "gpu"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert np.array_equal(io_api.png_decode(open(out3, "rb").read()), got)
 
 
 def test_cli_defaults_and_errors(pa, tmp_path):
