@@ -826,13 +826,16 @@ static inline int prim_test(const orc_scene* s, uint32_t gid, f3 o, f3 d, float 
   return 1;
 }
 
-/* conservative slab test: the interval is widened by 2^-16 relative before comparing */
+/* conservative slab test: the box is widened by 2^-16 relative in space (a ray parallel to an axis with its origin exactly
+ * on a face of the tight box would give 0 * inf = NaN and be rejected) and the interval by 2^-16 relative before comparing */
+static inline float box_lo(float v) { return v - (fabsf(v) * 1.52587890625e-05f + 1e-30f); }
+static inline float box_hi(float v) { return v + (fabsf(v) * 1.52587890625e-05f + 1e-30f); }
 static inline int box_test(const float lo[3], const float hi[3], f3 o, f3 inv, float tmin, float tmax, float* tnear) {
-  float t0 = (lo[0] - o.x) * inv.x, t1 = (hi[0] - o.x) * inv.x;
+  float t0 = (box_lo(lo[0]) - o.x) * inv.x, t1 = (box_hi(hi[0]) - o.x) * inv.x;
   float a = fminf(t0, t1), b = fmaxf(t0, t1);
-  t0 = (lo[1] - o.y) * inv.y, t1 = (hi[1] - o.y) * inv.y;
+  t0 = (box_lo(lo[1]) - o.y) * inv.y, t1 = (box_hi(hi[1]) - o.y) * inv.y;
   a = fmaxf(a, fminf(t0, t1)), b = fminf(b, fmaxf(t0, t1));
-  t0 = (lo[2] - o.z) * inv.z, t1 = (hi[2] - o.z) * inv.z;
+  t0 = (box_lo(lo[2]) - o.z) * inv.z, t1 = (box_hi(hi[2]) - o.z) * inv.z;
   a = fmaxf(a, fminf(t0, t1)), b = fminf(b, fmaxf(t0, t1));
   a = a - fabsf(a) * 1.52587890625e-05f;
   b = b + fabsf(b) * 1.52587890625e-05f;

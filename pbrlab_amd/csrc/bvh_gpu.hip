@@ -153,7 +153,11 @@ __global__ void k_lbvh_emit(int n, const uint32_t* __restrict__ left, const uint
   uint32_t ref[2];
   for (int c = 0; c < 2; c++) {
     const uint32_t k = ch[c];
-    for (int a = 0; a < 3; a++) nd.lo[a][c] = box[6 * (size_t)k + a], nd.hi[a][c] = box[6 * (size_t)k + 3 + a];
+    for (int a = 0; a < 3; a++) {  // stored widened, like BvhNode::set_box
+      const float l = box[6 * (size_t)k + a], h = box[6 * (size_t)k + 3 + a];
+      nd.lo[a][c] = l - (fabsf(l) * 1.52587890625e-05f + 1e-30f);
+      nd.hi[a][c] = h + (fabsf(h) * 1.52587890625e-05f + 1e-30f);
+    }
     uint32_t f, cnt;
     if (k >= (uint32_t)(n - 1)) f = k - (uint32_t)(n - 1), cnt = 1u;
     else f = first[k], cnt = last[k] - first[k] + 1u;

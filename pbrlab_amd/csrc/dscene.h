@@ -11,6 +11,7 @@
 //   textures   float pixel pool + descriptor table (bilinear, clamp addressing)
 //   lights     per-light and per-light-primitive sampling tables (LightManager::Commit)
 #pragma once
+#include <math.h>
 
 #include "dclosures.h"
 
@@ -36,8 +37,14 @@ struct alignas(16) BvhNode {
   float hi[3][2];
   uint32_t c0, c1;
   uint32_t pad[2];
+  // Boxes are stored widened by 2^-16 relative (+ a denormal-sized absolute step) on every side.  A ray parallel to an
+  // axis whose origin lies exactly ON a face of the tight box would otherwise produce 0 * inf = NaN in the slab test and
+  // be rejected although it can hit the primitive; with the stored faces strictly outside the geometry that product is
+  // -inf / +inf (no constraint), and a ray that is exactly on a stored face is too far from the geometry to hit it.
+  static float widen_lo(float v) { return v - (fabsf(v) * 1.52587890625e-05f + 1e-30f); }
+  static float widen_hi(float v) { return v + (fabsf(v) * 1.52587890625e-05f + 1e-30f); }
   void set_box(int child, const float* l, const float* h) {
-    for (int a = 0; a < 3; a++) lo[a][child] = l[a], hi[a][child] = h[a];
+    for (int a = 0; a < 3; a++) lo[a][child] = widen_lo(l[a]), hi[a][child] = widen_hi(h[a]);
   }
 };
 static_assert(sizeof(BvhNode) == 64, "node must be 64 B");

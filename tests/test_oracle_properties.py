@@ -26,6 +26,26 @@ def test_bvh_equals_brute_force(small):
     assert sh.trace_closest(rays).tobytes() == sh.trace_closest(rays, brute_force=True).tobytes()
 
 
+def test_axis_aligned_rays_through_vertices(small):
+    """Rays parallel to an axis whose origin coordinates equal a vertex's (so they lie exactly ON faces of the tight
+    boxes: 0 * inf in a naive slab test): the tree must not lose the hits the brute-force loop finds."""
+    d, so = small
+    rng = np.random.RandomState(4)
+    v = d.vertices[rng.randint(len(d.vertices), size=1500), :3]
+    r = np.zeros(1500, O.RAY_DT)
+    axis = rng.randint(3, size=1500)
+    sign = rng.choice([-1.0, 1.0], size=1500).astype(np.float32)
+    dirs = np.zeros((1500, 3), np.float32)
+    dirs[np.arange(1500), axis] = sign
+    r["org"] = v - dirs * np.float32(3.0)
+    r["dir"] = dirs
+    r["tmin"], r["tmax"] = 0.0, 1e30
+    a, b = so.trace_closest(r), so.trace_closest(r, brute_force=True)
+    assert (b["instance_id"] != 0xFFFFFFFF).sum() > 700
+    assert a.tobytes() == b.tobytes()
+    assert np.array_equal(so.trace_any(r), so.trace_any(r, brute_force=True))
+
+
 def test_hit_conventions(small):
     """tmin < t <= tmax; miss = ids 0xFFFFFFFF with TraceResult defaults (raytracer.h:9-17)."""
     d, so = small
