@@ -378,3 +378,46 @@ def test_triangle_soup_and_ties(pa, seed):
         short = rays.copy()
         short["tmax"] = np.where(np.isfinite(ho["t"]) & (ho["instance_id"] != 0xFFFFFFFF), ho["t"], 1.0)    # tmax == hit distance: accepted (t <= tmax)
         assert np.array_equal(sg.trace_any(short), so.trace_any(short))
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_curve_soup(pa, seed):
+    """Random cubic ribbons incl. duplicates, degenerate (all control points equal), zero-radius and straight ones, with a
+    few triangles mixed in; random rays and axis-aligned rays aimed at control points.  Oracle brute force (whole-curve
+    test) == oracle tree == GPU trees over the per-piece primitives (SAH and LBVH)."""
+    from pbrlab_amd import scenes
+    rng = np.random.RandomState(900 + seed)
+    nc = 300
+    cp = (rng.rand(nc, 4, 4).astype(np.float32) * 2 - 1)
+    cp[:, 1:, :3] = cp[:, :1, :3] + np.cumsum((rng.rand(nc, 3, 3).astype(np.float32) - 0.5) * np.float32(0.3), axis=1)
+    cp[..., 3] = np.float32(0.004) + rng.rand(nc, 4).astype(np.float32) * np.float32(0.03)
+    cp[:20] = cp[20:40]                                     # duplicates
+    cp[40:50, 1:] = cp[40:50, :1]                           # degenerate: a point
+    cp[50:60, :, 3] = 0.0                                   # zero radius
+    cp[60:70, 1:, :3] = cp[60:70, :1, :3] + np.arange(1, 4, dtype=np.float32)[None, :, None] * np.float32(0.1)   # straight
+    cp[70:90, :, :3] = np.round(cp[70:90, :, :3] * 8) / 8   # grid-aligned control points
+    curve = scenes.CurveShape("c", cp.reshape(-1, 4), (np.arange(nc, dtype=np.uint32) * 4))
+    tv = np.array([[-1, -1, -0.9, 1], [1, -1, -0.9, 1], [1, 1, -0.9, 1], [-1, 1, -0.9, 1]], np.float32)
+    mat = dict(scenes.PRINCIPLED_DEFAULTS, kind="principled", name="m")
+    desc = scenes.SceneDesc(tv, np.zeros((0, 4), np.float32), [mat],
+                            [scenes.Shape("back", np.array([[0, 1, 2], [0, 2, 3]], np.uint32), None, np.zeros(2, np.uint32))], [curve])
+    so = O.oracle_scene_from_desc(desc)
+    lo, hi = so.FetchSceneAABB()
+    rays = scenes.random_rays((lo, hi), 5000, seed=seed)
+    extra = np.zeros(1500, O.RAY_DT)
+    tgt = cp.reshape(-1, 4)[rng.randint(nc * 4, size=1500), :3]
+    axis = rng.randint(3, size=1500)
+    dirs = np.zeros((1500, 3), np.float32)
+    dirs[np.arange(1500), axis] = rng.choice([-1.0, 1.0], size=1500)
+    extra["org"], extra["dir"] = tgt - dirs * np.float32(2.5), dirs
+    extra["tmin"], extra["tmax"] = 0.0, 1e30
+    rays = np.concatenate([rays, extra])
+    hb = so.trace_closest(rays, brute_force=True)
+    assert_hits_equal(so.trace_closest(rays), hb)
+    assert ((hb["instance_id"] == 1)).sum() > 300          # the curve instance is hit often
+    for builder in (pa.api.BVH_HOST_SAH, pa.api.BVH_GPU_LBVH):
+        sg = pa.scene_from_desc(desc, bvh_builder=builder)
+        assert_hits_equal(sg.trace_closest(rays), hb)
+        short = rays.copy()
+        short["tmax"] = np.where(hb["instance_id"] != 0xFFFFFFFF, hb["t"], 1.0)
+        assert np.array_equal(sg.trace_any(short), so.trace_any(short, brute_force=True))
