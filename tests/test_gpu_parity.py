@@ -421,3 +421,52 @@ def test_curve_soup(pa, seed):
         short = rays.copy()
         short["tmax"] = np.where(hb["instance_id"] != 0xFFFFFFFF, hb["t"], 1.0)
         assert np.array_equal(sg.trace_any(short), so.trace_any(short, brute_force=True))
+
+
+def _mini_scene(shapes_spec, materials):
+    """shapes_spec: list of (name, verts (n,3), faces (m,3), material index)"""
+    from pbrlab_amd import scenes
+    vs, shapes, base = [], [], 0
+    for name, v, f, mi in shapes_spec:
+        v = np.asarray(v, np.float32)
+        f = np.asarray(f, np.uint32)
+        vs.append(np.concatenate([v, np.ones((len(v), 1), np.float32)], 1))
+        shapes.append(scenes.Shape(name, f + np.uint32(base), None, np.full(len(f), mi, np.uint32)))
+        base += len(v)
+    return scenes.SceneDesc(np.concatenate(vs), np.zeros((0, 4), np.float32), materials, shapes)
+
+
+@pytest.mark.parametrize("case", ["no_light", "light_only", "degenerate_light", "huge_emission_tiny_light", "black_materials"])
+def test_degenerate_scenes_render_parity(pa, case):
+    """scenes at the edges of the light tables and of the throughput arithmetic: no emitter at all, nothing but an emitter, an
+    emitter with a zero-area triangle, a pin-point emitter (huge pdf), all-black materials -- image == oracle, bit for bit"""
+    from pbrlab_amd import scenes
+    m = lambda **kw: dict(scenes.PRINCIPLED_DEFAULTS, kind="principled", name="m", **kw)     # noqa: E731
+    floor = ("floor", [[-1, -1, 1], [1, -1, 1], [1, -1, -1], [-1, -1, -1]], [[0, 1, 2], [0, 2, 3]], 0)
+    back = ("back", [[-1, -1, -1], [1, -1, -1], [1, 1, -1], [-1, 1, -1]], [[0, 1, 2], [0, 2, 3]], 0)
+    light = ("light", [[-0.3, 0.9, -0.3], [0.3, 0.9, -0.3], [0.3, 0.9, 0.3], [-0.3, 0.9, 0.3]], [[0, 1, 2], [0, 2, 3]], 1)
+    mats = [m(base_color=(0.7, 0.6, 0.5), specular=0.5, roughness=0.3), m(base_color=(0, 0, 0), specular=0.0)]
+    if case == "no_light":
+        desc = _mini_scene([floor, back, ("lamp", light[1], light[2], 1)], mats)          # not named light*: nothing emits
+    elif case == "light_only":
+        desc = _mini_scene([light], mats)
+    elif case == "degenerate_light":
+        lv = light[1] + [[0.3, 0.9, 0.3]]
+        desc = _mini_scene([floor, back, ("light", lv, [[0, 1, 2], [0, 2, 3], [2, 4, 2]], 1)], mats)   # third triangle has zero area
+    elif case == "huge_emission_tiny_light":
+        e = 1e-4
+        desc = _mini_scene([floor, back, ("light", [[-e, 0.9, -e], [e, 0.9, -e], [e, 0.9, e], [-e, 0.9, e]], light[2], 1)], mats)
+        desc.light_emission = (3e6, 2e6, 1e6)
+    else:
+        desc = _mini_scene([floor, back, light], [m(base_color=(0, 0, 0), specular=0.0), mats[1]])
+    so = O.oracle_scene_from_desc(desc)
+    sg = pa.scene_from_desc(desc)
+    rgba, cnt, _ = so.render(48, 40, 5, threads=4, math_mode=O.MATH_F64R)
+    for tail in (0, 0xFFFFFFFF):
+        layer = pa.RenderLayer()
+        pa.Render(sg, 48, 40, 5, layer=layer, tail_paths=tail)
+        assert np.array_equal(layer.count, cnt)
+        assert layer.rgba.tobytes() == rgba.tobytes() or np.array_equal(np.isnan(layer.rgba), np.isnan(rgba)) and \
+            np.array_equal(np.nan_to_num(layer.rgba).view(np.uint32), np.nan_to_num(rgba).view(np.uint32)), case
+    if case == "no_light":
+        assert not rgba[..., :3].any()
