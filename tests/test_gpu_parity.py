@@ -470,3 +470,39 @@ def test_degenerate_scenes_render_parity(pa, case):
             np.array_equal(np.nan_to_num(layer.rgba).view(np.uint32), np.nan_to_num(rgba).view(np.uint32)), case
     if case == "no_light":
         assert not rgba[..., :3].any()
+
+
+def test_multi_geometry_instances_and_duplicate_instances(pa):
+    """A local scene with two meshes (geometry ids 0 and 1) instantiated TWICE (exact duplicates: every hit is a tie that the
+    smaller instance id must win), lights attached to one geometry of one instance, materials overridden per instance."""
+    from pbrlab_amd import scenes
+    mats = [dict(scenes.PRINCIPLED_DEFAULTS, kind="principled", name="a", base_color=(0.8, 0.3, 0.2), specular=0.0),
+            dict(scenes.PRINCIPLED_DEFAULTS, kind="principled", name="b", base_color=(0.2, 0.7, 0.9), specular=1.0, roughness=0.2)]
+    quad = lambda z, s=1.0: np.array([[-s, -s, z, 1], [s, -s, z, 1], [s, s, z, 1], [-s, s, z, 1]], np.float32)   # noqa: E731
+    faces = np.array([[0, 1, 2], [0, 2, 3]], np.uint32)
+
+    def build(S, mk):
+        m0, m1 = S.AddMaterialParam(mk(mats[0])), S.AddMaterialParam(mk(mats[1]))
+        wall = S.AddTriangleMesh(quad(-1.0), None, None, faces, None, None, np.array([m0, m0], np.uint32))
+        lamp = S.AddTriangleMesh(quad(0.5, 0.25), None, None, faces[:, ::-1], None, None, np.array([m1, m1], np.uint32))
+        ls = S.CreateLocalScene()
+        assert S.AddMeshToLocalScene(ls, wall) == 0 and S.AddMeshToLocalScene(ls, lamp) == 1
+        i0, i1 = S.CreateInstance(ls, None), S.CreateInstance(ls, None)
+        lid = S.AddLightParam((5.0, 4.0, 3.0))
+        S.AttachLightParamIdsToInstance(i0, [np.full(2, 0xFFFFFFFF, np.uint32), np.full(2, lid, np.uint32)])
+        S.AttachMaterialParamIdsToInstance(i1, [np.array([m1, m1], np.uint32), np.array([m0, m0], np.uint32)])
+        S.CommitScene()
+        return S
+
+    sg = build(pa.Scene(), pa.make_principled)
+    so = build(O.OracleScene(), O.make_principled)
+    lo, hi = so.FetchSceneAABB()
+    rays = scenes.random_rays((lo, hi), 4000, seed=2)
+    hg, ho = sg.trace_closest(rays), so.trace_closest(rays, brute_force=True)
+    assert_hits_equal(hg, ho)
+    hit = hg["instance_id"] != 0xFFFFFFFF
+    assert hit.sum() > 500 and (hg["instance_id"][hit] == 0).all() and set(hg["geom_id"][hit]) == {0, 1}
+    rgba, cnt, _ = so.render(40, 40, 6, threads=4, math_mode=O.MATH_F64R)
+    layer = pa.RenderLayer()
+    pa.Render(sg, 40, 40, 6, layer=layer)
+    assert np.array_equal(layer.count, cnt) and layer.rgba.tobytes() == rgba.tobytes() and rgba[..., :3].max() > 0
