@@ -506,3 +506,21 @@ def test_multi_geometry_instances_and_duplicate_instances(pa):
     layer = pa.RenderLayer()
     pa.Render(sg, 40, 40, 6, layer=layer)
     assert np.array_equal(layer.count, cnt) and layer.rgba.tobytes() == rgba.tobytes() and rgba[..., :3].max() > 0
+
+
+def test_seeding_corners(pa, pairs):
+    """RNG((pass << 32) + y*W + x, seed_seq): very large pass indices, other stream selectors, ranks that own no tile"""
+    desc, sg, so = pairs["ggx"]
+    for first_pass, seed_seq in [(1 << 20, 1234567890), (0xFFFFFFF0, 1234567890), (3, 1), (0, 0xFFFFFFFFFFFFFFFF), (7, 0x0123456789ABCDEF)]:
+        rgba, cnt, _ = so.render(40, 24, 5, first_pass=first_pass, seed_seq=seed_seq, threads=4, math_mode=O.MATH_F64R)
+        layer = pa.RenderLayer()
+        pa.Render(sg, 40, 24, 5, layer=layer, first_pass=first_pass, seed_seq=seed_seq)
+        assert np.array_equal(layer.count, cnt) and layer.rgba.tobytes() == rgba.tobytes(), (first_pass, seed_seq)
+    a = pa.RenderLayer()
+    pa.Render(sg, 40, 24, 5, layer=a)
+    b = pa.RenderLayer()
+    pa.Render(sg, 40, 24, 5, layer=b, first_pass=1)
+    assert a.rgba.tobytes() != b.rgba.tobytes()                                   # different passes, different samples
+    empty = pa.RenderLayer()
+    ok, st = pa.Render(sg, 40, 24, 5, layer=empty, tile_rank=5, tile_world=9)     # one 64x64 tile only: rank 5 owns nothing
+    assert ok and not empty.rgba.any() and not empty.count.any() and st["samples"] == 0
