@@ -394,7 +394,7 @@ bool DecodePng(const uint8_t* file, size_t n, std::vector<uint8_t>* pixels, size
       if (len != 13) return *err = "bad IHDR", false;
       w = be32(data), h = be32(data + 4);
       depth = data[8], color = data[9], interlace = data[12];
-      if (w == 0 || h == 0 || w > (1u << 24) || h > (1u << 24)) return *err = "bad PNG size", false;
+      if (w == 0 || h == 0 || w > (1u << 24) || h > (1u << 24) || uint64_t(w) * h > (1ull << 28)) return *err = "bad PNG size", false;
       if (depth != 1 && depth != 2 && depth != 4 && depth != 8 && depth != 16) return *err = "bad PNG bit depth", false;
       if (color > 6 || color == 1 || color == 5) return *err = "bad PNG colour type", false;
       if (color == 3 && depth == 16) return *err = "bad PNG colour type", false;
@@ -537,7 +537,7 @@ bool DecodeHdr(const uint8_t* file, size_t n, std::vector<float>* pixels, size_t
   while (*rest == ' ') ++rest;
   if (strncmp(rest, "+X ", 3) != 0) return *err = "unsupported HDR data layout", false;
   const long ww = strtol(rest + 3, nullptr, 10);
-  if (ww <= 0 || hh <= 0 || ww > (1 << 24) || hh > (1 << 24)) return *err = "bad HDR size", false;
+  if (ww <= 0 || hh <= 0 || ww > (1 << 24) || hh > (1 << 24) || uint64_t(ww) * uint64_t(hh) > (1ull << 28)) return *err = "bad HDR size", false;
   const size_t w = size_t(ww), h = size_t(hh);
   pixels->assign(w * h * 3, 0.0f);
   auto convert = [&](float* out, const uint8_t* in) {  // stbi__hdr_convert, 3 channels
@@ -608,6 +608,11 @@ struct JpegHuff {
   uint8_t values[256];
   uint32_t maxcode[18];
   int delta[17];
+  JpegHuff() {  // a table the file never defines decodes nothing (every lookup ends at the sentinel)
+    memset(size, 0, sizeof(size)), memset(code, 0, sizeof(code)), memset(values, 0, sizeof(values));
+    memset(maxcode, 0, sizeof(maxcode)), memset(delta, 0, sizeof(delta));
+    maxcode[17] = 0xffffffffu;
+  }
   bool build(const int* count) {  // JPEG spec C.2 (stbi__build_huffman)
     int k = 0;
     for (int i = 0; i < 16; ++i)
@@ -764,10 +769,20 @@ void jpeg_idct(uint8_t* out, int stride, const short d[64]) {
   static const int c0 = f2f(0.5411961f), c1 = f2f(-1.847759065f), c2 = f2f(0.765366865f), c3 = f2f(1.175875602f),
                    c4 = f2f(0.298631336f), c5 = f2f(2.053119869f), c6 = f2f(3.072711026f), c7 = f2f(1.501321110f),
                    c8 = f2f(-0.899976223f), c9 = f2f(-2.562915447f), c10 = f2f(-1.961570560f), c11 = f2f(-0.390180644f);
+  // 32-bit arithmetic that wraps instead of overflowing (identical on valid files; corrupt coefficients must not be UB)
+  struct W {
+    int v;
+    W() : v(0) {}
+    W(int x) : v(x) {}
+    explicit operator int() const { return v; }
+    W operator+(W o) const { return W(int(uint32_t(v) + uint32_t(o.v))); }
+    W operator-(W o) const { return W(int(uint32_t(v) - uint32_t(o.v))); }
+    W operator*(W o) const { return W(int(uint32_t(v) * uint32_t(o.v))); }
+    W& operator+=(W o) { return *this = *this + o; }
+  };
   int val[64];
-  auto pass = [&](int s0, int s1, int s2, int s3, int s4, int s5, int s6, int s7, int& x0, int& x1, int& x2, int& x3, int& t0,
-                  int& t1, int& t2, int& t3) {
-    int p1, p2, p3, p4, p5;
+  auto pass = [&](W s0, W s1, W s2, W s3, W s4, W s5, W s6, W s7, W& x0, W& x1, W& x2, W& x3, W& t0, W& t1, W& t2, W& t3) {
+    W p1, p2, p3, p4, p5;
     p2 = s2, p3 = s6;
     p1 = (p2 + p3) * c0;
     t2 = p1 + p3 * c1;
@@ -790,22 +805,22 @@ void jpeg_idct(uint8_t* out, int stride, const short d[64]) {
       const int dc = c[0] * 4;
       v[0] = v[8] = v[16] = v[24] = v[32] = v[40] = v[48] = v[56] = dc;
     } else {
-      int x0, x1, x2, x3, t0, t1, t2, t3;
+      W x0, x1, x2, x3, t0, t1, t2, t3;
       pass(c[0], c[8], c[16], c[24], c[32], c[40], c[48], c[56], x0, x1, x2, x3, t0, t1, t2, t3);
       x0 += 512, x1 += 512, x2 += 512, x3 += 512;
-      v[0] = (x0 + t3) >> 10, v[56] = (x0 - t3) >> 10, v[8] = (x1 + t2) >> 10, v[48] = (x1 - t2) >> 10;
-      v[16] = (x2 + t1) >> 10, v[40] = (x2 - t1) >> 10, v[24] = (x3 + t0) >> 10, v[32] = (x3 - t0) >> 10;
+      v[0] = int(x0 + t3) >> 10, v[56] = int(x0 - t3) >> 10, v[8] = int(x1 + t2) >> 10, v[48] = int(x1 - t2) >> 10;
+      v[16] = int(x2 + t1) >> 10, v[40] = int(x2 - t1) >> 10, v[24] = int(x3 + t0) >> 10, v[32] = int(x3 - t0) >> 10;
     }
   }
   for (int i = 0; i < 8; ++i) {
     const int* v = val + i * 8;
     uint8_t* o = out + i * stride;
-    int x0, x1, x2, x3, t0, t1, t2, t3;
+    W x0, x1, x2, x3, t0, t1, t2, t3;
     pass(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], x0, x1, x2, x3, t0, t1, t2, t3);
     const int bias = 65536 + (128 << 17);
     x0 += bias, x1 += bias, x2 += bias, x3 += bias;
-    o[0] = clamp255((x0 + t3) >> 17), o[7] = clamp255((x0 - t3) >> 17), o[1] = clamp255((x1 + t2) >> 17), o[6] = clamp255((x1 - t2) >> 17);
-    o[2] = clamp255((x2 + t1) >> 17), o[5] = clamp255((x2 - t1) >> 17), o[3] = clamp255((x3 + t0) >> 17), o[4] = clamp255((x3 - t0) >> 17);
+    o[0] = clamp255(int(x0 + t3) >> 17), o[7] = clamp255(int(x0 - t3) >> 17), o[1] = clamp255(int(x1 + t2) >> 17), o[6] = clamp255(int(x1 - t2) >> 17);
+    o[2] = clamp255(int(x2 + t1) >> 17), o[5] = clamp255(int(x2 - t1) >> 17), o[3] = clamp255(int(x3 + t0) >> 17), o[4] = clamp255(int(x3 - t0) >> 17);
   }
 }
 
@@ -964,7 +979,7 @@ bool DecodeJpeg(const uint8_t* file, size_t n, std::vector<uint8_t>* pixels, siz
     if (Lf < 11) return bail("bad SOF length");
     if (z.get8() != 8) return bail("JPEG: only 8 bits per sample");
     z.img_y = z.get16(), z.img_x = z.get16();
-    if (z.img_y == 0 || z.img_x == 0) return bail("bad JPEG size");
+    if (z.img_y == 0 || z.img_x == 0 || uint64_t(z.img_x) * uint64_t(z.img_y) > (1ull << 28)) return bail("bad JPEG size");
     const int c = z.get8();
     if (c != 3 && c != 1 && c != 4) return bail("bad JPEG component count");
     z.img_n = c;
@@ -1259,7 +1274,7 @@ bool DecodeExr(const uint8_t* file, size_t n, std::vector<float>* pixels, size_t
   if (compression > 3) return *err = "OpenEXR compression PIZ / PXR24 / B44 is not decoded by this build (use ZIP)", false;
   if (dw[2] < dw[0] || dw[3] < dw[1]) return *err = "bad OpenEXR data window", false;
   const size_t w = size_t(dw[2] - dw[0]) + 1, h = size_t(dw[3] - dw[1]) + 1;
-  if (w > (1u << 24) || h > (1u << 24)) return *err = "bad OpenEXR data window", false;
+  if (w > (1u << 24) || h > (1u << 24) || uint64_t(w) * h > (1ull << 28)) return *err = "bad OpenEXR data window", false;
   size_t pixel_bytes = 0;
   for (ExrChannel& c : ch) {
     if (c.type != 1 && c.type != 2) return *err = "UINT OpenEXR channels are not decoded", false;

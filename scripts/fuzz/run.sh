@@ -1,0 +1,12 @@
+#!/bin/bash
+# AddressSanitizer + UBSan mutation fuzz of the standalone readers (CPU only; sanitizers cannot run on the GPU pool).
+# usage: scripts/fuzz/run.sh [mutations per seed file, default 300]
+set -e
+here=$(cd $(dirname $0) && pwd); io=$here/../../pbrlab_amd/csrc/io; gold=$here/../../tests/golden/io
+mkdir -p /tmp/pbrio_fuzz
+g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=undefined -I$io -I$here/../../include $here/readers_fuzz.cpp \
+    $io/obj_reader.cpp $io/hair_reader.cpp $io/image_codec.cpp -o /tmp/pbrio_fuzz/fuzz
+printf 'mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nusemtl A\nf 1 2 3\n' > /tmp/pbrio_fuzz/host.obj
+cd $gold && /tmp/pbrio_fuzz/fuzz ${1:-300} tex0.png tex3.png tex5.png tex8.png tex10.png tex12.png photo0.jpg photo1.jpg photo3.jpg \
+    photo4.jpg photo6.jpg photo7.jpg env0.exr env1.exr env2.exr env3.exr env5.exr env0.hdr env1.hdr env2.hdr case0.obj case5.obj \
+    case11.obj strands0.hair strands1.hair strands3.hair strands4.hair
