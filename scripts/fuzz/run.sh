@@ -10,3 +10,8 @@ printf 'mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nusemtl A\nf 1 2 3\n' > /tmp/pbr
 cd $gold && /tmp/pbrio_fuzz/fuzz ${1:-300} tex0.png tex3.png tex5.png tex8.png tex10.png tex12.png photo0.jpg photo1.jpg photo3.jpg \
     photo4.jpg photo6.jpg photo7.jpg env0.exr env1.exr env2.exr env3.exr env5.exr env0.hdr env1.hdr env2.hdr case0.obj case5.obj \
     case11.obj strands0.hair strands1.hair strands3.hair strands4.hair
+# host SAH builder: random / degenerate primitive sets, structural validation of the flattened tree
+cs=$here/../../pbrlab_amd/csrc
+/opt/rocm/bin/hipcc --offload-host-only -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=undefined -I$cs -I$here/../../include \
+    $here/bvh_check.cpp $cs/bvh_build.cpp -o /tmp/pbrio_fuzz/bvh_check -lpthread
+/tmp/pbrio_fuzz/bvh_check
