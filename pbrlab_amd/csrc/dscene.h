@@ -65,9 +65,13 @@ struct alignas(128) ShadeRec {
 };
 static_assert(sizeof(ShadeRec) == 128, "one cache line per primitive");
 
-// hit record code (P.hit[].w): slot | kind << 28 ; kNone = miss
+// hit record code (Hit::slot, P.hit[].w): slot | routing bits; kNone = miss.  The routing bits are stored with the
+// primitive's traversal data (.w of the third 16-byte word of its slot), so a hit can be routed (k_classify) without
+// touching the primitive's ShadeRec line.
 constexpr uint32_t kHitSlotMask = 0x0FFFFFFFu;
-constexpr uint32_t kHitKindPrincipled = 0u, kHitKindHair = 1u, kHitKindNoMaterial = 2u;
+constexpr uint32_t kHitHair = 1u << 28;        // hair material (== kSlotMatHair)
+constexpr uint32_t kHitLight = 1u << 29;       // the primitive is an area-light primitive (lightrec != kNone)
+constexpr uint32_t kHitNoMaterial = 1u << 30;  // == kSlotMatNone
 
 // closure set of one material == struct CyclesPrincipledBsdf (cycles-principled-shader.cc:20-45)
 struct PrincipledBsdf {

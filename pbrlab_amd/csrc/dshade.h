@@ -21,7 +21,7 @@ struct Surface {
 // Reads ONE 128-byte ShadeRec line (plus the 64-byte control-point slot for curves).
 __device__ __forceinline__ Surface make_surface(const DScene& sc, V3 org, V3 dir, const Hit& h, uint32_t* instance_id = nullptr) {
   Surface s;
-  const float4* r = reinterpret_cast<const float4*>(sc.shade + h.slot);
+  const float4* r = reinterpret_cast<const float4*>(sc.shade + (h.slot & kHitSlotMask));
   float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5];
   // words: v[0..8] n[9..17] gid(18) material(19) lightrec(20) flags(21) instance(22) geom(23) prim(24)
   s.material = __float_as_uint(r4.w), s.lightrec = __float_as_uint(r5.x), s.flags = __float_as_uint(r5.y);

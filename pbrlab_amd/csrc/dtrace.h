@@ -127,10 +127,10 @@ __device__ __forceinline__ bool leaf_test(const DScene& sc, uint32_t leaf, V3 o,
     if (!ok) continue;
     if (ANY) return true;
     if (t == best_t && hit.slot != kNone) {  // tie: the smaller canonical primitive id wins
-      if (!(sc.shade[s].gid < sc.shade[hit.slot].gid)) continue;
+      if (!(sc.shade[s].gid < sc.shade[hit.slot & kHitSlotMask].gid)) continue;
     }
     best_t = t;
-    hit.t = t, hit.u = u, hit.v = v, hit.slot = s;
+    hit.t = t, hit.u = u, hit.v = v, hit.slot = s | __float_as_uint(g[2].w);  // + routing bits (dscene.h)
   }
   return false;
 }

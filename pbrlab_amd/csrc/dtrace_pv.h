@@ -193,9 +193,9 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
             if (STATS) (any_ray ? st.acurves : st.curves)++;
             ok = segment_test(D0, D1, __float_as_uint(D2.x), o, d, tmin, hit.t, t, u, v);
           }
-          if (ok && !any_ray && t == hit.t && hit.slot != kNone) ok = sc.shade[cur].gid < sc.shade[hit.slot].gid;
+          if (ok && !any_ray && t == hit.t && hit.slot != kNone) ok = sc.shade[cur].gid < sc.shade[hit.slot & kHitSlotMask].gid;
           if (ok) {
-            hit.t = t, hit.u = u, hit.v = v, hit.slot = cur;
+            hit.t = t, hit.u = u, hit.v = v, hit.slot = cur | __float_as_uint(D2.w);  // + routing bits (dscene.h)
           }
           if (any_ray && ok) {
             state = kStDoneOccluded;

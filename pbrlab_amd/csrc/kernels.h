@@ -30,7 +30,8 @@ struct PathState {
 };
 
 enum : uint32_t { kFlagNotFirst = 1u };
-constexpr uint32_t kQSssBit = 0x80000000u, kQPathMask = 0x7FFFFFFFu;  // queue entry = path slot | in-medium bit
+// queue entry = path slot | in-medium bit | "the Russian roulette at the head of this path's next shading fails" bit
+constexpr uint32_t kQSssBit = 0x80000000u, kQDoomed = 0x40000000u, kQPathMask = 0x0FFFFFFFu;
 // shade-kernel result word (written over the kernel's own queue entry): path slot (28 bits) | flags
 constexpr uint32_t kRPathMask = 0x0FFFFFFFu, kRShadow = 1u << 28, kRAlive = 1u << 29;
 constexpr uint64_t kMaxPathsInFlight = (1ull << 28) - 1;

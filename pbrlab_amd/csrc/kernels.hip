@@ -179,6 +179,10 @@ struct TileCompactor {
 // Queue entries are path slots; bit 31 marks a path that is inside a medium (random-walk SSS).
 // Routes every traced path: in-medium -> q_sss; miss -> dropped (render.cc:34, no environment light);
 // hit -> q_hair / q_principled by the material kind denormalised into ShadeRec.flags.
+// A hit path whose next Russian roulette (render.cc:66-68) is known to fail (kQDoomed: the shading that continued the
+// path already knew the throughput and the generator state the roulette will use) and whose hit primitive is no light
+// ends at the head of its shading without storing anything (path_head returns false), so it is dropped here instead of
+// idling in a shading wave; likewise a hit on a primitive without material.  The routing bits come with the hit code.
 __global__ __launch_bounds__(kBlock) void k_classify(PathState P, DScene sc) {
   __shared__ uint32_t wcount[3][kItemsPerThread][kWavesPerBlock];
   __shared__ uint32_t base[3];
@@ -188,21 +192,24 @@ __global__ __launch_bounds__(kBlock) void k_classify(PathState P, DScene sc) {
   uint32_t* const queues[3] = {P.q_sss, P.q_principled, P.q_hair};
   for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     uint32_t p[kItemsPerThread], dest[kItemsPerThread];
+    bool doomed[kItemsPerThread];
 #pragma unroll
     for (int j = 0; j < kItemsPerThread; j++) {
       uint32_t i = tile * kTileItems + j * kBlock + threadIdx.x;
-      dest[j] = 0, p[j] = 0;
+      dest[j] = 0, p[j] = 0, doomed[j] = false;
       if (i < n) {
         uint32_t e = P.q_in[i];
         p[j] = e & kQPathMask;
         dest[j] = (e & kQSssBit) ? 1u : 0xFFu;
+        doomed[j] = (e & kQDoomed) != 0u;
       }
     }
 #pragma unroll
     for (int j = 0; j < kItemsPerThread; j++)
       if (dest[j] == 0xFFu) {
-        uint32_t slot = __float_as_uint(P.hit[p[j]].w);
-        dest[j] = (slot == kNone) ? 0u : ((sc.shade[slot].flags & kSlotMatHair) ? 3u : 2u);
+        const uint32_t code = __float_as_uint(P.hit[p[j]].w);
+        dest[j] = (code & kHitHair) ? 3u : 2u;
+        if (code == kNone || (!(code & kHitLight) && (doomed[j] || (code & kHitNoMaterial)))) dest[j] = 0u;
       }
     TileCompactor<3> tc = {wcount, base, {}};
     tc.run(dest, counters);
@@ -214,7 +221,7 @@ __global__ __launch_bounds__(kBlock) void k_classify(PathState P, DScene sc) {
 }
 
 // ------------------------------------------------------------------ k_compact
-// The shade kernels overwrite their queue entry with  path | kRShadow | kRAlive | kQSssBit  instead of
+// The shade kernels overwrite their queue entry with  path | kRShadow | kRAlive | kQSssBit | kQDoomed  instead of
 // appending; this pass turns the three result lists into the next trace queue and the shadow-ray queue.
 __global__ __launch_bounds__(kBlock) void k_compact(PathState P) {
   __shared__ uint32_t wcount[2][kItemsPerThread][kWavesPerBlock];
@@ -242,7 +249,7 @@ __global__ __launch_bounds__(kBlock) void k_compact(PathState P) {
       ta.run(dest, counters);
 #pragma unroll
       for (int j = 0; j < kItemsPerThread; j++)
-        if (dest[j]) P.q_out[ta.slot(j, 1u)] = e[j] & (kRPathMask | kQSssBit);
+        if (dest[j]) P.q_out[ta.slot(j, 1u)] = e[j] & (kRPathMask | kQSssBit | kQDoomed);
       __syncthreads();
     }
     {
@@ -292,6 +299,14 @@ __device__ __forceinline__ bool path_head(const PathState& P, const DScene& sc, 
   return (c.s.flags & kSlotMatNone) == 0;  // shader.cc:11-17: no material -> throughput 0 -> path ends
 }
 
+// kQDoomed for a path that continues with throughput `thr` and generator state `state`: the head of its next shading
+// draws once from that state and ends the path when max(thr) < u (path_head; render.cc:66-68)
+__device__ __forceinline__ uint32_t doomed_bit(V3 thr, uint64_t state, uint64_t rng_inc) {
+  Rng r;
+  r.state = state, r.inc = rng_inc;
+  return spectrum_norm(thr) < draw(r) ? kQDoomed : 0u;
+}
+
 // writes one shadow-queue entry
 __device__ __forceinline__ void put_shadow(const PathState& P, V3 pos, const Nee& n, V3 c_vis, V3 c_occ, uint32_t p,
                                            uint32_t mode) {
@@ -305,7 +320,7 @@ __device__ __forceinline__ void put_shadow(const PathState& P, V3 pos, const Nee
 
 // ------------------------------------------------------------------ k_shade_principled
 // CyclesPrincipledShader (cycles-principled-shader.cc:414-484) + the tail of GetRadiance (render.cc:76-87).
-// One path; returns the result bits (kRShadow | kRAlive | kQSssBit) its caller stores or acts on.
+// One path; returns the result bits (kRShadow | kRAlive | kQSssBit | kQDoomed) its caller stores or acts on.
 __device__ __forceinline__ uint32_t shade_principled_path(const PathState& P, const DScene& sc, uint32_t p, uint64_t rng_inc) {
   {
     const bool active = true;
@@ -392,7 +407,7 @@ __device__ __forceinline__ uint32_t shade_principled_path(const PathState& P, co
               P.ray_o[p] = mk4(s.pos, 1e-3f);
               P.ray_d[p] = mk4(gdir, t_scatter);
               P.sss_sigt[p] = mk4(sigt, __uint_as_float(0u));                      // .w = bounce index
-              P.sss_sigs[p] = mk4(sigs, __uint_as_float(sc.shade[h.slot].instance_id));  // .w = entry instance id
+              P.sss_sigs[p] = mk4(sigs, __uint_as_float(sc.shade[h.slot & kHitSlotMask].instance_id));  // .w = entry instance id
               P.sss_thr[p] = mk4(wthr, 0.f);
               P.sss_pdf[p] = mk4(chpdf, 0.f);
               P.sss_ez[p] = mk4(fr.ez, 0.f);
@@ -432,6 +447,7 @@ __device__ __forceinline__ uint32_t shade_principled_path(const PathState& P, co
             P.thr[p] = mk4(t2, new_pdf);
             P.rng[p] = rng.state;
             P.flags[p] = c.flags;
+            qbit = doomed_bit(t2, rng.state, rng_inc);
           }
         }
       }
@@ -456,6 +472,7 @@ __device__ __forceinline__ uint32_t shade_hair_path(const PathState& P, const DS
   {
     const bool active = true;
     bool alive = false, shadow = false;
+    uint32_t qbit = 0u;
     V3 sh_pos(0.f), c_vis(0.f);
     Nee nee;
     nee.dir = V3(0.f), nee.emission = V3(0.f), nee.dist = 0.f, nee.pdf_sigma = 0.f;
@@ -505,11 +522,12 @@ __device__ __forceinline__ uint32_t shade_hair_path(const PathState& P, const DS
           P.thr[p] = mk4(t2, pdf);
           P.rng[p] = rng.state;
           P.flags[p] = c.flags;
+          qbit = doomed_bit(t2, rng.state, rng_inc);
         }
       }
     }
     if (shadow) put_shadow(P, sh_pos, nee, c_vis, V3(0.f), p, kShNormal);
-    return (shadow ? kRShadow : 0u) | (alive ? kRAlive : 0u);
+    return (shadow ? kRShadow : 0u) | (alive ? kRAlive : 0u) | qbit;
   }
 }
 __global__ __launch_bounds__(kBlock) void k_shade_hair(PathState P, DScene sc, uint64_t rng_inc) {
@@ -641,6 +659,7 @@ __device__ __forceinline__ uint32_t sss_step_path(const PathState& P, const DSce
             P.ray_d[p] = mk4(next_dir, kInf);
             P.thr[p] = mk4(t2, pdf);
             P.rng[p] = rng.state;
+            qbit = doomed_bit(t2, rng.state, rng_inc);
           }
         }
       }
@@ -696,7 +715,7 @@ __global__ __launch_bounds__(kBlock) void k_tail(PathState P, DScene sc, uint64_
       } else {
         const uint32_t slot = __float_as_uint(P.hit[p].w);
         if (slot == kNone) break;  // miss: the path ends (render.cc:34)
-        r = (sc.shade[slot].flags & kSlotMatHair) ? shade_hair_path(P, sc, p, rng_inc) : shade_principled_path(P, sc, p, rng_inc);
+        r = (slot & kHitHair) ? shade_hair_path(P, sc, p, rng_inc) : shade_principled_path(P, sc, p, rng_inc);
       }
       if (r & kRShadow) {
         const float4 o4 = P.sh_o[p], d4 = P.sh_d[p];
@@ -749,7 +768,7 @@ __device__ __forceinline__ HookHit hook_result(const DScene& sc, V3 o, V3 d, con
   r.instance_id = r.geom_id = r.prim_id = kNone;
   if (h.slot != kNone) {
     Surface s = make_surface(sc, o, d, h);
-    const ShadeRec& sr = sc.shade[h.slot];
+    const ShadeRec& sr = sc.shade[h.slot & kHitSlotMask];
     r.ng[0] = s.n_g.x, r.ng[1] = s.n_g.y, r.ng[2] = s.n_g.z;
     r.t = h.t, r.u = h.u, r.v = h.v;
     r.instance_id = sr.instance_id, r.geom_id = sr.geom_id, r.prim_id = sr.prim_id;

@@ -547,6 +547,7 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
 
   // leaf-ordered slots (traversal geometry) + one 128-byte ShadeRec per slot (everything shading needs)
   uint32_t ns = (uint32_t)bvh.slot_gid.size();
+  if (ns > kHitSlotMask) return fail(PBRHIP_EINVAL, "%u traversal primitives: at most %u are supported", ns, kHitSlotMask);
   std::vector<float4> slots(4 * (size_t)ns);
   std::vector<ShadeRec> shade(ns);
   for (uint32_t k = 0; k < ns; k++) {
@@ -604,6 +605,9 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
       for (int c = 0; c < 16; c++) w[c] = cps[c];
     }
     sr.gid = g, sr.material = mat, sr.lightrec = lightrec, sr.flags = flags;
+    const uint32_t route = ((flags & kSlotMatHair) ? kHitHair : 0u) | ((flags & kSlotMatNone) ? kHitNoMaterial : 0u) |
+                           (lightrec != kNone ? kHitLight : 0u);
+    sl[2].w = __builtin_bit_cast(float, route);  // travels with the hit record (Hit::slot)
     sr.instance_id = pr.instance_id, sr.geom_id = pr.geom_id, sr.prim_id = pr.prim_id;
   }
   std::vector<Material> mats(s->materials.size());
