@@ -154,7 +154,7 @@ struct DScene {
   const LightRec* lrecs;
   const float* tex_pixels;
   const TexDesc* textures;
-  uint32_t num_nodes, num_slots, num_lights, num_materials, num_curves, num_textures;
+  uint32_t num_nodes, num_slots, num_lights, num_materials, num_curves, num_textures, num_lrecs;
 };
 
 // camera of RenderingTile (render.cc:132-158), derived on the host from the scene AABB

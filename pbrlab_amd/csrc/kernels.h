@@ -26,7 +26,7 @@ struct PathState {
   float4 *sh_o, *sh_d, *sh_c, *sh_e;
   uint32_t* spill;               // traversal-stack spill area: (kStackDepth - LDS part) x resident threads
   uint32_t* counts;              // kCnt*
-  unsigned long long* stats;     // kStat*
+  unsigned long long* stats;     // kStat*; null unless the render collects statistics
 };
 
 enum : uint32_t { kFlagNotFirst = 1u };
@@ -44,7 +44,7 @@ enum : uint32_t {
   kStatClosestRays = 0, kStatClosestNodes, kStatClosestTris, kStatClosestCurves,
   kStatShadowRays, kStatShadowNodes, kStatShadowTris, kStatShadowCurves,
   kStatPvItNode, kStatPvItTri, kStatPvItCurve, kStatPvItRefill, kStatPvLnNode, kStatPvLnTri, kStatPvLnCurve,
-  kStatTailClosestRays, kStatTailShadowRays, kStatNum
+  kStatTailClosestRays, kStatTailShadowRays, kStatPrunedRays, kStatNum
 };
 
 // Resident 256-thread blocks per CU of the persistent traversal kernel = waves per SIMD (VGPR budget 512 / waves).

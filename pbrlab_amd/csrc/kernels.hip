@@ -307,6 +307,25 @@ __device__ __forceinline__ uint32_t doomed_bit(V3 thr, uint64_t state, uint64_t 
   return spectrum_norm(thr) < draw(r) ? kQDoomed : 0u;
 }
 
+// A doomed path can still pick up the emission of an area light its next ray hits (path_head adds it before the roulette);
+// nothing else it does survives.  With a handful of light primitives that is decided here: if the ray misses every one
+// of them (the very test, on the very operands, the traversal would run on those primitives) the path ends now and its ray
+// is never traced.  Scenes with more light primitives than kLightPretest keep the ray (a linear scan would not pay).
+constexpr uint32_t kLightPretest = 8;
+__device__ __forceinline__ bool misses_all_lights(const DScene& sc, V3 o, V3 d, float tmin) {
+  if (sc.num_lrecs > kLightPretest) return false;
+  for (uint32_t i = 0; i < sc.num_lrecs; i++) {
+    const float4* lr = reinterpret_cast<const float4*>(sc.lrecs + i);
+    float t, u, v;
+    if (tri_test(ld3(lr[0]), ld3(lr[1]), ld3(lr[2]), o, d, tmin, t, u, v)) return false;
+  }
+  return true;
+}
+
+__device__ __forceinline__ void count_pruned(const PathState& P) {  // P.stats is null unless the render collects statistics
+  if (P.stats) atomicAdd(&P.stats[kStatPrunedRays], 1ull);
+}
+
 // writes one shadow-queue entry
 __device__ __forceinline__ void put_shadow(const PathState& P, V3 pos, const Nee& n, V3 c_vis, V3 c_occ, uint32_t p,
                                            uint32_t mode) {
@@ -441,13 +460,18 @@ __device__ __forceinline__ uint32_t shade_principled_path(const PathState& P, co
           // render.cc:80-86
           V3 t2 = new_thr * thr;
           if (!is_black(t2)) {
-            alive = true;
-            P.ray_o[p] = mk4(s.pos, 1e-3f);
-            P.ray_d[p] = mk4(next_dir, kInf);
-            P.thr[p] = mk4(t2, new_pdf);
-            P.rng[p] = rng.state;
-            P.flags[p] = c.flags;
             qbit = doomed_bit(t2, rng.state, rng_inc);
+            if (!(qbit && misses_all_lights(sc, s.pos, next_dir, 1e-3f))) {
+              alive = true;
+              P.ray_o[p] = mk4(s.pos, 1e-3f);
+              P.ray_d[p] = mk4(next_dir, kInf);
+              P.thr[p] = mk4(t2, new_pdf);
+              P.rng[p] = rng.state;
+              P.flags[p] = c.flags;
+            } else {
+              qbit = 0u;
+              count_pruned(P);
+            }
           }
         }
       }
@@ -516,13 +540,18 @@ __device__ __forceinline__ uint32_t shade_hair_path(const PathState& P, const DS
         c_vis = thr * ((V3(0.f) + d1) + V3(0.f));
         V3 t2 = new_thr * thr;
         if (!is_black(t2)) {
-          alive = true;
-          P.ray_o[p] = mk4(s.pos, 1e-3f);
-          P.ray_d[p] = mk4(next_dir, kInf);
-          P.thr[p] = mk4(t2, pdf);
-          P.rng[p] = rng.state;
-          P.flags[p] = c.flags;
           qbit = doomed_bit(t2, rng.state, rng_inc);
+          if (!(qbit && misses_all_lights(sc, s.pos, next_dir, 1e-3f))) {
+            alive = true;
+            P.ray_o[p] = mk4(s.pos, 1e-3f);
+            P.ray_d[p] = mk4(next_dir, kInf);
+            P.thr[p] = mk4(t2, pdf);
+            P.rng[p] = rng.state;
+            P.flags[p] = c.flags;
+          } else {
+            qbit = 0u;
+            count_pruned(P);
+          }
         }
       }
     }
@@ -654,12 +683,17 @@ __device__ __forceinline__ uint32_t sss_step_path(const PathState& P, const DSce
           }
           V3 t2 = new_thr * thr;
           if (!is_black(t2)) {
-            alive = true;
-            P.ray_o[p] = mk4(s.pos, 1e-3f);
-            P.ray_d[p] = mk4(next_dir, kInf);
-            P.thr[p] = mk4(t2, pdf);
-            P.rng[p] = rng.state;
             qbit = doomed_bit(t2, rng.state, rng_inc);
+            if (!(qbit && misses_all_lights(sc, s.pos, next_dir, 1e-3f))) {
+              alive = true;
+              P.ray_o[p] = mk4(s.pos, 1e-3f);
+              P.ray_d[p] = mk4(next_dir, kInf);
+              P.thr[p] = mk4(t2, pdf);
+              P.rng[p] = rng.state;
+            } else {
+              qbit = 0u;
+              count_pruned(P);
+            }
           }
         }
       }

@@ -639,7 +639,7 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
   d.nodes = s->d_nodes.p, d.slots = s->d_slots.p, d.shade = s->d_shade.p;
   d.materials = s->d_materials.p, d.light_cdf = s->d_light_cdf.p;
   d.light_heads = s->d_heads.p, d.lprim_cdf = s->d_lprim_cdf.p, d.lrecs = s->d_lrecs.p;
-  d.num_nodes = num_nodes, d.num_slots = ns, d.num_lights = (uint32_t)s->lights.size();
+  d.num_nodes = num_nodes, d.num_slots = ns, d.num_lights = (uint32_t)s->lights.size(), d.num_lrecs = (uint32_t)lrecs.size();
   d.num_materials = (uint32_t)mats.size();
   d.tex_pixels = s->d_tex_pixels.p, d.textures = s->d_tex_descs.p, d.num_textures = (uint32_t)s->tex_descs.size();
   d.num_curves = 0;
@@ -898,8 +898,8 @@ static int render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volat
     P.sss_ez = s->sss[4].p, P.sss_A = s->sss[5].p;
     P.q_in = s->q[0].p, P.q_out = s->q[1].p, P.q_principled = s->q[2].p, P.q_hair = s->q[3].p, P.q_sss = s->q[4].p, P.q_shadow = s->q[5].p, P.q_shadow_in = s->q[6].p;
     P.sh_o = s->sh[0].p, P.sh_d = s->sh[1].p, P.sh_c = s->sh[2].p, P.sh_e = s->sh[3].p;
-    P.counts = s->counts.p, P.stats = s->stats.p, P.spill = s->spill.p;
-    HIPCHK(hipMemsetAsync(P.stats, 0, sizeof(unsigned long long) * kStatNum, st));
+    P.counts = s->counts.p, P.stats = want_stats ? s->stats.p : nullptr, P.spill = s->spill.p;
+    HIPCHK(hipMemsetAsync(s->stats.p, 0, sizeof(unsigned long long) * kStatNum, st));
     const Camera cam = make_camera(s, d->width, d->height);
     const uint64_t rng_inc = (d->seed_seq << 1u) | 1u;  // pcg32_srandom (rng.h:30-36)
     const DScene& sc = s->dscene;
@@ -1030,11 +1030,12 @@ static int render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volat
     HIPCHK(hipStreamSynchronize(st));
     if (want_stats) {
       unsigned long long hs[kStatNum];
-      HIPCHK(hipMemcpy(hs, P.stats, sizeof(hs), hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(hs, s->stats.p, sizeof(hs), hipMemcpyDeviceToHost));
       S.closest_rays = hs[kStatClosestRays], S.closest_nodes = hs[kStatClosestNodes];
       S.closest_tris = hs[kStatClosestTris], S.closest_curves = hs[kStatClosestCurves];
       S.shadow_rays = hs[kStatShadowRays], S.shadow_nodes = hs[kStatShadowNodes];
       S.tail_closest_rays = hs[kStatTailClosestRays], S.tail_shadow_rays = hs[kStatTailShadowRays];
+      S.pruned_rays = hs[kStatPrunedRays];
       S.shadow_tris = hs[kStatShadowTris], S.shadow_curves = hs[kStatShadowCurves];
       if (getenv("PBRHIP_PV_STATS"))
         fprintf(stderr, "pv closest: it node %llu tri %llu curve %llu refill %llu | lanes/iter node %.1f tri %.1f curve %.1f\n",

@@ -100,7 +100,7 @@ def test_render_matches_oracle_and_fixture(pa, pairs, name, tail):
     assert ok is True and (layer.count == 4).all() and np.array_equal(layer.rgba[..., 3], np.full((64, 64), 4, np.float32))
     rgba, cnt, ost = so.render(64, 64, 4, threads=4, math_mode=O.MATH_F64R)
     ndiff, rel = image_check(layer.rgba, rgba)
-    assert (st["closest_rays"] + st["tail_closest_rays"], st["shadow_rays"] + st["tail_shadow_rays"]) == (ost["closest_rays"], ost["shadow_rays"])
+    assert (st["closest_rays"] + st["tail_closest_rays"] + st["pruned_rays"], st["shadow_rays"] + st["tail_shadow_rays"]) == (ost["closest_rays"], ost["shadow_rays"])
     fx = np.load(os.path.join(G, "oracle_images.npz"))
     image_check(layer.rgba, fx[f"{name}_f64r_rgba"])
     # against the reference's libm arithmetic: tolerance only
