@@ -103,7 +103,7 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
   float tmin = 0.f;  // (the current tmax of the ray is hit.t)
   Hit hit = {0.f, 0.f, 0.f, kNone};
   int sp = 0;
-  uint32_t cur = 0, end = 0;  // TRI/CURVE: slot cursor and end of the leaf
+  uint32_t cur = 0, end = 0;  // index of the current 64-byte item (node; TRI/CURVE: num_nodes + slot) and end of the leaf
   float4 D0 = make_float4(0, 0, 0, 0), D1 = D0, D2 = D0;  // prefetched node / primitive slot
   float2 D3 = make_float2(0, 0);                           // a node's two child references
 
@@ -193,9 +193,9 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
             if (STATS) (any_ray ? st.acurves : st.curves)++;
             ok = segment_test(D0, D1, __float_as_uint(D2.x), o, d, tmin, hit.t, t, u, v);
           }
-          if (ok && !any_ray && t == hit.t && hit.slot != kNone) ok = sc.shade[cur].gid < sc.shade[hit.slot & kHitSlotMask].gid;
+          if (ok && !any_ray && t == hit.t && hit.slot != kNone) ok = sc.shade[cur - sc.num_nodes].gid < sc.shade[hit.slot & kHitSlotMask].gid;
           if (ok) {
-            hit.t = t, hit.u = u, hit.v = v, hit.slot = cur | __float_as_uint(D2.w);  // + routing bits (dscene.h)
+            hit.t = t, hit.u = u, hit.v = v, hit.slot = (cur - sc.num_nodes) | __float_as_uint(D2.w);  // + routing bits (dscene.h)
           }
           if (any_ray && ok) {
             state = kStDoneOccluded;
@@ -215,13 +215,16 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
           advance = false;
         } else {
           sp--;
-          next = (sp < kPvLdsStack) ? stk_base[(uint32_t)sp * stride] : spill[(uint32_t)(sp - kPvLdsStack) * spill_stride];
+          // the LDS read is unconditional (a clamped index), the spill read the rare exception: one ds_read instead of a
+          // flat load behind an address select
+          next = stk_base[(uint32_t)(sp < kPvLdsStack ? sp : kPvLdsStack - 1) * stride];
+          if (sp >= kPvLdsStack) next = spill[(uint32_t)(sp - kPvLdsStack) * spill_stride];
         }
       }
       if (advance) {
         need_load = true;
         if (next & kLeafBit) {
-          cur = (next & 0x3FFFFFFFu) >> 3;
+          cur = ((next & 0x3FFFFFFFu) >> 3) + sc.num_nodes;  // slots follow the nodes in one array of 64-byte items
           end = cur + (next & 7u) + 1u;
           state = (CURVES && (next & kCurveBit)) ? kStCurve : kStTri;
         } else {
@@ -231,7 +234,7 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
       }
     }
     if (need_load) {
-      const float4* g = (state == kStNode) ? reinterpret_cast<const float4*>(sc.nodes + cur) : (sc.slots + (size_t)cur * 4);
+      const float4* g = reinterpret_cast<const float4*>(sc.nodes + cur);  // node, or slot cur - num_nodes
       D0 = g[0], D1 = g[1], D2 = g[2];
       if (state == kStNode) D3 = *reinterpret_cast<const float2*>(g + 3);
     }

@@ -113,7 +113,6 @@ struct pbrhip_scene {
   bool bvh_built_on_gpu = false;
   // device scene
   DevBuf<BvhNode> d_nodes;
-  DevBuf<float4> d_slots;
   DevBuf<ShadeRec> d_shade;
   DevBuf<Material> d_materials;
   DevBuf<float> d_light_cdf, d_lprim_cdf, d_tex_pixels;
@@ -138,7 +137,7 @@ struct pbrhip_scene {
   std::vector<hipEvent_t> events;
 
   size_t device_bytes() const {
-    return d_nodes.n * sizeof(BvhNode) + d_slots.n * 16 + d_shade.n * sizeof(ShadeRec) +
+    return d_nodes.n * sizeof(BvhNode) + d_shade.n * sizeof(ShadeRec) +
            d_materials.n * sizeof(Material) + d_lrecs.n * sizeof(LightRec);
   }
 };
@@ -495,7 +494,7 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
   int builder = s->bvh_builder;
   if (const char* e = getenv("PBRHIP_BVH")) builder = (strcmp(e, "gpu") == 0) ? PBRHIP_BVH_GPU_LBVH : PBRHIP_BVH_HOST_SAH;
   if (builder == PBRHIP_BVH_GPU_LBVH && np > 0) {
-    HIPCHK(s->d_nodes.reserve(std::max<size_t>(np > 1 ? np - 1 : 1, 1)));
+    HIPCHK(s->d_nodes.reserve(std::max<size_t>(np > 1 ? np - 1 : 1, 1) + np));  // nodes, then one 64-byte slot per primitive
     HIPCHK(build_bvh_gpu(s->stream, lo, hi, kinds, s->d_nodes.p, &bvh.slot_gid, &bvh.depth));
     if (bvh.depth > (uint32_t)kStackDepth) {
       // a Morton-order tree over badly distributed primitives can be deeper than the traversal stack: use the SAH tree
@@ -624,8 +623,14 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
   }
 
   hipStream_t st = s->stream;
-  if (!gpu_built) HIPCHK(s->d_nodes.upload(bvh.nodes, st));
-  HIPCHK(s->d_slots.upload(slots, st));
+  // nodes and primitive slots share one allocation (both are 64-byte items: the traversal addresses either as
+  // base + index * 64, with slot k at index num_nodes + k)
+  static_assert(sizeof(BvhNode) == 64 && sizeof(float4) == 16, "node / slot footprint");
+  if (!gpu_built) {
+    HIPCHK(s->d_nodes.reserve((size_t)num_nodes + ns));
+    if (num_nodes) HIPCHK(hipMemcpyAsync(s->d_nodes.p, bvh.nodes.data(), (size_t)num_nodes * sizeof(BvhNode), hipMemcpyHostToDevice, st));
+  }
+  if (ns) HIPCHK(hipMemcpyAsync(s->d_nodes.p + num_nodes, slots.data(), (size_t)ns * 64, hipMemcpyHostToDevice, st));
   HIPCHK(s->d_shade.upload(shade, st));
   HIPCHK(s->d_materials.upload(mats, st));
   HIPCHK(s->d_light_cdf.upload(s->light_cdf, st));
@@ -636,7 +641,7 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
   HIPCHK(s->d_tex_descs.upload(s->tex_descs, st));
   HIPCHK(hipStreamSynchronize(st));
   DScene& d = s->dscene;
-  d.nodes = s->d_nodes.p, d.slots = s->d_slots.p, d.shade = s->d_shade.p;
+  d.nodes = s->d_nodes.p, d.slots = reinterpret_cast<const float4*>(s->d_nodes.p + num_nodes), d.shade = s->d_shade.p;
   d.materials = s->d_materials.p, d.light_cdf = s->d_light_cdf.p;
   d.light_heads = s->d_heads.p, d.lprim_cdf = s->d_lprim_cdf.p, d.lrecs = s->d_lrecs.p;
   d.num_nodes = num_nodes, d.num_slots = ns, d.num_lights = (uint32_t)s->lights.size(), d.num_lrecs = (uint32_t)lrecs.size();
