@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--max-paths", type=int, default=0)
+    ap.add_argument("--streams", type=int, default=0, help="concurrent path groups (0 = the library's default)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = spp x N (per-GPU work fixed, default); strong = the fixed 64-spp frame split over N GPUs")
     args = ap.parse_args()
@@ -150,7 +151,7 @@ def main():
 
     def step(flags=0):
         _, st = api.Render(scene, W, H, spp, tile_rank=rank, tile_world=world, device_out=ptrs, flags=flags,
-                           max_paths_in_flight=args.max_paths)
+                           max_paths_in_flight=args.max_paths, num_streams=args.streams)
         if dist is not None:                   # the only exchange step: framebuffer reduce over xGMI
             reduce_layer(rgba, count, dst=0)
         if rank == 0:                          # RenderLayer lives on the host
@@ -189,7 +190,11 @@ def main():
     if not args.no_roofline:
         # untimed pass with traversal counters (deterministic: identical work to the timed steps)
         _, sst = api.Render(scene, W, H, spp, tile_rank=rank, tile_world=world, device_out=ptrs,
-                            flags=api.RENDER_STATS, max_paths_in_flight=args.max_paths)
+                            flags=api.RENDER_STATS, max_paths_in_flight=args.max_paths, num_streams=args.streams)
+        torch.cuda.synchronize()
+        # untimed: the same frame with ONE path group, i.e. every k_trace launch has the GPU to itself
+        _, solo = api.Render(scene, W, H, spp, tile_rank=rank, tile_world=world, device_out=ptrs,
+                             flags=api.RENDER_TIMING, max_paths_in_flight=args.max_paths, num_streams=1)
         torch.cuda.synchronize()
         bytes_step = (NODE_B * (sst["closest_nodes"] + sst["shadow_nodes"]) + TRI_B * (sst["closest_tris"] + sst["shadow_tris"]) +
                       CURVE_B * (sst["closest_curves"] + sst["shadow_curves"]) + RAY_B * sst["closest_rays"] +
@@ -202,7 +207,14 @@ def main():
                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                         "note": "achieved = ALGORITHMIC bytes (64 B per node visit, 48 B per triangle test, rays) / kernel time as "
                                 "SURVEY 8d defines it; the 128 MB scene is served from L2 / Infinity Cache, so this can exceed the HBM "
-                                "peak -- the HBM-side bytes per launch measured with PMC counters are `traffic`",
+                                "peak -- the HBM-side bytes per launch measured with PMC counters are `traffic`.  By default the "
+                                "frame runs as two path groups on two HIP streams: their k_trace launches overlap each other and the "
+                                "other group's shading, so a launch's duration (HIP events on its own stream, timed region) includes "
+                                "time in which it shares the GPU; `solo` is the same frame run as one group (untimed extra render), "
+                                "every launch alone on the GPU",
+                        "solo": {"launches_per_step": solo["n_trace_closest"], "avg_launch_ms": solo["ms_trace_closest"] / max(solo["n_trace_closest"], 1),
+                                 "achieved": bytes_step / (solo["ms_trace_closest"] * 1e-3) / 1e9,
+                                 "frac": bytes_step / (solo["ms_trace_closest"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_frame": solo["ms_total"]},
                         "traffic": None if args.max_paths else pmc_traffic(args.workload, spp, world),
                         "algorithmic_bytes_per_launch": bytes_step / max(launches, 1),
                         "avg_launch_ms": ms_step / max(launches, 1), "launches_per_step": launches,

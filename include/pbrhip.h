@@ -78,7 +78,7 @@ typedef struct {
   uint32_t tile_rank, tile_world;     /* 64x64 tiles (render.cc:107-108) with index % world == rank */
   uint32_t max_paths_in_flight;       /* 0 = default (half of the free HBM, <= 256 Mi): passes are rendered in chunks of this many paths */
   uint32_t flags;                     /* PBRHIP_RENDER_* */
-  uint32_t num_streams;               /* concurrent path groups, one HIP stream each (0 = default 1, max 8) */
+  uint32_t num_streams;               /* concurrent path groups, one HIP stream each (0 = default: 2 when a chunk holds >= 16 Mi paths, else 1; max 8) */
   uint32_t tail_paths;                /* once a group has at most this many live paths, the rest of every path runs in ONE launch
                                          (k_tail) instead of one set of launches per bounce; 0 = default 262144, 0xFFFFFFFF = never */
 } pbrhip_render_desc;

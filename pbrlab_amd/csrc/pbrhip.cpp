@@ -915,7 +915,10 @@ static int render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volat
     // one group's drain overlaps the others' bulk work.  Path slots stay global, so results are unchanged.
     uint32_t tail_paths = d->tail_paths == 0xFFFFFFFFu ? 0u : (d->tail_paths ? d->tail_paths : 262144u);
     if (const char* e = getenv("PBRHIP_TAIL_PATHS")) tail_paths = (uint32_t)strtoul(e, nullptr, 10);  // 0 = never
-    uint32_t want_groups = d->num_streams ? d->num_streams : 1u;
+    // default: two groups once a chunk holds >= 16 Mi paths (A/B on C2, 132.7 M paths: 1 -> 72.5 ms, 2 -> 69.7, 3 -> 70.6,
+    // 4 -> 78.1: one group's latency-bound k_tail and drains hide behind the other's bulk work; more groups only add launches)
+    const uint64_t chunk_paths = (uint64_t)chunk_passes * npix;
+    uint32_t want_groups = d->num_streams ? d->num_streams : (chunk_paths >= (16ull << 20) ? 2u : 1u);
     if (const char* e = getenv("PBRHIP_STREAMS")) want_groups = (uint32_t)atoi(e);
     want_groups = std::max(1u, std::min(want_groups, (uint32_t)kMaxGroups));
     if (int rc = ensure_groups(s, want_groups)) return rc;

@@ -134,6 +134,24 @@ def test_chunking_and_progressive_are_exact(pa, pairs):
     assert a.rgba.tobytes() == c.rgba.tobytes()
 
 
+@pytest.mark.parametrize("name", ["ggx", "sss", "hair"])
+def test_concurrent_path_groups_are_exact(pa, pairs, name):
+    """pbrhip_render_desc.num_streams: the passes of a chunk split into independent groups on their own HIP streams
+    (their tails and drains overlap); path slots stay global, so the image is bit-identical for any group count, with
+    and without the tail kernel, also when there are fewer passes than groups"""
+    desc, sg, so = pairs[name]
+    ref = pa.RenderLayer()
+    pa.Render(sg, 96, 80, 5, layer=ref, num_streams=1)
+    for streams, tail in ((2, 0), (3, 0), (8, 0), (2, 0xFFFFFFFF), (3, 64)):
+        lay = pa.RenderLayer()
+        ok, st = pa.Render(sg, 96, 80, 5, layer=lay, num_streams=streams, tail_paths=tail)
+        assert ok is True and (lay.count == 5).all()
+        assert lay.rgba.tobytes() == ref.rgba.tobytes(), (streams, tail)
+    lay = pa.RenderLayer()
+    pa.Render(sg, 96, 80, 5, layer=lay, num_streams=2, max_paths_in_flight=96 * 80 * 3)   # chunks of 3 + 2 passes
+    assert lay.rgba.tobytes() == ref.rgba.tobytes()
+
+
 def test_tile_sharding_matches_single(pa, pairs):
     desc, sg, so = pairs["sss"]
     full = pa.RenderLayer()
