@@ -215,7 +215,7 @@ def main():
                         "solo": {"launches_per_step": solo["n_trace_closest"], "avg_launch_ms": solo["ms_trace_closest"] / max(solo["n_trace_closest"], 1),
                                  "achieved": bytes_step / (solo["ms_trace_closest"] * 1e-3) / 1e9,
                                  "frac": bytes_step / (solo["ms_trace_closest"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_frame": solo["ms_total"]},
-                        "traffic": None if args.max_paths else pmc_traffic(args.workload, spp, world),
+                        "traffic": None if (args.max_paths or args.streams) else pmc_traffic(args.workload, spp, world),
                         "algorithmic_bytes_per_launch": bytes_step / max(launches, 1),
                         "avg_launch_ms": ms_step / max(launches, 1), "launches_per_step": launches,
                         "rays_per_step": sst["closest_rays"] + sst["shadow_rays"],
