@@ -8,7 +8,7 @@
  *   pbrlab::io::LoadImageFromFile / WritePNG   src/io/image-io.cc:98-224
  *   the output stage of pbrlab-cli             pc/pbrlab-cli.cc:47-57 (rgba/count -> sRGB -> 8-bit PNG)
  * Image files read: PNG, baseline JPEG, Radiance .hdr, scanline OpenEXR (NONE/RLE/ZIPS/ZIP).  Not decoded by this
- * build: progressive JPEG, BMP/TGA/GIF/PSD/PNM and tiled or PIZ/PXR24/B44 OpenEXR textures (the call fails and says so). */
+ * build: progressive JPEG, Softimage PIC and tiled or PIZ/PXR24/B44 OpenEXR textures (the call fails and says so). */
 #ifndef PBRHIP_IO_H_
 #define PBRHIP_IO_H_
 

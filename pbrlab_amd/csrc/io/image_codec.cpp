@@ -1367,14 +1367,11 @@ bool read_file(const std::string& path, std::vector<uint8_t>* out) {
   out->assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
   return true;
 }
-const char* sniff(const std::vector<uint8_t>& d) {
-  if (d.size() >= 3 && d[0] == 0xFF && d[1] == 0xD8) return "JPEG";
-  if (d.size() >= 2 && d[0] == 'B' && d[1] == 'M') return "BMP";
-  if (d.size() >= 4 && memcmp(d.data(), "GIF8", 4) == 0) return "GIF";
-  if (d.size() >= 4 && memcmp(d.data(), "8BPS", 4) == 0) return "PSD";
-  if (d.size() >= 2 && d[0] == 'P' && (d[1] == '5' || d[1] == '6')) return "PNM";
-  if (d.size() >= 4 && d[0] == 0x76 && d[1] == 0x2f && d[2] == 0x31 && d[3] == 0x01) return "OpenEXR";
-  return "unknown (TGA?)";
+bool is_pic(const std::vector<uint8_t>& d) {  // Softimage PIC
+  return d.size() >= 92 && d[0] == 0x53 && d[1] == 0x80 && d[2] == 0xF6 && d[3] == 0x34 && memcmp(d.data() + 88, "PICT", 4) == 0;
+}
+bool is_radiance(const std::vector<uint8_t>& d) {
+  return (d.size() >= 11 && memcmp(d.data(), "#?RADIANCE\n", 11) == 0) || (d.size() >= 7 && memcmp(d.data(), "#?RGBE\n", 7) == 0);
 }
 }  // namespace
 
@@ -1425,8 +1422,42 @@ bool LoadImageFromFile(const std::string& filename, const std::string& asset_pat
     for (size_t i = 0; i < px8.size(); ++i) (*pixels)[i] = float(px8[i]) / float(255);
     return true;
   }
-  std::cerr << "image file [" << path << "]: format " << sniff(bytes) << " is not decoded by this build (convert to .png)" << std::endl;
-  return false;
+  // stb_image's order for what is left: BMP, GIF, PSD, PIC, PNM, Radiance (tone-mapped to 8 bits), and TGA last because it
+  // has no signature
+  typedef bool (*Decoder)(const uint8_t*, size_t, std::vector<uint8_t>*, size_t*, size_t*, size_t*, std::string*);
+  Decoder dec = nullptr;
+  if (IsBmp(bytes.data(), bytes.size())) dec = DecodeBmp;
+  else if (IsGif(bytes.data(), bytes.size())) dec = DecodeGif;
+  else if (IsPsd(bytes.data(), bytes.size())) dec = DecodePsd;
+  else if (is_pic(bytes)) {
+    std::cerr << "image file [" << path << "]: Softimage PIC is not decoded by this build (convert to .png)" << std::endl;
+    return false;
+  } else if (IsPnm(bytes.data(), bytes.size())) dec = DecodePnm;
+  else if (is_radiance(bytes)) {
+    std::vector<float> hdr;
+    if (!DecodeHdr(bytes.data(), bytes.size(), &hdr, width, height, &err)) {
+      std::cerr << "image file [" << path << "]: " << err << std::endl;
+      return false;
+    }
+    std::vector<uint8_t> px8;
+    HdrToLdr(hdr, &px8);
+    *channels = 3;
+    pixels->resize(px8.size());
+    for (size_t i = 0; i < px8.size(); ++i) (*pixels)[i] = float(px8[i]) / float(255);
+    return true;
+  } else if (IsTga(bytes.data(), bytes.size())) dec = DecodeTga;
+  if (!dec) {
+    std::cerr << "image file [" << path << "]: not an image of any known type" << std::endl;
+    return false;
+  }
+  std::vector<uint8_t> px8;
+  if (!dec(bytes.data(), bytes.size(), &px8, width, height, channels, &err)) {
+    std::cerr << "image file [" << path << "]: " << err << std::endl;
+    return false;
+  }
+  pixels->resize(px8.size());
+  for (size_t i = 0; i < px8.size(); ++i) (*pixels)[i] = float(px8[i]) / float(255);
+  return true;
 }
 
 namespace {

@@ -44,7 +44,12 @@ int main(int argc, char** argv) {
       if (ext == ".png") r = pbio::DecodePng(d.data(), d.size(), &px8, &w, &h, &c, &err);
       else if (ext == ".jpg") r = pbio::DecodeJpeg(d.data(), d.size(), &px8, &w, &h, &c, &err);
       else if (ext == ".exr") r = pbio::DecodeExr(d.data(), d.size(), &pxf, &w, &h, &err);
-      else if (ext == ".hdr") r = pbio::DecodeHdr(d.data(), d.size(), &pxf, &w, &h, &err);
+      else if (ext == ".hdr" || ext == ".pic") r = pbio::DecodeHdr(d.data(), d.size(), &pxf, &w, &h, &err);
+      else if (ext == ".bmp") r = pbio::IsBmp(d.data(), d.size()) && pbio::DecodeBmp(d.data(), d.size(), &px8, &w, &h, &c, &err);
+      else if (ext == ".tga") r = pbio::IsTga(d.data(), d.size()) && pbio::DecodeTga(d.data(), d.size(), &px8, &w, &h, &c, &err);
+      else if (ext == ".ppm" || ext == ".pgm") r = pbio::IsPnm(d.data(), d.size()) && pbio::DecodePnm(d.data(), d.size(), &px8, &w, &h, &c, &err);
+      else if (ext == ".gif") r = pbio::IsGif(d.data(), d.size()) && pbio::DecodeGif(d.data(), d.size(), &px8, &w, &h, &c, &err);
+      else if (ext == ".psd") r = pbio::IsPsd(d.data(), d.size()) && pbio::DecodePsd(d.data(), d.size(), &px8, &w, &h, &c, &err);
       else if (ext == ".obj" || ext == ".hair" || ext == ".mtl") {
         const std::string tmp = std::string("/tmp/pbrio_fuzz/m") + ext;
         { std::ofstream o(tmp, std::ios::binary); o.write(reinterpret_cast<const char*>(d.data()), long(d.size())); }

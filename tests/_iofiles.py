@@ -570,3 +570,215 @@ def write_jpeg(path, planes, sampling, *, quant=None, restart=0, quant16=False, 
     with open(path, "wb") as f:
         f.write(out)
     return W, H
+
+
+# ------------------------------------------------------------------ BMP / TGA / PNM / GIF / PSD test-file writers
+def write_bmp(path, img, *, bpp=24, header=40, top_down=False, palette=None, masks=None, compress=None, gap=0):
+    """img: (h, w, c) uint8 for 24/32 bpp; (h, w) palette indices for 1/4/8; (h, w) raw pixel words for 16/32 with masks.
+    header: 12 (OS/2), 40, 56, 108, 124.  masks = (r, g, b[, a]) -> BI_BITFIELDS (40: 3 words after the header; 56/108/124:
+    inside the header).  gap: unused bytes between palette / masks and the pixel data."""
+    img = np.asarray(img)
+    h, w = img.shape[:2]
+    rows = []
+    for y in (range(h) if top_down else range(h - 1, -1, -1)):
+        r = img[y]
+        if bpp == 24:
+            b = r[:, [2, 1, 0]].astype(np.uint8).tobytes()
+        elif bpp == 32 and masks is None:
+            b = r[:, [2, 1, 0, 3]].astype(np.uint8).tobytes()
+        elif bpp in (16, 32):
+            b = r.astype("<u2" if bpp == 16 else "<u4").tobytes()
+        elif bpp == 8:
+            b = r.astype(np.uint8).tobytes()
+        elif bpp == 4:
+            v = list(int(k) for k in r) + [0]
+            b = bytes((v[i] << 4) | v[i + 1] for i in range(0, w, 2))
+        else:
+            v = list(int(k) for k in r) + [0] * 8
+            b = bytes(sum(v[i + k] << (7 - k) for k in range(8)) for i in range(0, w, 8))
+        rows.append(b + bytes((-len(b)) % 4))
+    pal = b""
+    if palette is not None:
+        for p in palette:
+            pal += bytes([int(p[2]), int(p[1]), int(p[0])]) + (b"" if header == 12 else b"\0")
+    if compress is None:
+        compress = 3 if masks is not None else 0
+    if header == 12:
+        info = struct.pack("<IHHHH", 12, w, h, 1, bpp)
+    else:
+        info = struct.pack("<IiiHHIIiiII", header, w, -h if top_down else h, 1, bpp, compress, 0, 2835, 2835, 0, 0)
+        m = list(masks or ()) + [0] * 4
+        if header == 56:
+            # stb skips the four mask words of a 56-byte header and, for BI_BITFIELDS, expects three more after it
+            info += struct.pack("<IIII", *m[:4]) + (struct.pack("<III", *m[:3]) if masks is not None else b"")
+        elif header in (108, 124):
+            info += struct.pack("<IIII", *m[:4]) + b"sRGB"[::-1] + bytes(48) + (bytes(16) if header == 124 else b"")
+        elif masks is not None:
+            info += struct.pack("<III", *m[:3])          # the three words that follow a 40-byte header
+    offset = 14 + len(info) + len(pal) + gap
+    with open(path, "wb") as f:
+        f.write(b"BM" + struct.pack("<IHHI", offset + sum(map(len, rows)), 0, 0, offset) + info + pal + bytes(gap) + b"".join(rows))
+
+
+def write_tga(path, img, *, kind="rgb", rle=False, top_down=False, palette=None, pal_bits=24, id_bytes=b"", index16=False, rng=None):
+    """kind: rgb (24/32 by channel count), rgb16 (img = (h, w) 15-bit words), grey, grey_alpha, indexed (img = indices)"""
+    img = np.asarray(img)
+    h, w = img.shape[:2]
+    if kind == "rgb":
+        c = img.shape[2]
+        px = [bytes(int(v) for v in (p[[2, 1, 0, 3]] if c == 4 else p[[2, 1, 0]])) for p in img.reshape(-1, c)]
+        typ, bpp = 2, 8 * c
+    elif kind == "rgb16":
+        px = [struct.pack("<H", int(v)) for v in img.reshape(-1)]
+        typ, bpp = 2, 16
+    elif kind == "grey":
+        px = [bytes([int(v)]) for v in img.reshape(-1)]
+        typ, bpp = 3, 8
+    elif kind == "grey_alpha":
+        px = [bytes(int(v) for v in p) for p in img.reshape(-1, 2)]
+        typ, bpp = 3, 16
+    else:
+        px = [struct.pack("<H", int(v)) if index16 else bytes([int(v)]) for v in img.reshape(-1)]
+        typ, bpp = 1, 16 if index16 else 8
+    if not top_down:
+        px = [px[(h - 1 - y) * w + x] for y in range(h) for x in range(w)]
+    if rle:
+        rng = rng or np.random.default_rng(0)
+        data, i = b"", 0
+        while i < len(px):                   # packets may cross rows, as stb allows
+            run = 1
+            while i + run < len(px) and px[i + run] == px[i] and run < 128:
+                run += 1
+            if run > 1 and rng.random() < 0.9:
+                data += bytes([0x80 | (run - 1)]) + px[i]
+                i += run
+            else:
+                n = int(min(len(px) - i, rng.integers(1, 9)))
+                data += bytes([n - 1]) + b"".join(px[i:i + n])
+                i += n
+        typ += 8
+    else:
+        data = b"".join(px)
+    pal = b""
+    if palette is not None:
+        for p in palette:
+            pal += struct.pack("<H", int(p)) if pal_bits in (15, 16) else bytes(int(v) for v in (p[::-1] if pal_bits == 24 else (p[[2, 1, 0, 3]] if pal_bits == 32 else p)))
+    hdr = struct.pack("<BBBHHBHHHHBB", len(id_bytes), 1 if palette is not None else 0, typ, 0, 0 if palette is None else len(palette),
+                      pal_bits if palette is not None else 0, 0, 0, w, h, bpp, (0x20 if top_down else 0) | (8 if bpp == 32 else 0))
+    with open(path, "wb") as f:
+        f.write(hdr + id_bytes + pal + data)
+
+
+def write_pnm(path, img, *, comments=False):
+    img = np.asarray(img, np.uint8)
+    h, w = img.shape[:2]
+    magic = b"P6" if img.ndim == 3 else b"P5"
+    head = magic + (b"\n# made by tests\n" if comments else b" ") + b"%d" % w + (b"\t# width\r\n" if comments else b" ") + b"%d\n255\n" % h
+    with open(path, "wb") as f:
+        f.write(head + img.tobytes())
+
+
+def _gif_lzw(indices, min_bits, *, clear_every=0):
+    out, acc, nacc = bytearray(), 0, 0
+
+    def put(code, nb):
+        nonlocal acc, nacc
+        acc |= code << nacc
+        nacc += nb
+        while nacc >= 8:
+            out.append(acc & 255)
+            acc >>= 8
+            nacc -= 8
+    clear, end = 1 << min_bits, (1 << min_bits) + 1
+    table, nb, nxt = {(i,): i for i in range(clear)}, min_bits + 1, end + 1
+    put(clear, nb)
+    cur, emitted = (), 0
+    for v in indices:
+        t = cur + (int(v),)
+        if t in table:
+            cur = t
+            continue
+        put(table[cur], nb)
+        emitted += 1
+        if nxt < 4096:
+            table[t] = nxt
+            nxt += 1
+            if nxt - 1 == (1 << nb) and nb < 12:
+                nb += 1
+        if nxt >= 4096 or (clear_every and emitted % clear_every == 0):
+            put(clear, nb)
+            table, nb, nxt = {(i,): i for i in range(clear)}, min_bits + 1, end + 1
+        cur = (int(v),)
+    if cur:
+        put(table[cur], nb)
+    put(end, nb)
+    if nacc:
+        out.append(acc & 255)
+    return bytes(out)
+
+
+def write_gif(path, indices, palette, *, canvas=None, origin=(0, 0), bg_index=0, transparent=None, interlace=False, local_palette=None,
+              comment=False, version=b"89a", clear_every=0, block=255):
+    """one frame of palette indices (h, w) placed at `origin` on a canvas"""
+    indices = np.asarray(indices)
+    h, w = indices.shape
+    cw, ch = canvas or (w + origin[0], h + origin[1])
+    def table(p):
+        n = max(2, 1 << int(np.ceil(np.log2(max(len(p), 2)))))
+        return n, b"".join(bytes(int(v) for v in c) for c in p) + bytes(3 * (n - len(p)))
+    gn, gt = table(palette) if palette is not None else (0, b"")
+    f = b"GIF" + version + struct.pack("<HHBBB", cw, ch, (0x80 | (int(np.log2(gn)) - 1)) if gn else 0, bg_index, 0) + gt
+    if comment:
+        f += b"\x21\xFE\x05hello\x03abc\x00"
+    if transparent is not None:
+        f += b"\x21\xF9\x04" + struct.pack("<BHB", 1, 7, transparent) + b"\x00"
+    ln, lt = table(local_palette) if local_palette is not None else (0, b"")
+    f += b"\x2C" + struct.pack("<HHHHB", origin[0], origin[1], w, h, (0x40 if interlace else 0) | ((0x80 | (int(np.log2(ln)) - 1)) if ln else 0)) + lt
+    rows = list(range(h))
+    if interlace:
+        rows = list(range(0, h, 8)) + list(range(4, h, 8)) + list(range(2, h, 4)) + list(range(1, h, 2))
+    ncol = ln or gn
+    min_bits = max(2, int(np.ceil(np.log2(ncol))))
+    data = _gif_lzw(indices[rows].reshape(-1), min_bits, clear_every=clear_every)
+    f += bytes([min_bits])
+    for i in range(0, len(data), block):
+        f += bytes([len(data[i:i + block])]) + data[i:i + block]
+    f += b"\x00\x3B"
+    with open(path, "wb") as fo:
+        fo.write(f)
+
+
+def _packbits(row, rng):
+    out, i = b"", 0
+    while i < len(row):
+        run = 1
+        while i + run < len(row) and row[i + run] == row[i] and run < 128:
+            run += 1
+        if run > 2:
+            out += bytes([257 - run, row[i]])
+            i += run
+        else:
+            n = int(min(len(row) - i, rng.integers(1, 20)))
+            out += bytes([n - 1]) + bytes(row[i:i + n])
+            i += n
+        if rng.random() < 0.05:
+            out += b"\x80"                      # no-op byte
+    return out
+
+
+def write_psd(path, planes, *, depth=8, rle=False, seed=0):
+    """planes: (channels, h, w) uint8 (depth 8) or uint16 (depth 16): the merged image of an RGB document"""
+    planes = np.asarray(planes)
+    nch, h, w = planes.shape
+    rng = np.random.default_rng(seed)
+    f = b"8BPS" + struct.pack(">H6xHIIHH", 1, nch, h, w, depth, 3)
+    f += struct.pack(">I", 0) + struct.pack(">I", 6) + b"8BIM\x00\x00" + struct.pack(">I", 0)
+    f += struct.pack(">H", 1 if rle else 0)
+    if rle:
+        assert depth == 8
+        packed = [[_packbits(list(int(v) for v in planes[c, y]), rng) for y in range(h)] for c in range(nch)]
+        f += b"".join(struct.pack(">H", len(r)) for c in packed for r in c) + b"".join(r for c in packed for r in c)
+    else:
+        f += planes.astype(">u2" if depth == 16 else np.uint8).tobytes()
+    with open(path, "wb") as fo:
+        fo.write(f)

@@ -32,6 +32,48 @@ EXR_CASES = [(["A", "B", "G", "R"], False, 3, 0), (["B", "G", "R"], True, 3, 0),
              (["B", "G", "R"], False, 0, 0), (["A", "B", "G", "R"], True, 3, 1)]
 
 
+def write_other_format_fixtures(out):
+    rng = np.random.default_rng(2024)
+    h, w = 9, 14
+    rgb = rng.integers(0, 256, size=(h, w, 3)).astype(np.uint8)
+    rgba = rng.integers(0, 256, size=(h, w, 4)).astype(np.uint8)
+    rgb[:, :5] = rgb[0, 0]
+    names = []
+
+    def add(name, fn, *a, **k):
+        fn(os.path.join(out, name), *a, **k)
+        names.append(name)
+    add("o_24.bmp", _iofiles.write_bmp, rgb)
+    add("o_32_topdown.bmp", _iofiles.write_bmp, rgba, bpp=32, top_down=True)
+    add("o_pal4.bmp", _iofiles.write_bmp, rng.integers(0, 16, size=(h, w)), bpp=4, palette=rng.integers(0, 256, size=(16, 3)))
+    add("o_pal1_v4.bmp", _iofiles.write_bmp, rng.integers(0, 2, size=(h, w)), bpp=1, header=108, palette=rng.integers(0, 256, size=(2, 3)), gap=4)
+    add("o_565.bmp", _iofiles.write_bmp, rng.integers(0, 1 << 16, size=(h, w)), bpp=16, masks=(0xF800, 0x07E0, 0x001F))
+    add("o_4444_v5.bmp", _iofiles.write_bmp, rng.integers(0, 1 << 16, size=(h, w)), bpp=16, header=124, masks=(0x0F00, 0x00F0, 0x000F, 0xF000))
+    add("o_rgb_rle.tga", _iofiles.write_tga, rgb, rle=True, rng=rng)
+    add("o_rgba_topdown.tga", _iofiles.write_tga, rgba, top_down=True, id_bytes=b"fixture")
+    add("o_555.tga", _iofiles.write_tga, rng.integers(0, 1 << 16, size=(h, w)), kind="rgb16")
+    add("o_grey_alpha_rle.tga", _iofiles.write_tga, rgba[..., :2], kind="grey_alpha", rle=True, rng=rng)
+    add("o_indexed.tga", _iofiles.write_tga, rng.integers(0, 40, size=(h, w)), kind="indexed", palette=rng.integers(0, 256, size=(37, 3)), rle=True, rng=rng)
+    add("o_indexed16.tga", _iofiles.write_tga, rng.integers(0, 300, size=(h, w)), kind="indexed", palette=rng.integers(0, 1 << 16, size=300), pal_bits=16, index16=True)
+    add("o.ppm", _iofiles.write_pnm, rgb, comments=True)
+    add("o.pgm", _iofiles.write_pnm, rgb[..., 1])
+    idx = rng.integers(0, 16, size=(h, w))
+    idx[:, :6] = 3
+    add("o_plain.gif", _iofiles.write_gif, idx, rng.integers(0, 256, size=(16, 3)))
+    add("o_interlaced_transparent.gif", _iofiles.write_gif, idx, rng.integers(0, 256, size=(16, 3)), interlace=True, transparent=3, canvas=(w + 2, h + 3),
+        origin=(1, 2), bg_index=5, comment=True)
+    add("o_local_palette.gif", _iofiles.write_gif, idx, None, local_palette=rng.integers(0, 256, size=(16, 3)), version=b"87a", clear_every=7, block=19)
+    add("o_rgb16.psd", _iofiles.write_psd, rng.integers(0, 65536, size=(3, h, w)), depth=16)
+    pl = rng.integers(0, 256, size=(4, h, w))
+    pl[:, :, :7] = 200
+    add("o_rgba_rle.psd", _iofiles.write_psd, pl, rle=True, seed=5)
+    add("o_5ch.psd", _iofiles.write_psd, rng.integers(0, 256, size=(5, h, w)))
+    img = (rng.random((5, 8, 3)) * 4).astype(np.float32)
+    img[0, 0] = (0, 1e-5, 700.0)
+    add("o_radiance.pic", _iofiles.write_hdr, img, rle=True)
+    return names
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     g = {}
@@ -98,6 +140,10 @@ def main():
     for i in range(len(JPEG_CASES) + 2):
         g["jpg%d" % i] = _refio.image_load("photo%d.jpg" % i, OUT)
         assert g["jpg%d" % i] is not None
+    # the other stb_image formats: BMP, TGA, PNM, GIF, PSD, and a Radiance picture under a non-.hdr name
+    for name in write_other_format_fixtures(OUT):
+        g["other_" + name] = _refio.image_load(name, OUT)
+        assert g["other_" + name] is not None, name
     # output stage of pbrlab-cli (rgba/count -> sRGB -> byte(x*256) -> stb PNG), decoded back by stb
     rgba = (rng.random((19, 23, 4)) * 40).astype(np.float32)
     count = np.full((19, 23), 32, np.uint32)

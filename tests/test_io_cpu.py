@@ -347,12 +347,237 @@ def test_png_decode_fuzz_vs_reference(tmp_path, capfd):
         assert want is not None and got.shape == want.shape and np.array_equal(bits(got), bits(want)), (case, color, depth)
 
 
+OTHER_FIXTURES = sorted(k[len("other_"):] for k in GOLD.files if k.startswith("other_"))
+
+
+@pytest.mark.parametrize("name", OTHER_FIXTURES)
+def test_other_formats_golden(name, capfd):
+    """BMP / TGA / PNM / GIF / PSD fixtures (and a Radiance picture under a non-.hdr name) == the reference's stb_image pixels"""
+    got = io_api.LoadImageFromFile(name, GOLD_DIR)
+    want = GOLD["other_" + name]
+    assert got.shape == want.shape and np.array_equal(bits(got), bits(want))
+
+
+def test_other_formats_golden_is_complete():
+    assert len(OTHER_FIXTURES) >= 21 and {n.rsplit(".", 1)[1] for n in OTHER_FIXTURES} >= {"bmp", "tga", "ppm", "pgm", "gif", "psd", "pic"}
+
+
+def _other_format_cases(d, rng):
+    """writes BMP / TGA / PNM / GIF / PSD files of every flavour stb_image reads into d; yields (file name, expected pixels or
+    None).  Expected pixels are known from the generator for the lossless cases, so the generators are checked too."""
+    def rgb(h, w, c=3):
+        return rng.integers(0, 256, size=(h, w, c)).astype(np.uint8)
+    n = 0
+    for (w, h) in [(1, 1), (5, 3), (18, 7), (33, 12)]:
+        # --- BMP
+        img = rgb(h, w)
+        for header in (12, 40, 56, 108, 124):
+            for td in (False, True):
+                if header == 12 and td:
+                    continue
+                name = "b%d_24_%d_%d.bmp" % (n, header, td); n += 1
+                _iofiles.write_bmp(os.path.join(d, name), img, bpp=24, header=header, top_down=td)
+                yield name, img
+        img4 = rgb(h, w, 4)
+        name = "b%d_32.bmp" % n; n += 1
+        _iofiles.write_bmp(os.path.join(d, name), img4, bpp=32)
+        yield name, img4
+        img0 = img4.copy(); img0[..., 3] = 0                  # all-zero alpha bytes: opaque
+        name = "b%d_32a0.bmp" % n; n += 1
+        _iofiles.write_bmp(os.path.join(d, name), img0, bpp=32)
+        e = img0.copy(); e[..., 3] = 255
+        yield name, e
+        name = "b%d_32v5.bmp" % n; n += 1                      # masks in a V5 header, standard layout
+        packed = (img4[..., 3].astype(np.uint64) << 24) | (img4[..., 0].astype(np.uint64) << 16) | (img4[..., 1].astype(np.uint64) << 8) | img4[..., 2]
+        _iofiles.write_bmp(os.path.join(d, name), packed, bpp=32, header=124, masks=(0xff0000, 0xff00, 0xff, 0xff000000), compress=3)
+        yield name, img4
+        for bpp in (1, 4, 8):
+            ncol = 1 << bpp
+            pal = rng.integers(0, 256, size=(ncol if bpp < 8 else 200, 3))
+            idx = rng.integers(0, len(pal), size=(h, w))
+            for header, gap in ((40, 0), (108, 8)):
+                name = "b%d_p%d_%d.bmp" % (n, bpp, header); n += 1
+                _iofiles.write_bmp(os.path.join(d, name), idx, bpp=bpp, header=header, palette=pal, gap=gap)
+                yield name, pal[idx].astype(np.uint8)
+        # OS/2 header: stb derives the palette size from the data offset with a formula that is 12 bytes short, i.e. it reads 4
+        # entries fewer than the file has (and none at all, leaving the colours uninitialised, below 5 entries): only an 8-bit
+        # file with a full palette whose last four entries are unused decodes to something defined
+        pal = rng.integers(0, 256, size=(256, 3))
+        idx = rng.integers(0, 252, size=(h, w))
+        name = "b%d_p8_os2.bmp" % n; n += 1
+        _iofiles.write_bmp(os.path.join(d, name), idx, bpp=8, header=12, palette=pal)
+        yield name, pal[idx].astype(np.uint8)
+        words = rng.integers(0, 1 << 16, size=(h, w))
+        name = "b%d_555.bmp" % n; n += 1
+        _iofiles.write_bmp(os.path.join(d, name), words, bpp=16)
+        yield name, None
+        for masks in ((0xF800, 0x07E0, 0x001F), (0x0F00, 0x00F0, 0x000F, 0xF000), (0x7C00, 0x03E0, 0x001F, 0x8000)):
+            for header in (40, 56, 108):
+                if header == 40 and len(masks) == 4:
+                    continue
+                name = "b%d_bf16_%d.bmp" % (n, header); n += 1
+                _iofiles.write_bmp(os.path.join(d, name), words, bpp=16, header=header, masks=masks)
+                yield name, None
+        words32 = rng.integers(0, 1 << 32, size=(h, w), dtype=np.uint64)
+        for masks in ((0x3FC00000, 0x000FF000, 0x000003FC), (0xFF, 0xFF00, 0xFF0000, 0xFF000000), (0x00E00000, 0x00001C00, 0x00000003, 0x80000000)):
+            name = "b%d_bf32.bmp" % n; n += 1
+            _iofiles.write_bmp(os.path.join(d, name), words32, bpp=32, header=108, masks=masks)
+            yield name, None
+        # --- TGA
+        for td in (False, True):
+            for rle in (False, True):
+                for c in (3, 4):
+                    im = rgb(h, w, c)
+                    if rle:
+                        im[:, : w // 2] = im[0, 0]
+                    name = "t%d_rgb%d_%d%d.tga" % (n, c, td, rle); n += 1
+                    _iofiles.write_tga(os.path.join(d, name), im, rle=rle, top_down=td, rng=rng, id_bytes=b"id" if td else b"")
+                    yield name, im
+                g = rng.integers(0, 256, size=(h, w)).astype(np.uint8)
+                if rle:
+                    g[h // 2:] = 7
+                name = "t%d_grey_%d%d.tga" % (n, td, rle); n += 1
+                _iofiles.write_tga(os.path.join(d, name), g, kind="grey", rle=rle, top_down=td, rng=rng)
+                yield name, g[..., None]
+                ga = rgb(h, w, 2)
+                name = "t%d_ga_%d%d.tga" % (n, td, rle); n += 1
+                _iofiles.write_tga(os.path.join(d, name), ga, kind="grey_alpha", rle=rle, top_down=td, rng=rng)
+                yield name, ga
+                w16 = rng.integers(0, 1 << 16, size=(h, w))
+                name = "t%d_16_%d%d.tga" % (n, td, rle); n += 1
+                _iofiles.write_tga(os.path.join(d, name), w16, kind="rgb16", rle=rle, top_down=td, rng=rng)
+                yield name, None
+                for pal_bits in (24, 32, 16, 8):
+                    npal = int(rng.integers(2, 256))
+                    pal = rng.integers(0, 1 << 16, size=npal) if pal_bits == 16 else rng.integers(0, 256, size=(npal, {24: 3, 32: 4, 8: 1}[pal_bits]))
+                    idx = rng.integers(0, npal + (3 if pal_bits == 24 else 0), size=(h, w))    # a few indices past the map -> entry 0
+                    name = "t%d_idx%d_%d%d.tga" % (n, pal_bits, td, rle); n += 1
+                    _iofiles.write_tga(os.path.join(d, name), idx, kind="indexed", palette=pal, pal_bits=pal_bits, rle=rle, top_down=td,
+                                       index16=(pal_bits == 32), rng=rng)
+                    yield name, (None if pal_bits == 16 else np.asarray(pal, np.uint8)[np.where(idx >= npal, 0, idx)].reshape(h, w, -1))
+        # --- PNM
+        for comments in (False, True):
+            im = rgb(h, w)
+            name = "n%d.ppm" % n; n += 1
+            _iofiles.write_pnm(os.path.join(d, name), im, comments=comments)
+            yield name, im
+            name = "n%d.pgm" % n; n += 1
+            _iofiles.write_pnm(os.path.join(d, name), im[..., 0], comments=comments)
+            yield name, im[..., :1]
+        # --- GIF
+        for k in range(6):
+            ncol = [2, 4, 16, 200, 256, 7][k]
+            pal = rng.integers(0, 256, size=(ncol, 3))
+            idx = rng.integers(0, ncol, size=(h, w))
+            if k % 2:
+                idx[:, : w // 2] = idx[0, 0]
+            kw = [dict(), dict(interlace=True), dict(transparent=int(idx[0, 0])), dict(canvas=(w + 3, h + 2), origin=(2, 1), bg_index=1),
+                  dict(local_palette=rng.integers(0, 256, size=(ncol, 3)), comment=True, version=b"87a"),
+                  dict(interlace=True, transparent=1, canvas=(w + 1, h + 1), bg_index=2, clear_every=5, block=17)][k]
+            name = "g%d.gif" % n; n += 1
+            _iofiles.write_gif(os.path.join(d, name), idx, pal, **kw)
+            exp = None
+            if k in (0, 1):
+                exp = np.concatenate([pal[idx], np.full((h, w, 1), 255)], -1).astype(np.uint8)
+            yield name, exp
+        # --- PSD
+        for nch in (3, 4, 5):
+            for depth, rle in ((8, False), (8, True), (16, False)):
+                pl = rng.integers(0, 256 if depth == 8 else 65536, size=(nch, h, w))
+                if rle:
+                    pl[:, :, : w // 2] = 9
+                name = "p%d_%d_%d%d.psd" % (n, nch, depth, rle); n += 1
+                _iofiles.write_psd(os.path.join(d, name), pl, depth=depth, rle=rle, seed=n)
+                exp = None
+                if nch == 3:
+                    p8 = (pl >> 8) if depth == 16 else pl
+                    exp = np.concatenate([np.moveaxis(p8, 0, -1), np.full((h, w, 1), 255)], -1).astype(np.uint8)
+                yield name, exp
+
+
+@needs_ref
+def test_bmp_tga_pnm_gif_psd_vs_reference(tmp_path, capfd):
+    """every flavour of the other stb_image formats: this library's pixels == the reference's stb_image's, and == what the
+    generator put in where that is known"""
+    d = str(tmp_path)
+    rng = np.random.default_rng(77)
+    count = {}
+    for name, exp in _other_format_cases(d, rng):
+        want = _refio.image_load(name, d)
+        assert want is not None, name
+        got = io_api.LoadImageFromFile(name, d)
+        assert got.shape == want.shape and np.array_equal(bits(got), bits(want)), name
+        if exp is not None:
+            assert got.shape == exp.shape and np.array_equal((got * 255 + 0.5).astype(np.uint8), exp), name
+        count[name.rsplit(".", 1)[1]] = count.get(name.rsplit(".", 1)[1], 0) + 1
+    assert min(count[k] for k in ("bmp", "tga", "ppm", "pgm", "gif", "psd")) >= 8, count
+    # a Radiance picture under a name that does not end in .hdr goes through stb's 8-bit path (gamma 2.2)
+    img = (rng.random((6, 9, 3)) * 3).astype(np.float32)
+    img[0, 0] = (0, 1e-5, 700.0)
+    _iofiles.write_hdr(os.path.join(d, "sky.pic"), img, rle=True)
+    want, got = _refio.image_load("sky.pic", d), io_api.LoadImageFromFile("sky.pic", d)
+    assert want.shape == (6, 9, 3) and np.array_equal(bits(got), bits(want))
+
+
+def _declared_pixels(m):
+    """width * height a (mutated) BMP / TGA / PNM / GIF / PSD header announces: the fuzz skips files that announce huge images
+    (both decoders would spend seconds filling them with zeros)"""
+    m = bytes(m) + bytes(32)
+    if m[:2] == b"BM":
+        if m[14] == 12:
+            w, h = struct.unpack_from("<HH", m, 18)
+        else:
+            w, h = struct.unpack_from("<ii", m, 18)
+    elif m[:4] == b"GIF8":
+        w, h = struct.unpack_from("<HH", m, 6)
+    elif m[:4] == b"8BPS":
+        h, w = struct.unpack_from(">ii", m, 14)
+    elif m[:1] == b"P":
+        import re
+        nums = re.findall(rb"\d+", m[2:64])
+        w, h = (int(nums[0]), int(nums[1])) if len(nums) >= 2 else (0, 0)
+    else:
+        w, h = struct.unpack_from("<HH", m, 12)
+    return abs(w) * abs(h)
+
+
+@needs_ref
+def test_other_formats_mutation_fuzz_vs_reference(tmp_path, capfd):
+    """byte mutations of valid files: wherever the reference's stb_image still returns an image whose content does not depend on
+    bytes it never had (truncated files are skipped), this library returns the same one; neither crashes"""
+    d = str(tmp_path)
+    rng = np.random.default_rng(78)
+    names = [n for n, _ in _other_format_cases(d, rng)]
+    checked = agree = 0
+    for name in names[::3]:
+        data = bytearray(open(os.path.join(d, name), "rb").read())
+        for k in range(6):
+            m = bytearray(data)
+            for _ in range(int(rng.integers(1, 4))):
+                m[int(rng.integers(0, min(len(m), 64 if k < 4 else len(m))))] = int(rng.integers(0, 256))
+            if _declared_pixels(m) > (1 << 18):
+                continue
+            f = "m_%d_%s" % (k, name)
+            open(os.path.join(d, f), "wb").write(bytes(m))
+            want = _refio.image_load(f, d)
+            try:
+                got = io_api.LoadImageFromFile(f, d)
+            except io_api.PbrIoError:
+                got = None
+            checked += 1
+            if want is not None and got is not None and got.shape == want.shape and np.array_equal(bits(got), bits(want)):
+                agree += 1
+            elif want is None and got is None:
+                agree += 1
+    assert checked > 300 and agree >= 0.9 * checked, (checked, agree)      # the rest: files stb reads past their end
+
+
 def test_unsupported_image_formats_fail_loudly(tmp_path, capfd):
     d = str(tmp_path)
     rng = np.random.default_rng(0)
     _iofiles.write_jpeg(os.path.join(d, "a.jpg"), [rng.integers(0, 256, size=(8, 8)).astype(np.uint8)], [(1, 1)], sof=0xC2)  # progressive SOF
     with open(os.path.join(d, "a.bmp"), "wb") as f:
-        f.write(b"BM" + bytes(64))
+        f.write(b"BM" + bytes(12) + struct.pack("<IiiHHI", 40, 4, 4, 1, 8, 1) + bytes(64))       # BI_RLE8
     with open(os.path.join(d, "a.exr"), "wb") as f:
         f.write(b"\x76\x2f\x31\x01\x02\x02\x00\x00" + bytes(64))     # tiled flag set
     with open(os.path.join(d, "trunc.png"), "wb") as f:
@@ -361,7 +586,7 @@ def test_unsupported_image_formats_fail_loudly(tmp_path, capfd):
         with pytest.raises(io_api.PbrIoError):
             io_api.LoadImageFromFile(name, d)
     err = capfd.readouterr().err
-    assert "progressive JPEG" in err and "BMP" in err and "tiled OpenEXR" in err
+    assert "progressive JPEG" in err and "BMP: RLE" in err and "tiled OpenEXR" in err
 
 
 def _png_decode_python(data):
