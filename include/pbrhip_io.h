@@ -7,8 +7,9 @@
  *   CreateScene / CreateSceneFromObj / CreateSceneFromCubicBezierCurve   pc/pc-common.cc:100-270
  *   pbrlab::io::LoadImageFromFile / WritePNG   src/io/image-io.cc:98-224
  *   the output stage of pbrlab-cli             pc/pbrlab-cli.cc:47-57 (rgba/count -> sRGB -> 8-bit PNG)
- * Image files read: PNG, baseline JPEG, Radiance .hdr, scanline OpenEXR (NONE/RLE/ZIPS/ZIP).  Not decoded by this
- * build: progressive JPEG, Softimage PIC and tiled or PIZ/PXR24/B44 OpenEXR textures (the call fails and says so). */
+ * Image files read: PNG, JPEG (baseline and progressive), BMP, TGA, GIF, PSD, PNM, Radiance .hdr, scanline OpenEXR
+ * (NONE/RLE/ZIPS/ZIP) -- pixel for pixel what the reference's stb_image / tinyexr return.  Not decoded by this build:
+ * Softimage PIC and tiled or PIZ/PXR24/B44 OpenEXR textures (the call fails and says so). */
 #ifndef PBRHIP_IO_H_
 #define PBRHIP_IO_H_
 

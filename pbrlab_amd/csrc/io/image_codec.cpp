@@ -642,6 +642,8 @@ struct JpegComp {
   int id = 0, h = 0, v = 0, tq = 0, hd = 0, ha = 0, dc_pred = 0;
   int x = 0, y = 0, w2 = 0, h2 = 0;
   std::vector<uint8_t> data;
+  std::vector<short> coeff;  // progressive: 64 coefficients per block, (w2 / 8) blocks per row
+  int coeff_w = 0;
 };
 
 struct JpegDecoder {
@@ -658,6 +660,7 @@ struct JpegDecoder {
   int scan_n = 0, order[4] = {0, 0, 0, 0};
   int rgb = 0, jfif = 0, app14 = -1;
   bool progressive = false;
+  int spec_start = 0, spec_end = 63, succ_high = 0, succ_low = 0, eob_run = 0;  // progressive scan parameters
   std::string err;
 
   int get8() { return pos < n ? p[pos++] : 0; }
@@ -742,11 +745,120 @@ struct JpegDecoder {
     } while (k < 64);
     return true;
   }
+  int get_bits(int nb) {
+    if (code_bits < nb) grow();
+    uint32_t k = (code_buffer << nb) | (code_buffer >> (32 - nb));
+    const uint32_t mask = (1u << nb) - 1u;
+    code_buffer = k & ~mask;
+    code_bits -= nb;
+    return int(k & mask);
+  }
+  bool get_bit() {
+    if (code_bits < 1) grow();
+    const uint32_t k = code_buffer;
+    code_buffer <<= 1;
+    --code_bits;
+    return (k & 0x80000000u) != 0;
+  }
+  // Progressive scans (ITU T.81 annex G): one spectral band / one bit plane of the coefficients per scan.
+  // DC: first pass codes the difference of (value >> Al); refinement passes add one bit each
+  bool prog_dc(short* data, int b) {
+    if (spec_end != 0) return fail("progressive JPEG: DC and AC in one scan");
+    JpegComp& c = comp[b];
+    if (code_bits < 16) grow();
+    if (succ_high == 0) {
+      memset(data, 0, 64 * sizeof(short));
+      const int t = huff_decode(huff_dc[c.hd]);
+      if (t < 0 || t > 15) return fail("bad huffman code in JPEG");
+      const int diff = t ? extend_receive(t) : 0;
+      const int dc = c.dc_pred + diff;
+      c.dc_pred = dc;
+      data[0] = short(uint32_t(dc) << succ_low);
+    } else if (get_bit()) {
+      data[0] = short(data[0] + short(1 << succ_low));
+    }
+    return true;
+  }
+  // AC: first pass codes run/size pairs with end-of-band runs spanning blocks; refinement passes append one bit to every
+  // coefficient that is already non-zero while placing new +-1 coefficients
+  bool prog_ac(short* data, int b) {
+    if (spec_start == 0) return fail("progressive JPEG: DC and AC in one scan");
+    const JpegHuff& hac = huff_ac[comp[b].ha];
+    if (succ_high == 0) {
+      if (eob_run) {
+        --eob_run;
+        return true;
+      }
+      int k = spec_start;
+      do {
+        if (code_bits < 16) grow();
+        const int rs = huff_decode(hac);
+        if (rs < 0) return fail("bad huffman code in JPEG");
+        const int sbits = rs & 15, r = rs >> 4;
+        if (sbits == 0) {
+          if (r < 15) {
+            eob_run = 1 << r;
+            if (r) eob_run += get_bits(r);
+            --eob_run;
+            break;
+          }
+          k += 16;
+        } else {
+          k += r;
+          const unsigned zig = kZigzag[k++];
+          data[zig] = short(uint32_t(extend_receive(sbits)) << succ_low);
+        }
+      } while (k <= spec_end);
+      return true;
+    }
+    const short bit = short(1 << succ_low);
+    auto refine = [&](short* p) {  // one correction bit for a coefficient that is already non-zero
+      if (get_bit() && (*p & bit) == 0) *p = short(*p > 0 ? *p + bit : *p - bit);
+    };
+    if (eob_run) {
+      --eob_run;
+      for (int k = spec_start; k <= spec_end; ++k) {
+        short* p = &data[kZigzag[k]];
+        if (*p != 0) refine(p);
+      }
+      return true;
+    }
+    int k = spec_start;
+    do {
+      const int rs = huff_decode(hac);
+      if (rs < 0) return fail("bad huffman code in JPEG");
+      int sbits = rs & 15, r = rs >> 4;
+      if (sbits == 0) {
+        if (r < 15) {
+          eob_run = (1 << r) - 1;
+          if (r) eob_run += get_bits(r);
+          r = 64;  // to the end of the band
+        }
+      } else {
+        if (sbits != 1) return fail("bad huffman code in JPEG");
+        sbits = get_bit() ? bit : -bit;
+      }
+      while (k <= spec_end) {
+        short* p = &data[kZigzag[k++]];
+        if (*p != 0) {
+          refine(p);
+        } else {
+          if (r == 0) {
+            *p = short(sbits);
+            break;
+          }
+          --r;
+        }
+      }
+    } while (k <= spec_end);
+    return true;
+  }
   void reset() {
     code_bits = 0, code_buffer = 0, nomore = 0;
     for (JpegComp& c : comp) c.dc_pred = 0;
     marker = 0xff;
     todo = restart_interval ? restart_interval : 0x7fffffff;
+    eob_run = 0;
   }
   int get_marker() {
     if (marker != 0xff) {
@@ -973,7 +1085,7 @@ bool DecodeJpeg(const uint8_t* file, size_t n, std::vector<uint8_t>* pixels, siz
       m = z.get_marker();
     }
   }
-  if (m == 0xc2) return bail("progressive JPEG is not decoded by this build (re-save as baseline, or as PNG)");
+  z.progressive = (m == 0xc2);
   {
     const int Lf = z.get16();
     if (Lf < 11) return bail("bad SOF length");
@@ -1004,6 +1116,7 @@ bool DecodeJpeg(const uint8_t* file, size_t n, std::vector<uint8_t>* pixels, siz
       k.y = (z.img_y * k.v + z.v_max - 1) / z.v_max;
       k.w2 = z.mcu_x * k.h * 8, k.h2 = z.mcu_y * k.v * 8;
       k.data.assign(size_t(k.w2) * size_t(k.h2), 0);
+      if (z.progressive) k.coeff_w = k.w2 / 8, k.coeff.assign(size_t(k.w2) * size_t(k.h2), 0);
     }
   }
   // scans
@@ -1024,15 +1137,57 @@ bool DecodeJpeg(const uint8_t* file, size_t n, std::vector<uint8_t>* pixels, siz
         if (z.comp[which].hd > 3 || z.comp[which].ha > 3) return bail("bad SOS huffman table index");
         z.order[i] = which;
       }
-      const int ss = z.get8();
-      z.get8();
+      z.spec_start = z.get8(), z.spec_end = z.get8();
       const int aa = z.get8();
-      if (ss != 0 || aa != 0) return bail("bad SOS");
+      z.succ_high = aa >> 4, z.succ_low = aa & 15;
+      if (z.progressive) {
+        if (z.spec_start > 63 || z.spec_end > 63 || z.spec_start > z.spec_end || z.succ_high > 13 || z.succ_low > 13) return bail("bad SOS");
+      } else {
+        if (z.spec_start != 0 || aa != 0) return bail("bad SOS");
+        z.spec_end = 63;
+      }
       // entropy-coded data
       z.reset();
       short data[64];
       bool stop = false;
-      if (z.scan_n == 1) {
+      auto restart_or_stop = [&]() {  // after each MCU: at a restart interval's end a restart marker must follow
+        if (--z.todo > 0) return false;
+        if (z.code_bits < 24) z.grow();
+        if (!(z.marker >= 0xd0 && z.marker <= 0xd7)) return true;  // not a restart: keep what was decoded
+        z.reset();
+        return false;
+      };
+      if (z.progressive && z.scan_n == 1) {
+        const int c = z.order[0];
+        JpegComp& k = z.comp[c];
+        const int bw = (k.x + 7) >> 3, bh = (k.y + 7) >> 3;
+        for (int j = 0; j < bh && !stop; ++j)
+          for (int i = 0; i < bw; ++i) {
+            short* blk = k.coeff.data() + 64 * (size_t(i) + size_t(j) * size_t(k.coeff_w));
+            if (!(z.spec_start == 0 ? z.prog_dc(blk, c) : z.prog_ac(blk, c))) return bail(z.err.c_str());
+            if (restart_or_stop()) {
+              stop = true;
+              break;
+            }
+          }
+      } else if (z.progressive) {  // interleaved: DC only
+        for (int j = 0; j < z.mcu_y && !stop; ++j)
+          for (int i = 0; i < z.mcu_x; ++i) {
+            for (int s = 0; s < z.scan_n; ++s) {
+              const int c = z.order[s];
+              JpegComp& k = z.comp[c];
+              for (int y = 0; y < k.v; ++y)
+                for (int x = 0; x < k.h; ++x) {
+                  const size_t x2 = size_t(i * k.h + x), y2 = size_t(j * k.v + y);
+                  if (!z.prog_dc(k.coeff.data() + 64 * (x2 + y2 * size_t(k.coeff_w)), c)) return bail(z.err.c_str());
+                }
+            }
+            if (restart_or_stop()) {
+              stop = true;
+              break;
+            }
+          }
+      } else if (z.scan_n == 1) {
         const int c = z.order[0];
         JpegComp& k = z.comp[c];
         const int bw = (k.x + 7) >> 3, bh = (k.y + 7) >> 3;
@@ -1087,6 +1242,20 @@ bool DecodeJpeg(const uint8_t* file, size_t n, std::vector<uint8_t>* pixels, siz
       if (!process_marker(m)) return bail(z.err.c_str());
     }
     m = z.get_marker();
+  }
+  if (z.progressive) {  // all scans are in: dequantise and transform every block
+    short data[64];
+    for (int c = 0; c < z.img_n; ++c) {
+      JpegComp& k = z.comp[c];
+      const int bw = (k.x + 7) >> 3, bh = (k.y + 7) >> 3;
+      const uint16_t* dq = z.dequant[k.tq];
+      for (int j = 0; j < bh; ++j)
+        for (int i = 0; i < bw; ++i) {
+          const short* blk = k.coeff.data() + 64 * (size_t(i) + size_t(j) * size_t(k.coeff_w));
+          for (int t = 0; t < 64; ++t) data[t] = short(int(blk[t]) * int(dq[t]));
+          jpeg_idct(k.data.data() + size_t(k.w2) * size_t(j) * 8 + size_t(i) * 8, k.w2, data);
+        }
+    }
   }
   // upsample + colour conversion (load_jpeg_image)
   const int out_n = z.img_n >= 3 ? 3 : 1;

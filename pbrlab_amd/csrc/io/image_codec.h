@@ -3,11 +3,11 @@
 // to the vendored stb_image / stb_image_write), src/image-utils.cc:8-107 (sRGB transfer functions).
 //
 // Written from scratch: a zlib inflater/deflater, PNG reader (all colour types and bit depths, Adam7) and writer,
-// baseline JPEG reader, Radiance .hdr reader, scanline OpenEXR reader.  Decoded pixels equal stb_image's / tinyexr's for
+// baseline + progressive JPEG reader, Radiance .hdr reader, scanline OpenEXR reader.  Decoded pixels equal stb_image's / tinyexr's for
 // the same file (16-bit PNG samples keep their high byte, sub-byte grey is scaled to 0..255, a tRNS colour key becomes
 // an alpha channel; JPEG through stb's integer IDCT, upsampling filters and fixed-point colour conversion).
-// BMP, TGA, PNM, GIF and PSD are in image_formats.cpp.  Progressive JPEG, Softimage PIC and tiled / PIZ-compressed OpenEXR
-// are NOT decoded by this build: loading such a file fails with a message naming the format.
+// BMP, TGA, PNM, GIF and PSD are in image_formats.cpp.  Softimage PIC and tiled / PIZ-compressed OpenEXR are NOT decoded by
+// this build: loading such a file fails with a message naming the format.
 #ifndef PBRLAB_AMD_IO_IMAGE_CODEC_H_
 #define PBRLAB_AMD_IO_IMAGE_CODEC_H_
 
@@ -31,8 +31,8 @@ bool DecodePng(const uint8_t* file, size_t n, std::vector<uint8_t>* pixels, size
 bool DecodeHdr(const uint8_t* file, size_t n, std::vector<float>* pixels, size_t* width, size_t* height,
                std::string* err);
 
-// baseline / extended-sequential Huffman JPEG (1, 3 or 4 components, any sampling factors, restart intervals) -> 1 or 3
-// channels of 8 bits, the bytes stb_image returns (stbi_load, req_comp = 0).  Progressive files are refused.
+// baseline / extended-sequential / progressive Huffman JPEG (1, 3 or 4 components, any sampling factors, restart intervals)
+// -> 1 or 3 channels of 8 bits, the bytes stb_image returns (stbi_load, req_comp = 0).
 bool DecodeJpeg(const uint8_t* file, size_t n, std::vector<uint8_t>* pixels, size_t* width, size_t* height, size_t* channels,
                 std::string* err);
 

@@ -12,7 +12,7 @@ cd $gold && /tmp/pbrio_fuzz/fuzz ${1:-300} tex0.png tex3.png tex5.png tex8.png t
     case11.obj strands0.hair strands1.hair strands3.hair strands4.hair \
     o_24.bmp o_32_topdown.bmp o_pal4.bmp o_pal1_v4.bmp o_565.bmp o_4444_v5.bmp o_rgb_rle.tga o_rgba_topdown.tga o_555.tga \
     o_grey_alpha_rle.tga o_indexed.tga o_indexed16.tga o.ppm o.pgm o_plain.gif o_interlaced_transparent.gif o_local_palette.gif \
-    o_rgb16.psd o_rgba_rle.psd o_5ch.psd o_radiance.pic
+    o_rgb16.psd o_rgba_rle.psd o_5ch.psd o_radiance.pic prog0.jpg prog1.jpg prog2.jpg
 # host SAH builder: random / degenerate primitive sets, structural validation of the flattened tree
 cs=$here/../../pbrlab_amd/csrc
 /opt/rocm/bin/hipcc --offload-host-only -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=undefined -I$cs -I$here/../../include \

@@ -572,6 +572,173 @@ def write_jpeg(path, planes, sampling, *, quant=None, restart=0, quant16=False, 
     return W, H
 
 
+# symbols a progressive AC table needs: run/size pairs, ZRL, and the end-of-band run symbols EOB0..EOB14 (all 9-bit codes)
+_PROG_AC_SYMS = [0x00, 0xF0] + [(r << 4) | sz for r in range(16) for sz in range(1, 11)] + [r << 4 for r in range(1, 15)]
+_PROG_AC_L = ([0] * 8 + [len(_PROG_AC_SYMS)] + [0] * 7, _PROG_AC_SYMS)
+
+# libjpeg's default script for three components, and simpler ones
+PROGRESSIVE_SCRIPTS = {
+    "default3": [([0, 1, 2], 0, 0, 0, 1), ([0], 1, 5, 0, 2), ([2], 1, 63, 0, 1), ([1], 1, 63, 0, 1), ([0], 6, 63, 0, 2), ([0], 1, 63, 2, 1),
+                 ([0, 1, 2], 0, 0, 1, 0), ([2], 1, 63, 1, 0), ([1], 1, 63, 1, 0), ([0], 1, 63, 1, 0)],
+    "spectral3": [([0, 1, 2], 0, 0, 0, 0), ([0], 1, 9, 0, 0), ([1], 1, 63, 0, 0), ([2], 1, 63, 0, 0), ([0], 10, 63, 0, 0)],
+    "deep1": [([0], 0, 0, 0, 3), ([0], 1, 63, 0, 3), ([0], 0, 0, 3, 2), ([0], 1, 63, 3, 2), ([0], 1, 20, 2, 1), ([0], 21, 63, 2, 1), ([0], 0, 0, 2, 1),
+              ([0], 0, 0, 1, 0), ([0], 1, 63, 1, 0)],
+    "gray": [([0], 0, 0, 0, 1), ([0], 1, 63, 0, 1), ([0], 0, 0, 1, 0), ([0], 1, 63, 1, 0)],
+    "dc_separate3": [([0], 0, 0, 0, 0), ([1], 0, 0, 0, 0), ([2], 0, 0, 0, 0), ([0], 1, 63, 0, 1), ([1], 1, 63, 0, 1), ([2], 1, 63, 0, 1),
+                     ([0], 1, 63, 1, 0), ([1], 1, 63, 1, 0), ([2], 1, 63, 1, 0)],
+    "four": [([0, 1, 2, 3], 0, 0, 0, 0), ([0], 1, 63, 0, 0), ([1], 1, 63, 0, 0), ([2], 1, 63, 0, 0), ([3], 1, 63, 0, 0)],
+}
+
+
+def write_jpeg_progressive(path, planes, sampling, script, *, quant=None, restart=0, ids=None, adobe=None, jfif=True):
+    """progressive (SOF2) JPEG of the same coefficients write_jpeg would code; script: [(components, Ss, Se, Ah, Al)]"""
+    nc = len(planes)
+    hmax, vmax = max(s[0] for s in sampling), max(s[1] for s in sampling)
+    H = min(p.shape[0] * vmax // s[1] for p, s in zip(planes, sampling) if s[1] == vmax)
+    W = min(p.shape[1] * hmax // s[0] for p, s in zip(planes, sampling) if s[0] == hmax)
+    q = np.asarray(quant if quant is not None else np.full(64, 8), np.int64).reshape(64)
+    ids = ids or list(range(1, nc + 1))
+    dcl, acl = _huff_codes(*_STD_DC_L), _huff_codes(*_PROG_AC_L)
+    x = np.arange(8)
+    Cm = np.cos((2 * x[None, :] + 1) * x[:, None] * np.pi / 16) * np.where(x[:, None] == 0, np.sqrt(1 / 8), np.sqrt(2 / 8))
+    mcux, mcuy = -(-W // (8 * hmax)), -(-H // (8 * vmax))
+    coefs = []
+    for ci in range(nc):
+        p = planes[ci].astype(np.float64)
+        hh, ww = mcuy * sampling[ci][1] * 8, mcux * sampling[ci][0] * 8
+        pad = np.zeros((hh, ww))
+        ph, pw = p.shape
+        pad[:ph, :pw] = p
+        pad[:ph, pw:] = p[:, -1:]
+        pad[ph:, :] = pad[ph - 1:ph, :]
+        cf = {}
+        for by in range(hh // 8):
+            for bx in range(ww // 8):
+                d = Cm @ (pad[by * 8:by * 8 + 8, bx * 8:bx * 8 + 8] - 128.0) @ Cm.T
+                c = np.rint(d.reshape(64) / q).astype(np.int64)
+                cf[(by, bx)] = [int(c[_ZZ[k]]) for k in range(64)]          # zigzag order
+        coefs.append(cf)
+
+    def seg(marker, payload):
+        return bytes([0xFF, marker]) + struct.pack(">H", len(payload) + 2) + payload
+
+    out = bytearray(b"\xFF\xD8")
+    if jfif:
+        out += seg(0xE0, b"JFIF\x00\x01\x01\x00\x00\x01\x00\x01\x00\x00")
+    if adobe is not None:
+        out += seg(0xEE, b"Adobe\x00\x64\x00\x00\x00\x00" + bytes([adobe]))
+    out += seg(0xDB, bytes([0x00]) + bytes([int(q[_ZZ[k]]) for k in range(64)]))
+    out += seg(0xC2, bytes([8]) + struct.pack(">HH", H, W) + bytes([nc]) + b"".join(bytes([ids[i], (sampling[i][0] << 4) | sampling[i][1], 0]) for i in range(nc)))
+    for tc, th, (bits, vals) in ((0, 0, _STD_DC_L), (1, 0, _PROG_AC_L)):
+        out += seg(0xC4, bytes([(tc << 4) | th]) + bytes(bits) + bytes(vals))
+    if restart:
+        out += seg(0xDD, struct.pack(">H", restart))
+
+    for (comp_list, ss, se, ah, al) in script:
+        out += seg(0xDA, bytes([len(comp_list)]) + b"".join(bytes([ids[c], 0x00]) for c in comp_list) + bytes([ss, se, (ah << 4) | al]))
+        if len(comp_list) == 1:
+            c = comp_list[0]
+            eff_w, eff_h = -(-(W * sampling[c][0]) // hmax), -(-(H * sampling[c][1]) // vmax)
+            units = [[(c, by, bx)] for by in range((eff_h + 7) // 8) for bx in range((eff_w + 7) // 8)]
+        else:
+            units = [[(c, my * sampling[c][1] + y, mx * sampling[c][0] + xx) for c in comp_list for y in range(sampling[c][1]) for xx in range(sampling[c][0])]
+                     for my in range(mcuy) for mx in range(mcux)]
+        bw = _Bits()
+        st = dict(pred={c: 0 for c in comp_list}, eobrun=0, be=[])
+
+        def emit_eobrun():
+            if st["eobrun"] > 0:
+                nb = st["eobrun"].bit_length() - 1
+                bw.put(*acl[nb << 4])
+                if nb:
+                    bw.put(st["eobrun"] & ((1 << nb) - 1), nb)
+                st["eobrun"] = 0
+            for b in st["be"]:
+                bw.put(b, 1)
+            st["be"] = []
+
+        def code_block(c, zz):
+            if ss == 0:
+                if ah == 0:                                   # DC, first pass: difference of the shifted value
+                    v = zz[0] >> al
+                    diff = v - st["pred"][c]
+                    st["pred"][c] = v
+                    mag = abs(diff).bit_length()
+                    bw.put(*dcl[mag])
+                    if mag:
+                        bw.put(diff if diff >= 0 else diff + (1 << mag) - 1, mag)
+                else:                                         # DC refinement: one more bit
+                    bw.put((zz[0] >> al) & 1, 1)
+                return
+            a = [abs(zz[k]) >> al for k in range(64)]
+            if ah == 0:                                       # AC, first pass
+                r = 0
+                for k in range(ss, se + 1):
+                    if a[k] == 0:
+                        r += 1
+                        continue
+                    emit_eobrun()
+                    while r > 15:
+                        bw.put(*acl[0xF0])
+                        r -= 16
+                    nb = a[k].bit_length()
+                    bw.put(*acl[(r << 4) | nb])
+                    bw.put(a[k] if zz[k] >= 0 else (~a[k]) & ((1 << nb) - 1), nb)
+                    r = 0
+                if r > 0:
+                    st["eobrun"] += 1
+                    if st["eobrun"] == 0x7FFF:
+                        emit_eobrun()
+                return
+            # AC refinement
+            last_new = max([k for k in range(ss, se + 1) if a[k] == 1], default=-1)
+            r, br = 0, []
+            for k in range(ss, se + 1):
+                if a[k] == 0:
+                    r += 1
+                    continue
+                while r > 15 and k <= last_new:
+                    emit_eobrun()
+                    bw.put(*acl[0xF0])
+                    r -= 16
+                    for b in br:
+                        bw.put(b, 1)
+                    br = []
+                if a[k] > 1:                                  # non-zero before this pass: one correction bit
+                    br.append(a[k] & 1)
+                    continue
+                emit_eobrun()
+                bw.put(*acl[(r << 4) | 1])
+                bw.put(1 if zz[k] >= 0 else 0, 1)
+                for b in br:
+                    bw.put(b, 1)
+                br, r = [], 0
+            if r > 0 or br:
+                st["eobrun"] += 1
+                st["be"] += br
+                if st["eobrun"] == 0x7FFF or len(st["be"]) > 900:
+                    emit_eobrun()
+
+        rst = 0
+        for ui, u in enumerate(units):
+            for (c, by, bx) in u:
+                code_block(c, coefs[c][(by, bx)])
+            if restart and (ui + 1) % restart == 0 and ui + 1 < len(units):
+                emit_eobrun()
+                bw.flush()
+                out += bw.out + bytes([0xFF, 0xD0 + (rst & 7)])
+                rst += 1
+                bw = _Bits()
+                st["pred"] = {c: 0 for c in comp_list}
+        emit_eobrun()
+        bw.flush()
+        out += bw.out
+    out += b"\xFF\xD9"
+    with open(path, "wb") as f:
+        f.write(out)
+    return W, H
+
+
 # ------------------------------------------------------------------ BMP / TGA / PNM / GIF / PSD test-file writers
 def write_bmp(path, img, *, bpp=24, header=40, top_down=False, palette=None, masks=None, compress=None, gap=0):
     """img: (h, w, c) uint8 for 24/32 bpp; (h, w) palette indices for 1/4/8; (h, w) raw pixel words for 16/32 with masks.

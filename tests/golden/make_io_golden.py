@@ -140,6 +140,14 @@ def main():
     for i in range(len(JPEG_CASES) + 2):
         g["jpg%d" % i] = _refio.image_load("photo%d.jpg" % i, OUT)
         assert g["jpg%d" % i] is not None
+    # progressive JPEG (test encoder; the same coefficients as a baseline file)
+    for i, (W, H, samp, script, kw) in enumerate([(37, 29, [(2, 2), (1, 1), (1, 1)], "default3", {}), (23, 40, [(1, 1)], "deep1", dict(restart=2)),
+                                                  (30, 21, [(1, 1)] * 3, "spectral3", {})]):
+        hmax, vmax = max(s[0] for s in samp), max(s[1] for s in samp)
+        planes = [plane(-(-H * s[1] // vmax), -(-W * s[0] // hmax), k) for k, s in enumerate(samp)]
+        _iofiles.write_jpeg_progressive(os.path.join(OUT, "prog%d.jpg" % i), planes, samp, _iofiles.PROGRESSIVE_SCRIPTS[script], **kw)
+        g["pjpg%d" % i] = _refio.image_load("prog%d.jpg" % i, OUT)
+        assert g["pjpg%d" % i] is not None
     # the other stb_image formats: BMP, TGA, PNM, GIF, PSD, and a Radiance picture under a non-.hdr name
     for name in write_other_format_fixtures(OUT):
         g["other_" + name] = _refio.image_load(name, OUT)

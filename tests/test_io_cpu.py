@@ -285,6 +285,60 @@ def test_jpeg_decode_fuzz_vs_reference(tmp_path, capfd):
             n += 1
 
 
+PROG_CASES = [("gray", [(1, 1)], "gray", {}), ("default420", [(2, 2), (1, 1), (1, 1)], "default3", {}), ("spectral444", [(1, 1)] * 3, "spectral3", {}),
+              ("deep", [(1, 1)], "deep1", {}), ("dcsep422", [(2, 1), (1, 1), (1, 1)], "dc_separate3", {}), ("rst", [(2, 2), (1, 1), (1, 1)], "default3", dict(restart=3)),
+              ("cmyk", [(1, 1)] * 4, "four", dict(adobe=0, jfif=False)), ("rst1", [(1, 1)], "deep1", dict(restart=1)),
+              ("mixed", [(2, 2), (2, 1), (1, 2)], "default3", {})]
+
+
+@pytest.mark.parametrize("i", range(3))
+def test_progressive_jpeg_golden(i, capfd):
+    """progressive JPEG (spectral selection + successive approximation, EOB runs, refinement passes) == stb_image's pixels"""
+    got = io_api.LoadImageFromFile("prog%d.jpg" % i, GOLD_DIR)
+    want = GOLD["pjpg%d" % i]
+    assert got.shape == want.shape and np.array_equal(bits(got), bits(want))
+
+
+@needs_ref
+def test_progressive_jpeg_vs_reference(tmp_path, capfd):
+    """progressive files from the test encoder, several scan scripts: this decoder == the reference's stb_image == the baseline
+    file of the same coefficients (which pins the test encoder too)"""
+    d = str(tmp_path)
+    rng = np.random.default_rng(41)
+    n = 0
+    for (W, H) in [(1, 1), (9, 7), (33, 17), (47, 70)]:
+        for name, samp, script, kw in PROG_CASES:
+            hmax, vmax = max(s[0] for s in samp), max(s[1] for s in samp)
+            planes = [_jpeg_plane(rng, -(-H * s[1] // vmax), -(-W * s[0] // hmax), k) for k, s in enumerate(samp)]
+            if n % 3 == 0:
+                planes = [rng.integers(0, 256, size=p.shape).astype(np.uint8) for p in planes]      # noise: many non-zero coefficients
+            quant = [None, np.arange(1, 65), np.full(64, 2)][n % 3]
+            fb, fp = "b%d_%s.jpg" % (n, name), "p%d_%s.jpg" % (n, name)
+            bkw = {k: v for k, v in kw.items() if k != "restart"}
+            _iofiles.write_jpeg(os.path.join(d, fb), planes, samp, quant=quant, **bkw)
+            _iofiles.write_jpeg_progressive(os.path.join(d, fp), planes, samp, _iofiles.PROGRESSIVE_SCRIPTS[script], quant=quant, **kw)
+            base, want, got = _refio.image_load(fb, d), _refio.image_load(fp, d), io_api.LoadImageFromFile(fp, d)
+            assert want is not None and np.array_equal(bits(base), bits(want)), (W, H, name)
+            assert got.shape == want.shape and np.array_equal(bits(got), bits(want)), (W, H, name)
+            n += 1
+    # mutations: same verdict and pixels as the reference wherever it still decodes
+    data = bytearray(open(os.path.join(d, fp), "rb").read())
+    same = total = 0
+    for k in range(150):
+        m = bytearray(data)
+        for _ in range(int(rng.integers(1, 4))):
+            m[int(rng.integers(20, len(m)))] = int(rng.integers(0, 256))
+        open(os.path.join(d, "mut.jpg"), "wb").write(bytes(m))
+        want = _refio.image_load("mut.jpg", d)
+        try:
+            got = io_api.LoadImageFromFile("mut.jpg", d)
+        except io_api.PbrIoError:
+            got = None
+        total += 1
+        same += (want is None and got is None) or (want is not None and got is not None and got.shape == want.shape and np.array_equal(bits(got), bits(want)))
+    assert same >= 0.95 * total, (same, total)
+
+
 @pytest.mark.parametrize("i", range(6))
 def test_exr_decode_golden(i, capfd):
     """scanline OpenEXR written by tinyexr (NONE/RLE/ZIPS/ZIP, HALF/FLOAT, 1/3/4 channels, both line orders) == tinyexr's LoadEXR"""
@@ -575,18 +629,20 @@ def test_other_formats_mutation_fuzz_vs_reference(tmp_path, capfd):
 def test_unsupported_image_formats_fail_loudly(tmp_path, capfd):
     d = str(tmp_path)
     rng = np.random.default_rng(0)
-    _iofiles.write_jpeg(os.path.join(d, "a.jpg"), [rng.integers(0, 256, size=(8, 8)).astype(np.uint8)], [(1, 1)], sof=0xC2)  # progressive SOF
+    _iofiles.write_jpeg(os.path.join(d, "a.jpg"), [rng.integers(0, 256, size=(8, 8)).astype(np.uint8)], [(1, 1)], sof=0xC2)  # SOF2 over a baseline scan
+    with open(os.path.join(d, "a.pic"), "wb") as f:
+        f.write(b"\x53\x80\xF6\x34" + bytes(84) + b"PICT" + bytes(32))
     with open(os.path.join(d, "a.bmp"), "wb") as f:
         f.write(b"BM" + bytes(12) + struct.pack("<IiiHHI", 40, 4, 4, 1, 8, 1) + bytes(64))       # BI_RLE8
     with open(os.path.join(d, "a.exr"), "wb") as f:
         f.write(b"\x76\x2f\x31\x01\x02\x02\x00\x00" + bytes(64))     # tiled flag set
     with open(os.path.join(d, "trunc.png"), "wb") as f:
         f.write(open(os.path.join(GOLD_DIR, "tex4.png"), "rb").read()[:60])
-    for name in ("a.jpg", "a.bmp", "a.exr", "trunc.png", "missing.png"):
+    for name in ("a.jpg", "a.pic", "a.bmp", "a.exr", "trunc.png", "missing.png"):
         with pytest.raises(io_api.PbrIoError):
             io_api.LoadImageFromFile(name, d)
     err = capfd.readouterr().err
-    assert "progressive JPEG" in err and "BMP: RLE" in err and "tiled OpenEXR" in err
+    assert "progressive JPEG: DC and AC in one scan" in err and "Softimage PIC" in err and "BMP: RLE" in err and "tiled OpenEXR" in err
 
 
 def _png_decode_python(data):
