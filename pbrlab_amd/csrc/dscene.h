@@ -152,6 +152,7 @@ struct DScene {
   const LightHead* light_heads;
   const float* lprim_cdf;
   const LightRec* lrecs;
+  const BvhNode* light_boxes;  // bounding boxes of the lights (emissive meshes), two per node, stored like BVH boxes
   const float* tex_pixels;
   const TexDesc* textures;
   uint32_t num_nodes, num_slots, num_lights, num_materials, num_curves, num_textures, num_lrecs;

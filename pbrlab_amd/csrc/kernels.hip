@@ -310,14 +310,28 @@ __device__ __forceinline__ uint32_t doomed_bit(V3 thr, uint64_t state, uint64_t 
 // A doomed path can still pick up the emission of an area light its next ray hits (path_head adds it before the roulette);
 // nothing else it does survives.  With a handful of light primitives that is decided here: if the ray misses every one
 // of them (the very test, on the very operands, the traversal would run on those primitives) the path ends now and its ray
-// is never traced.  Scenes with more light primitives than kLightPretest keep the ray (a linear scan would not pay).
+// is never traced.  Scenes with more light primitives than kLightPretest but at most kLightPretest lights (emissive meshes)
+// get the conservative version of the same argument: a ray that misses the bounding box of every light -- the traversal's
+// own slab test on boxes stored like BVH boxes (sc.light_boxes, two per node) -- cannot hit a light primitive either.
+// Beyond that the ray is kept (a linear scan would not pay).
 constexpr uint32_t kLightPretest = 8;
 __device__ __forceinline__ bool misses_all_lights(const DScene& sc, V3 o, V3 d, float tmin) {
-  if (sc.num_lrecs > kLightPretest) return false;
-  for (uint32_t i = 0; i < sc.num_lrecs; i++) {
-    const float4* lr = reinterpret_cast<const float4*>(sc.lrecs + i);
-    float t, u, v;
-    if (tri_test(ld3(lr[0]), ld3(lr[1]), ld3(lr[2]), o, d, tmin, t, u, v)) return false;
+  if (sc.num_lrecs <= kLightPretest) {
+    for (uint32_t i = 0; i < sc.num_lrecs; i++) {
+      const float4* lr = reinterpret_cast<const float4*>(sc.lrecs + i);
+      float t, u, v;
+      if (tri_test(ld3(lr[0]), ld3(lr[1]), ld3(lr[2]), o, d, tmin, t, u, v)) return false;
+    }
+    return true;
+  }
+  if (sc.num_lights > kLightPretest) return false;
+  const V3 inv(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  for (uint32_t i = 0; i < (sc.num_lights + 1u) / 2u; i++) {
+    const float4* np = reinterpret_cast<const float4*>(sc.light_boxes + i);
+    bool h0, h1;
+    float t0, t1;
+    box_test2(np[0], np[1], np[2], o, inv, tmin, kInf, h0, h1, t0, t1);
+    if (h0 || h1) return false;
   }
   return true;
 }

@@ -119,6 +119,7 @@ struct pbrhip_scene {
   DevBuf<TexDesc> d_tex_descs;
   DevBuf<LightHead> d_heads;
   DevBuf<LightRec> d_lrecs;
+  DevBuf<BvhNode> d_light_boxes;
   DScene dscene;
   // render working set (grown on demand, reused across calls)
   DevBuf<float4> ray_o, ray_d, thr, L, hit, sss[6], sh[4];
@@ -637,13 +638,25 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
   HIPCHK(s->d_heads.upload(heads, st));
   HIPCHK(s->d_lprim_cdf.upload(lprim_cdf, st));
   HIPCHK(s->d_lrecs.upload(lrecs, st));
+  // one box per light over all primitives of its mesh, packed two per node (an odd last one is stored twice)
+  std::vector<BvhNode> light_boxes((heads.size() + 1) / 2);
+  for (size_t l = 0; l < heads.size(); l++) {
+    float lo3[3] = {INFINITY, INFINITY, INFINITY}, hi3[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t f = heads[l].first; f < heads[l].first + heads[l].count; f++)
+      for (const float* p : {lrecs[f].p0, lrecs[f].p1, lrecs[f].p2})
+        for (int a = 0; a < 3; a++) lo3[a] = std::min(lo3[a], p[a]), hi3[a] = std::max(hi3[a], p[a]);
+    BvhNode& nd = light_boxes[l / 2];
+    if (l % 2 == 0) memset(&nd, 0, sizeof(nd)), nd.set_box(1, lo3, hi3);
+    nd.set_box(int(l % 2), lo3, hi3);
+  }
+  HIPCHK(s->d_light_boxes.upload(light_boxes, st));
   HIPCHK(s->d_tex_pixels.upload(s->tex_pixels, st));
   HIPCHK(s->d_tex_descs.upload(s->tex_descs, st));
   HIPCHK(hipStreamSynchronize(st));
   DScene& d = s->dscene;
   d.nodes = s->d_nodes.p, d.slots = reinterpret_cast<const float4*>(s->d_nodes.p + num_nodes), d.shade = s->d_shade.p;
   d.materials = s->d_materials.p, d.light_cdf = s->d_light_cdf.p;
-  d.light_heads = s->d_heads.p, d.lprim_cdf = s->d_lprim_cdf.p, d.lrecs = s->d_lrecs.p;
+  d.light_heads = s->d_heads.p, d.lprim_cdf = s->d_lprim_cdf.p, d.lrecs = s->d_lrecs.p, d.light_boxes = s->d_light_boxes.p;
   d.num_nodes = num_nodes, d.num_slots = ns, d.num_lights = (uint32_t)s->lights.size(), d.num_lrecs = (uint32_t)lrecs.size();
   d.num_materials = (uint32_t)mats.size();
   d.tex_pixels = s->d_tex_pixels.p, d.textures = s->d_tex_descs.p, d.num_textures = (uint32_t)s->tex_descs.size();

@@ -490,11 +490,12 @@ def test_degenerate_scenes_render_parity(pa, case):
         assert not rgba[..., :3].any()
 
 
-@pytest.mark.parametrize("nlight", [1, 2, 8, 9, 40])
-def test_doomed_path_pruning_around_the_light_count_limit(pa, nlight):
-    """Paths whose next Russian roulette is known to fail are ended in shading when their ray misses every light primitive, but
-    only in scenes with <= 8 light primitives (kLightPretest): 1, 2 and 8 light triangles prune rays, 9 and 40 do not, and in
-    every case the image and the ray total (traced + pruned) are the oracle's.  The emitter is a fan of thin triangles."""
+@pytest.mark.parametrize("nlight,nshapes", [(1, 1), (2, 1), (8, 1), (9, 1), (40, 1), (16, 8), (9, 9), (27, 9)])
+def test_doomed_path_pruning_around_the_light_limits(pa, nlight, nshapes):
+    """Paths whose next Russian roulette is known to fail are ended in shading when their ray cannot reach a light: with <= 8
+    light primitives each one is tested exactly; with more primitives but <= 8 lights (emissive meshes) the lights' bounding
+    boxes are tested; with more than 8 lights nothing is pruned.  In every case the image and the ray total (traced + pruned)
+    are the oracle's.  The emitter is a fan of thin triangles under the ceiling, split over `nshapes` meshes."""
     from pbrlab_amd import scenes
     m = lambda **kw: dict(scenes.PRINCIPLED_DEFAULTS, kind="principled", name="m", **kw)     # noqa: E731
     mats = [m(base_color=(0.75, 0.7, 0.65), specular=0.4, roughness=0.4), m(base_color=(0.1, 0.1, 0.1), specular=0.0)]
@@ -502,11 +503,11 @@ def test_doomed_path_pruning_around_the_light_count_limit(pa, nlight):
            ("back", [[-1, -1, -1], [1, -1, -1], [1, 1, -1], [-1, 1, -1]], [[0, 1, 2], [0, 2, 3]], 0),
            ("left", [[-1, -1, 1], [-1, -1, -1], [-1, 1, -1], [-1, 1, 1]], [[0, 1, 2], [0, 2, 3]], 0),
            ("top", [[-1, 1, -1], [1, 1, -1], [1, 1, 1], [-1, 1, 1]], [[0, 1, 2], [0, 2, 3]], 0)]
-    # a fan of nlight triangles under the ceiling
     xs = np.linspace(-0.5, 0.5, nlight + 1)
     lv = [[0.0, 0.95, -0.4]] + [[float(x), 0.95, 0.3] for x in xs]
-    lf = [[0, k + 2, k + 1] for k in range(nlight)]
-    desc = _mini_scene(box + [("light", lv, lf, 1)], mats)
+    per = nlight // nshapes
+    lights = [("light%d" % k, lv, [[0, j + 2, j + 1] for j in range(k * per, (k + 1) * per)], 1) for k in range(nshapes)]
+    desc = _mini_scene(box + lights, mats)
     so = O.oracle_scene_from_desc(desc)
     sg = pa.scene_from_desc(desc)
     W, H, SPP = 56, 40, 6
@@ -514,10 +515,10 @@ def test_doomed_path_pruning_around_the_light_count_limit(pa, nlight):
     for tail in (0, 0xFFFFFFFF, 300):
         layer = pa.RenderLayer()
         ok, st = pa.Render(sg, W, H, SPP, layer=layer, flags=pa.api.RENDER_STATS, tail_paths=tail)
-        assert layer.rgba.tobytes() == rgba.tobytes(), (nlight, tail)
+        assert layer.rgba.tobytes() == rgba.tobytes(), (nlight, nshapes, tail)
         assert st["closest_rays"] + st["tail_closest_rays"] + st["pruned_rays"] == ost["closest_rays"]
         assert st["shadow_rays"] + st["tail_shadow_rays"] == ost["shadow_rays"]
-        assert (st["pruned_rays"] > 0) == (nlight <= 8), (nlight, st["pruned_rays"])
+        assert (st["pruned_rays"] > 0) == (nlight <= 8 or nshapes <= 8), (nlight, nshapes, st["pruned_rays"])
     assert rgba[..., :3].max() > 0
 
 
