@@ -8,8 +8,8 @@
  *   pbrlab::io::LoadImageFromFile / WritePNG   src/io/image-io.cc:98-224
  *   the output stage of pbrlab-cli             pc/pbrlab-cli.cc:47-57 (rgba/count -> sRGB -> 8-bit PNG)
  * Image files read: PNG, JPEG (baseline and progressive), BMP, TGA, GIF, PSD, PNM, Radiance .hdr, scanline OpenEXR
- * (NONE/RLE/ZIPS/ZIP) -- pixel for pixel what the reference's stb_image / tinyexr return.  Not decoded by this build:
- * Softimage PIC and tiled or PIZ/PXR24/B44 OpenEXR textures (the call fails and says so). */
+ * (NONE/RLE/ZIPS/ZIP/PIZ) -- pixel for pixel what the reference's stb_image / tinyexr return.  Not decoded by this build:
+ * Softimage PIC and tiled or PXR24/B44/DWA OpenEXR textures (the call fails and says so). */
 #ifndef PBRHIP_IO_H_
 #define PBRHIP_IO_H_
 

@@ -1380,6 +1380,195 @@ void exr_unfilter(std::vector<uint8_t>* buf) {
 
 // Single-part scanline OpenEXR -> RGBA float (LoadEXR, tinyexr.h:6004-6260): one channel is replicated into all
 // four; otherwise R, G, B are required and A defaults to 1.  Compression NONE / RLE / ZIPS / ZIP; HALF and FLOAT channels.
+namespace {
+// ---- PIZ (OpenEXR): the 16-bit words of a block of 32 scan lines are (1) mapped to a dense value range through a table
+// derived from a bitmap of the values that occur, (2) transformed channel by channel with a 2-D integer wavelet, (3) coded with
+// a canonical Huffman code that has a run-length symbol.  Decoding undoes 3, 2, 1.  Format: OpenEXR's ImfPizCompressor /
+// ImfHuf / ImfWav as tinyexr reads them (tinyexr.h:1694-3288).
+struct MsbBits {  // bits most-significant first
+  const uint8_t* p;
+  size_t n, i = 0;
+  uint64_t acc = 0;
+  int have = 0;
+  uint32_t get(int nb) {
+    while (have < nb) acc = (acc << 8) | (i < n ? p[i] : 0u), ++i, have += 8;
+    have -= nb;
+    return uint32_t((acc >> have) & ((uint64_t(1) << nb) - 1u));
+  }
+};
+
+bool piz_huffman(const uint8_t* in, size_t len, uint16_t* out, size_t count) {
+  if (len < 20) return false;
+  auto le32 = [&](size_t at) { return uint32_t(in[at]) | (uint32_t(in[at + 1]) << 8) | (uint32_t(in[at + 2]) << 16) | (uint32_t(in[at + 3]) << 24); };
+  const uint32_t im = le32(0), iM = le32(4), nbits = le32(12);
+  const uint32_t kSymbols = (1u << 16) + 1u;  // 65536 values + the run-length symbol (= iM)
+  if (im >= kSymbols || iM >= kSymbols) return false;
+  // code lengths, 6 bits each; 59..62 = 2..5 zero lengths, 63 = 6 + (next 8 bits) zero lengths
+  std::vector<uint8_t> length(kSymbols, 0);
+  MsbBits tb{in + 20, len - 20};
+  for (uint32_t sym = im; sym <= iM; ++sym) {
+    if (tb.i > tb.n + 8) return false;
+    const uint32_t l = tb.get(6);
+    length[sym] = uint8_t(l);
+    if (l >= 59) {
+      uint32_t zeros = l == 63 ? tb.get(8) + 6u : l - 59u + 2u;
+      if (sym + zeros > iM + 1u) return false;
+      while (zeros--) length[sym++] = 0;
+      --sym;
+    }
+  }
+  const size_t data_at = 20 + std::min(tb.i, tb.n);
+  if (uint64_t(nbits) > 8ull * (len - data_at)) return false;
+  // canonical code: the longest codes get the smallest values; within one length, values rise with the symbol
+  uint64_t base[60], cnt[60] = {0};
+  for (uint32_t sym = 0; sym < kSymbols; ++sym) cnt[length[sym]]++;
+  uint64_t c = 0;
+  for (int l = 58; l > 0; --l) {
+    base[l] = c;
+    c = (c + cnt[l]) >> 1;
+  }
+  std::vector<uint32_t> first(60, 0), order;  // symbols sorted by (length, symbol)
+  order.reserve(size_t(iM - im) + 1);
+  for (int l = 1; l <= 58; ++l) {
+    first[size_t(l)] = uint32_t(order.size());
+    if (cnt[l])
+      for (uint32_t sym = im; sym <= iM; ++sym)
+        if (length[sym] == l) order.push_back(sym);
+  }
+  MsbBits br{in + data_at, len - data_at};
+  uint64_t left = nbits;
+  size_t produced = 0;
+  while (left > 0) {
+    uint64_t v = 0;
+    int l = 0;
+    uint32_t sym = kSymbols;
+    while (left > 0 && l < 58) {
+      v = (v << 1) | br.get(1), ++l, --left;
+      if (cnt[l] && v >= base[l] && v - base[l] < cnt[l]) {
+        sym = order[first[size_t(l)] + size_t(v - base[l])];
+        break;
+      }
+    }
+    if (sym == kSymbols) return false;  // bits that are no code
+    if (sym == iM) {  // run: repeat the previous word
+      if (left < 8 || produced == 0) return false;
+      const uint32_t run = br.get(8);
+      left -= 8;
+      if (produced + run > count) return false;
+      for (uint32_t k = 0; k < run; ++k) out[produced + k] = out[produced - 1];
+      produced += run;
+    } else {
+      if (produced >= count) return false;
+      out[produced++] = uint16_t(sym);
+    }
+  }
+  return produced == count;
+}
+
+// inverse of one wavelet butterfly; the 14-bit form is used when every value is below 2^14 (no wrap-around possible)
+inline void wav_dec14(uint16_t l, uint16_t h, uint16_t& a, uint16_t& b) {
+  const int ls = int16_t(l), hs = int16_t(h);
+  const int ai = ls + (hs & 1) + (hs >> 1);
+  a = uint16_t(int16_t(ai)), b = uint16_t(int16_t(ai - hs));
+}
+inline void wav_dec16(uint16_t l, uint16_t h, uint16_t& a, uint16_t& b) {
+  const int m = l, d = h;
+  const int bb = (m - (d >> 1)) & 0xffff;
+  a = uint16_t((d + bb - 0x8000) & 0xffff), b = uint16_t(bb);
+}
+void piz_wavelet(uint16_t* in, int nx, int ox, int ny, int oy, uint16_t max_value) {
+  const bool w14 = max_value < (1 << 14);
+  const int n = nx > ny ? ny : nx;
+  int p = 1;
+  while (p <= n) p <<= 1;
+  p >>= 1;
+  int p2 = p;
+  p >>= 1;
+  auto dec = [&](uint16_t l, uint16_t h, uint16_t& a, uint16_t& b) { w14 ? wav_dec14(l, h, a, b) : wav_dec16(l, h, a, b); };
+  while (p >= 1) {  // from the coarsest level down: rebuild 2x2 groups that are p apart
+    const int oy1 = oy * p, oy2 = oy * p2, ox1 = ox * p, ox2 = ox * p2;
+    uint16_t* py = in;
+    uint16_t* const ey = in + oy * (ny - p2);
+    for (; py <= ey; py += oy2) {
+      uint16_t* px = py;
+      uint16_t* const ex = py + ox * (nx - p2);
+      for (; px <= ex; px += ox2) {
+        uint16_t *p01 = px + ox1, *p10 = px + oy1, *p11 = p10 + ox1;
+        uint16_t i00, i01, i10, i11;
+        dec(*px, *p10, i00, i10);
+        dec(*p01, *p11, i01, i11);
+        dec(i00, i01, *px, *p01);
+        dec(i10, i11, *p10, *p11);
+      }
+      if (nx & p) {  // odd column left over at this level
+        uint16_t* p10 = px + oy1;
+        uint16_t i00;
+        dec(*px, *p10, i00, *p10);
+        *px = i00;
+      }
+    }
+    if (ny & p) {  // odd row
+      uint16_t* px = py;
+      uint16_t* const ex = py + ox * (nx - p2);
+      for (; px <= ex; px += ox2) {
+        uint16_t* p01 = px + ox1;
+        uint16_t i00;
+        dec(*px, *p01, i00, *p01);
+        *px = i00;
+      }
+    }
+    p2 = p;
+    p >>= 1;
+  }
+}
+
+// one PIZ chunk -> the uncompressed chunk layout (line after line, inside a line channel after channel)
+bool piz_uncompress(const uint8_t* in, size_t in_len, std::vector<uint8_t>* out, size_t w, size_t lines, const std::vector<ExrChannel>& ch) {
+  if (in_len < 4) return false;
+  const uint32_t min_nz = in[0] | (uint32_t(in[1]) << 8), max_nz = in[2] | (uint32_t(in[3]) << 8);
+  if (max_nz >= 8192 || min_nz > max_nz) return false;  // (tinyexr refuses the empty bitmap of an all-zero block too)
+  size_t at = 4;
+  if (at + (max_nz - min_nz + 1) + 4 > in_len) return false;
+  std::vector<uint8_t> bitmap(8192, 0);
+  memcpy(bitmap.data() + min_nz, in + at, max_nz - min_nz + 1);
+  at += max_nz - min_nz + 1;
+  std::vector<uint16_t> lut(1 << 16, 0);  // dense index -> value
+  uint32_t k = 0;
+  for (uint32_t v = 0; v < (1u << 16); ++v)
+    if (v == 0 || (bitmap[v >> 3] & (1u << (v & 7)))) lut[k++] = uint16_t(v);
+  const uint16_t max_value = uint16_t(k - 1);
+  const int32_t hlen = int32_t(uint32_t(in[at]) | (uint32_t(in[at + 1]) << 8) | (uint32_t(in[at + 2]) << 16) | (uint32_t(in[at + 3]) << 24));
+  at += 4;
+  if (hlen < 0 || at + size_t(hlen) > in_len) return false;
+  size_t words = 0;
+  for (const ExrChannel& c : ch) words += w * lines * (c.type == 1 ? 1 : 2);
+  std::vector<uint16_t> tmp(words, 0);
+  (void)piz_huffman(in + at, size_t(hlen), tmp.data(), words);  // tinyexr goes on with whatever was decoded
+  size_t start = 0;
+  for (const ExrChannel& c : ch) {
+    const int size = c.type == 1 ? 1 : 2;
+    for (int j = 0; j < size; ++j) piz_wavelet(tmp.data() + start + size_t(j), int(w), size, int(lines), int(w) * size, max_value);
+    start += w * lines * size_t(size);
+  }
+  for (uint16_t& v : tmp) v = lut[v];
+  out->resize(words * 2);
+  std::vector<size_t> next(ch.size());
+  start = 0;
+  for (size_t c = 0; c < ch.size(); ++c) next[c] = start, start += w * lines * (ch[c].type == 1 ? 1 : 2);
+  size_t o = 0;
+  for (size_t y = 0; y < lines; ++y)
+    for (size_t c = 0; c < ch.size(); ++c) {
+      const size_t nw = w * (ch[c].type == 1 ? 1 : 2);
+      for (size_t q = 0; q < nw; ++q) {
+        const uint16_t v = tmp[next[c] + q];
+        (*out)[o++] = uint8_t(v & 255), (*out)[o++] = uint8_t(v >> 8);
+      }
+      next[c] += nw;
+    }
+  return true;
+}
+}  // namespace
+
 bool DecodeExr(const uint8_t* file, size_t n, std::vector<float>* pixels, size_t* width, size_t* height, std::string* err) {
   auto rd32 = [&](size_t at) { return uint32_t(file[at]) | (uint32_t(file[at + 1]) << 8) | (uint32_t(file[at + 2]) << 16) | (uint32_t(file[at + 3]) << 24); };
   if (n < 8 || rd32(0) != 0x01312f76u) return *err = "not an OpenEXR file", false;
@@ -1440,7 +1629,7 @@ bool DecodeExr(const uint8_t* file, size_t n, std::vector<float>* pixels, size_t
   }
   if (ch.empty() || compression < 0 || !have_dw || !have_disp || line_order < 0 || !have_par || !have_swc || !have_sww)
     return *err = "OpenEXR header lacks a required attribute", false;
-  if (compression > 3) return *err = "OpenEXR compression PIZ / PXR24 / B44 is not decoded by this build (use ZIP)", false;
+  if (compression > 4) return *err = "OpenEXR compression PXR24 / B44 / DWA is not decoded by this build (use ZIP or PIZ)", false;
   if (dw[2] < dw[0] || dw[3] < dw[1]) return *err = "bad OpenEXR data window", false;
   const size_t w = size_t(dw[2] - dw[0]) + 1, h = size_t(dw[3] - dw[1]) + 1;
   if (w > (1u << 24) || h > (1u << 24) || uint64_t(w) * h > (1ull << 28)) return *err = "bad OpenEXR data window", false;
@@ -1450,7 +1639,7 @@ bool DecodeExr(const uint8_t* file, size_t n, std::vector<float>* pixels, size_t
     c.offset = pixel_bytes;
     pixel_bytes += c.type == 1 ? 2 : 4;
   }
-  const size_t block_lines = compression == 3 ? 16 : 1;
+  const size_t block_lines = compression == 4 ? 32 : (compression == 3 ? 16 : 1);
   const size_t nblocks = (h + block_lines - 1) / block_lines;
   if (pos + nblocks * 8 > n) return *err = "truncated OpenEXR offset table", false;
   std::vector<std::vector<float>> img(ch.size(), std::vector<float>(w * h, 0.0f));
@@ -1473,6 +1662,8 @@ bool DecodeExr(const uint8_t* file, size_t n, std::vector<float>* pixels, size_t
     } else if (compression == 1) {
       if (!rle_uncompress(src, len, &block, raw) || block.size() != raw) return *err = "bad RLE data in OpenEXR chunk", false;
       exr_unfilter(&block);
+    } else if (compression == 4) {
+      if (!piz_uncompress(src, len, &block, w, lines, ch) || block.size() != raw) return *err = "bad PIZ data in OpenEXR chunk", false;
     } else {
       std::string zerr;
       if (!ZlibInflate(src, len, &block, &zerr) || block.size() != raw) return *err = "bad zlib data in OpenEXR chunk", false;

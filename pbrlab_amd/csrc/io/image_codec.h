@@ -6,8 +6,8 @@
 // baseline + progressive JPEG reader, Radiance .hdr reader, scanline OpenEXR reader.  Decoded pixels equal stb_image's / tinyexr's for
 // the same file (16-bit PNG samples keep their high byte, sub-byte grey is scaled to 0..255, a tRNS colour key becomes
 // an alpha channel; JPEG through stb's integer IDCT, upsampling filters and fixed-point colour conversion).
-// BMP, TGA, PNM, GIF and PSD are in image_formats.cpp.  Softimage PIC and tiled / PIZ-compressed OpenEXR are NOT decoded by
-// this build: loading such a file fails with a message naming the format.
+// BMP, TGA, PNM, GIF and PSD are in image_formats.cpp.  Softimage PIC and tiled or PXR24 / B44 / DWA-compressed OpenEXR are
+// NOT decoded by this build: loading such a file fails with a message naming the format.
 #ifndef PBRLAB_AMD_IO_IMAGE_CODEC_H_
 #define PBRLAB_AMD_IO_IMAGE_CODEC_H_
 
@@ -52,8 +52,8 @@ bool DecodeTga(const uint8_t* file, size_t n, std::vector<uint8_t>* pixels, size
 // a Radiance picture opened as an 8-bit image (its name does not end in .hdr): gamma 2.2, clamp, truncate
 void HdrToLdr(const std::vector<float>& rgb, std::vector<uint8_t>* out);
 
-// single-part scanline OpenEXR (NONE / RLE / ZIPS / ZIP; HALF and FLOAT channels) -> RGBA float as tinyexr's LoadEXR
-// returns it (one channel replicated; A = 1 when absent).  Tiled, multipart, PIZ/PXR24/B44 files are refused.
+// single-part scanline OpenEXR (NONE / RLE / ZIPS / ZIP / PIZ; HALF and FLOAT channels) -> RGBA float as tinyexr's LoadEXR
+// returns it (one channel replicated; A = 1 when absent).  Tiled, multipart, PXR24/B44/DWA files are refused.
 bool DecodeExr(const uint8_t* file, size_t n, std::vector<float>* pixels, size_t* width, size_t* height, std::string* err);
 
 // io::LoadImageFromFile<float> (image-io.cc:98-152): 8-bit formats are returned as value / 255

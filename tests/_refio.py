@@ -120,6 +120,19 @@ def save_exr(path, planes, names, half=False, compression=3, line_order=0):
     return bool(lib().refio_save_exr(os.fsencode(path), planes.ctypes.data, blob, nchan, w, h, int(half), compression, line_order))
 
 
+def save_exr_isolated(path, planes, names, half=False, compression=3, line_order=0):
+    """save_exr in a child process: tinyexr's PIZ compressor crashes on some inputs (seen: one FLOAT channel of smooth data,
+    38 x 34), which must not take the test run down.  Returns False when the child failed."""
+    import pickle
+    import subprocess
+    import sys
+    blob = pickle.dumps((path, np.ascontiguousarray(planes, np.float32), list(names), half, compression, line_order))
+    code = ("import pickle, sys; sys.path.insert(0, %r); import _refio; a = pickle.loads(sys.stdin.buffer.read()); "
+            "sys.exit(0 if _refio.save_exr(*a) else 1)") % os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-c", code], input=blob, capture_output=True)
+    return r.returncode == 0 and os.path.exists(path)
+
+
 def write_jpg(path, pixels, quality=90):
     """stb_image_write's JPEG writer (test-file generator).  pixels: (h, w, c) uint8"""
     px = np.ascontiguousarray(pixels, np.uint8)

@@ -29,7 +29,8 @@ JPEG_CASES = [(33, 17, [(1, 1)], {}), (45, 30, [(2, 1), (1, 1), (1, 1)], dict(re
               (20, 20, [(1, 1)] * 4, dict(adobe=0, jfif=False)), (26, 22, [(2, 2), (1, 1), (1, 1), (2, 2)], dict(adobe=2, jfif=False)),
               (19, 23, [(1, 1)] * 3, dict(ids=[82, 71, 66]))]
 EXR_CASES = [(["A", "B", "G", "R"], False, 3, 0), (["B", "G", "R"], True, 3, 0), (["Y"], True, 2, 0), (["A", "B", "G", "R"], True, 1, 0),
-             (["B", "G", "R"], False, 0, 0), (["A", "B", "G", "R"], True, 3, 1)]
+             (["B", "G", "R"], False, 0, 0), (["A", "B", "G", "R"], True, 3, 1),
+             (["B", "G", "R"], True, 4, 0), (["A", "B", "G", "R"], False, 4, 0), (["Y"], True, 4, 1)]           # PIZ
 
 
 def write_other_format_fixtures(out):
@@ -119,6 +120,8 @@ def main():
     # OpenEXR (written by tinyexr itself): compression NONE/RLE/ZIPS/ZIP, HALF/FLOAT, RGBA / RGB / one channel, both line orders
     for i, (names, half, comp, lo) in enumerate(EXR_CASES):
         w, h = int(rng.integers(5, 40)), int(rng.integers(17, 40))
+        if comp == 4:
+            h += 30                                # more than one 32-line block
         planes = (rng.random((len(names), h, w)) * 10.0 ** rng.integers(-2, 3)).astype(np.float32)
         planes[:, : h // 2] = 0.5
         if half:

@@ -339,9 +339,9 @@ def test_progressive_jpeg_vs_reference(tmp_path, capfd):
     assert same >= 0.95 * total, (same, total)
 
 
-@pytest.mark.parametrize("i", range(6))
+@pytest.mark.parametrize("i", range(9))
 def test_exr_decode_golden(i, capfd):
-    """scanline OpenEXR written by tinyexr (NONE/RLE/ZIPS/ZIP, HALF/FLOAT, 1/3/4 channels, both line orders) == tinyexr's LoadEXR"""
+    """scanline OpenEXR written by tinyexr (NONE/RLE/ZIPS/ZIP/PIZ, HALF/FLOAT, 1/3/4 channels, both line orders) == tinyexr's LoadEXR"""
     got = io_api.LoadImageFromFile("env%d.exr" % i, GOLD_DIR)
     want = GOLD["exr%d" % i]
     assert got.shape == want.shape and got.shape[2] == 4 and np.array_equal(bits(got), bits(want))
@@ -371,6 +371,39 @@ def test_exr_decode_fuzz_vs_reference(tmp_path, capfd):
         assert got.shape == want.shape and np.array_equal(bits(got), bits(want)), (case, comp, half, names)
         nimg += 1
     assert nimg >= 48
+
+
+@needs_ref
+def test_exr_piz_vs_reference(tmp_path, capfd):
+    """PIZ-compressed scanline OpenEXR (bitmap + range table, wavelet, Huffman with run lengths) written by tinyexr == tinyexr's
+    LoadEXR: noise, flat areas, smooth gradients, few distinct values; HALF and FLOAT; 1/3/4 channels; blocks of 32 lines"""
+    d = str(tmp_path)
+    rng = np.random.default_rng(23)
+    nimg = 0
+    for case in range(36):
+        names = [["A", "B", "G", "R"], ["B", "G", "R"], ["Y"]][case % 3]
+        half = bool(case % 2)
+        w, h = [(1, 1), (2, 1), (1, 5), (33, 1)][case] if case < 4 else (int(rng.integers(1, 90)), int(rng.integers(1, 110)))
+        kind = case % 4
+        if kind == 0:
+            planes = (rng.random((len(names), h, w)) * 10.0 ** rng.integers(-2, 3)).astype(np.float32)
+        elif kind == 1:
+            planes = np.full((len(names), h, w), 0.5, np.float32)
+            planes[:, : h // 2] = 0.25
+        elif kind == 2:
+            yy, xx = np.mgrid[0:h, 0:w]
+            planes = np.stack([np.sin(xx / 7.0 + k) * np.cos(yy / 5.0) + 1.5 for k in range(len(names))]).astype(np.float32)
+        else:
+            planes = rng.integers(0, 4, size=(len(names), h, w)).astype(np.float32) * 0.125
+        name = "z%d.exr" % case
+        if not _refio.save_exr_isolated(os.path.join(d, name), planes, names, half, 4, (case // 18) % 2):
+            continue                              # tinyexr's own PIZ writer crashed on this input
+        want = _refio.image_load(name, d)
+        assert want is not None, case
+        got = io_api.LoadImageFromFile(name, d)
+        assert got.shape == want.shape and np.array_equal(bits(got), bits(want)), (case, names, half, w, h, kind)
+        nimg += 1
+    assert nimg >= 30
 
 
 @needs_ref
