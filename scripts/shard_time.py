@@ -21,3 +21,11 @@ for world in (1, 2, 4, 8):
     if world == 1: base = ts[0]
 _, st = api.Render(s, W, H, SPP, tile_rank=0, tile_world=8, device_out=(rgba.data_ptr(), cnt.data_ptr()), flags=api.RENDER_TIMING)
 print({k: round(v, 2) for k, v in st.items() if k.startswith("ms_")})
+# weak-scaling proxy (what bench.py --gpus N runs per rank): rank 0's tiles of an N-rank job at 64*N spp
+for world in (2, 4, 8):
+    best = 1e9
+    for rep in range(3):
+        t = time.perf_counter()
+        _, st = api.Render(s, W, H, SPP * world, tile_rank=0, tile_world=world, device_out=(rgba.data_ptr(), cnt.data_ptr()))
+        best = min(best, (time.perf_counter() - t) * 1e3)
+    print(f"weak proxy world {world}: rank 0 renders its tiles at {SPP * world} spp in {best:.1f} ms (1-GPU frame {base:.1f} ms)")
