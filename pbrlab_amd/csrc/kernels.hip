@@ -354,6 +354,9 @@ __device__ __forceinline__ void put_shadow(const PathState& P, V3 pos, const Nee
 // ------------------------------------------------------------------ k_shade_principled
 // CyclesPrincipledShader (cycles-principled-shader.cc:414-484) + the tail of GetRadiance (render.cc:76-87).
 // One path; returns the result bits (kRShadow | kRAlive | kQSssBit | kQDoomed) its caller stores or acts on.
+// PLAIN: the scene has no material that can enter a medium and no textured material (neither branch can be taken), so that
+// code -- and the registers it holds -- is compiled out of the wavefront kernel.
+template <bool PLAIN = false>
 __device__ __forceinline__ uint32_t shade_principled_path(const PathState& P, const DScene& sc, uint32_t p, uint64_t rng_inc) {
   {
     const bool active = true;
@@ -377,7 +380,7 @@ __device__ __forceinline__ uint32_t shade_principled_path(const PathState& P, co
         branchless_onb(fr.ez, fr.ex, fr.ey);
         V3 wo = to_local(fr, wo_g);
         PrincipledBsdf b = sc.materials[s.material].bsdf;
-        if (sc.materials[s.material].textured) {  // ParamToBsdf per hit (cycles-principled-shader.cc:281-301)
+        if (!PLAIN && sc.materials[s.material].textured) {  // ParamToBsdf per hit (cycles-principled-shader.cc:281-301)
           const PrincipledParam mp = sc.materials[s.material].param;
           V3 bc(mp.base_color[0], mp.base_color[1], mp.base_color[2]);
           V3 ssc(mp.subsurface_color[0], mp.subsurface_color[1], mp.subsurface_color[2]);
@@ -414,6 +417,8 @@ __device__ __forceinline__ uint32_t shade_principled_path(const PathState& P, co
           float u0 = draw(rng);
           float u1 = draw(rng);
           ggx_sample(wo, b.clearcoat_alpha_x, b.clearcoat_alpha_y, u0, u1, wi);
+        } else if (PLAIN) {
+          sampled = false;  // unreachable: no material has a subsurface weight
         } else {
           // RandomWalkSubsurface entry (random-walk-sss.h:236-287)
           sampled = false;
@@ -497,11 +502,12 @@ __device__ __forceinline__ uint32_t shade_principled_path(const PathState& P, co
 #ifndef PB_SHADE_WAVES
 #define PB_SHADE_WAVES 3  // min waves per SIMD: <= 168 VGPRs (A/B on C2: 1 -> 20.5 ms, 2 -> 20.3, 3 -> 19.3, 4 spills -> 25.5)
 #endif
+template <bool PLAIN>
 __global__ __launch_bounds__(kBlock, PB_SHADE_WAVES) void k_shade_principled(PathState P, DScene sc, uint64_t rng_inc) {
   const uint32_t n = P.counts[kCntPrincipled];
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
     const uint32_t p = P.q_principled[i];
-    P.q_principled[i] = p | shade_principled_path(P, sc, p, rng_inc);
+    P.q_principled[i] = p | shade_principled_path<PLAIN>(P, sc, p, rng_inc);
   }
 }
 
@@ -924,8 +930,9 @@ void launch_classify(hipStream_t s, const PathState& P, const DScene& sc, uint32
 void launch_compact(hipStream_t s, const PathState& P, uint32_t n_upper) {
   hipLaunchKernelGGL(k_compact, dim3(tiles_grid(n_upper)), dim3(kBlock), 0, s, P);
 }
-void launch_shade_principled(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc) {
-  hipLaunchKernelGGL(k_shade_principled, dim3(grid_for(n_upper, kShadeGridCap)), dim3(kBlock), 0, s, P, sc, rng_inc);
+void launch_shade_principled(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc, bool plain) {
+  if (plain) hipLaunchKernelGGL(k_shade_principled<true>, dim3(grid_for(n_upper, kShadeGridCap)), dim3(kBlock), 0, s, P, sc, rng_inc);
+  else hipLaunchKernelGGL(k_shade_principled<false>, dim3(grid_for(n_upper, kShadeGridCap)), dim3(kBlock), 0, s, P, sc, rng_inc);
 }
 void launch_shade_hair(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc) {
   hipLaunchKernelGGL(k_shade_hair, dim3(grid_for(n_upper, kShadeGridCap)), dim3(kBlock), 0, s, P, sc, rng_inc);

@@ -986,7 +986,7 @@ static int render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volat
           launch_classify(gr.st, gr.P, sc, n);
           HIPCHK(gr.tm.end());
           HIPCHK(gr.tm.begin(&S.ms_shade_principled));
-          launch_shade_principled(gr.st, gr.P, sc, n, rng_inc);
+          launch_shade_principled(gr.st, gr.P, sc, n, rng_inc, !s->has_sss);
           HIPCHK(gr.tm.end());
           if (s->has_hair) {
             HIPCHK(gr.tm.begin(&S.ms_shade_hair));
