@@ -246,6 +246,8 @@ def test_full_size_properties(pa, config):
     c = pa.RenderLayer()
     pa.Render(sg, W, H, SPP, layer=c, tail_paths=0xFFFFFFFF)          # every bounce through the wavefront kernels
     assert c.rgba.tobytes() == a.rgba.tobytes()
+    pa.Render(sg, W, H, SPP, layer=c, num_streams=2)                  # two concurrent path groups (the default for big chunks)
+    assert c.rgba.tobytes() == a.rgba.tobytes()
     # spot parity with the oracle at full size: 3 tiles' worth of pixels through per-sample traces
     so = O.oracle_scene_from_desc(desc)
     rng = np.random.RandomState(0)
