@@ -260,6 +260,28 @@ def test_full_size_properties(pa, config):
         assert np.array_equal(tot.view(np.uint32), a.rgba[y, x, :3].view(np.uint32)), (x, y)
 
 
+def test_headline_configuration_spot_parity(pa):
+    """The frame bench.py times -- C2 at 1920 x 1080 x 64 spp with the library's defaults (one chunk, two path groups, tail kernel,
+    doomed-path pruning) -- against the oracle: 48 random pixels, every one of their 64 samples traced by the oracle and summed
+    in pass order, bit for bit; plus the frame-level invariants the bench asserts."""
+    from pbrlab_amd import scenes
+    desc = scenes.cornell_scene("ggx", seed=1)
+    sg = pa.scene_from_desc(desc)
+    W, H, SPP = 1920, 1080, 64
+    a = pa.RenderLayer()
+    ok, st = pa.Render(sg, W, H, SPP, layer=a)
+    assert ok is True and (a.count == SPP).all() and np.isfinite(a.rgba).all() and np.array_equal(a.rgba[..., 3], np.full((H, W), SPP, np.float32))
+    so = O.oracle_scene_from_desc(desc)
+    rng = np.random.RandomState(7)
+    for _ in range(48):
+        x, y = int(rng.randint(W)), int(rng.randint(H))
+        tot = np.zeros(3, np.float32)
+        for p in range(SPP):
+            rad, _, _, _ = so.sample_trace(W, H, x, y, p, math_mode=O.MATH_F64R)
+            tot = tot + rad
+        assert np.array_equal(tot.view(np.uint32), a.rgba[y, x, :3].view(np.uint32)), (x, y)
+
+
 @pytest.mark.parametrize("name", ["lambert", "sss", "hair", "textured"])
 def test_gpu_built_bvh_gives_identical_results(pa, pairs, name):
     """Row N3: the acceleration structure built on the GPU (Morton-order linear BVH).  Hits, and therefore images, do not
