@@ -260,6 +260,25 @@ def test_full_size_properties(pa, config):
         assert np.array_equal(tot.view(np.uint32), a.rgba[y, x, :3].view(np.uint32)), (x, y)
 
 
+@pytest.mark.parametrize("config", ["c2", "c3", "c4"])
+def test_whole_frames_on_the_benchmark_scenes(pa, config):
+    """The full-geometry benchmark scenes (545 k triangles; Lucy with random-walk SSS; 4.8 M hair pieces) rendered whole at a
+    quarter of the resolution, 4 spp: every pixel of the GPU frame equals the oracle's, bit for bit (relative L2 = 0)."""
+    from pbrlab_amd import scenes
+    desc = {"c2": lambda: scenes.cornell_scene("ggx", seed=1), "c3": lambda: scenes.cornell_scene("sss", seed=1),
+            "c4": lambda: scenes.hair_scene(seed=1)}[config]()
+    sg = pa.scene_from_desc(desc)
+    so = O.oracle_scene_from_desc(desc)
+    W, H, SPP = 480, 270, 4
+    a = pa.RenderLayer()
+    pa.Render(sg, W, H, SPP, layer=a)
+    rgba, cnt, _ = so.render(W, H, SPP, threads=os.cpu_count() or 8, math_mode=O.MATH_F64R)
+    assert np.array_equal(a.count, cnt)
+    ndiff, rel = image_check(a.rgba, rgba)
+    assert ndiff == 0 and rel == 0.0, (ndiff, rel)
+    assert a.rgba[..., :3].max() > 0
+
+
 def test_headline_configuration_spot_parity(pa):
     """The frame bench.py times -- C2 at 1920 x 1080 x 64 spp with the library's defaults (one chunk, two path groups, tail kernel,
     doomed-path pruning) -- against the oracle: 48 random pixels, every one of their 64 samples traced by the oracle and summed
