@@ -16,14 +16,15 @@ namespace pb {
 //     sss_sigt (sigma_t.rgb, step index) | sss_sigs (sigma_s.rgb, entry instance id) | sss_thr (walk throughput)
 //     sss_pdf (channel pdf of the pending step) | sss_ez (entry frame normal) | sss_A (resolved first NEE)
 //   queues (u32 path slots): q_in/q_out (ping-pong), q_principled, q_hair, q_sss, q_shadow; the shadow-ray payload
-//     sits at the path's own slot: sh_o (org, tmin) | sh_d (dir, tmax) | sh_c (contribution if visible) | sh_e (if occluded, mode)
+//     sits at the path's own slot: sh_d (dir, tmax) | sh_c (contribution if visible, mode) | sh_e (contribution if occluded:
+//     medium exits only); origin and tmin are ray_o's (the shadow ray starts where the continuation ray starts)
 struct PathState {
   float4 *ray_o, *ray_d, *thr, *L, *hit;
   uint64_t* rng;
   uint32_t* flags;
   float4 *sss_sigt, *sss_sigs, *sss_thr, *sss_pdf, *sss_ez, *sss_A;
   uint32_t *q_in, *q_out, *q_principled, *q_hair, *q_sss, *q_shadow, *q_shadow_in;
-  float4 *sh_o, *sh_d, *sh_c, *sh_e;
+  float4 *sh_d, *sh_c, *sh_e;
   uint32_t* spill;               // traversal-stack spill area: (kStackDepth - LDS part) x resident threads
   uint32_t* counts;              // kCnt*
   unsigned long long* stats;     // kStat*; null unless the render collects statistics

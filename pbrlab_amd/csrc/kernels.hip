@@ -78,7 +78,7 @@ struct TraceSink {
       return false;
     }
     tag = P.q_shadow_in[idx - n_closest];
-    float4 o4 = P.sh_o[tag], d4 = P.sh_d[tag];
+    float4 o4 = P.ray_o[tag], d4 = P.sh_d[tag];
     o = ld3(o4), d = ld3(d4), tmin = o4.w, tmax = d4.w;
     tag |= 0x80000000u;
     return true;
@@ -89,12 +89,13 @@ struct TraceSink {
       P.hit[p] = make_float4(h.t, h.u, h.v, __uint_as_float(h.slot));
       return;
     }
-    float4 c = P.sh_c[p], e = P.sh_e[p];
-    uint32_t mode = __float_as_uint(e.w);
+    const float4 c = P.sh_c[p];
+    const uint32_t mode = __float_as_uint(c.w);
     if (mode == kShSssEntry) {
       if (!occluded) P.sss_A[p] = make_float4(0.0f + c.x, 0.0f + c.y, 0.0f + c.z, 0.0f);
     } else if (!occluded || mode == kShSssExit) {
-      V3 add = occluded ? V3(e.x, e.y, e.z) : V3(c.x, c.y, c.z);
+      V3 add(c.x, c.y, c.z);
+      if (occluded) add = ld3(P.sh_e[p]);
       float4 L = P.L[p];
       P.L[p] = make_float4(L.x + add.x, L.y + add.y, L.z + add.z, L.w);
     }
@@ -342,13 +343,15 @@ __device__ __forceinline__ void count_pruned(const PathState& P) {  // P.stats i
 
 // writes one shadow-queue entry
 __device__ __forceinline__ void put_shadow(const PathState& P, V3 pos, const Nee& n, V3 c_vis, V3 c_occ, uint32_t p,
-                                           uint32_t mode) {
+                                           uint32_t mode, bool alive) {
   // ShadowRay (shader-utils.h:116-129): [kEps, max(kEps, dist - kEps)]  (Q9).  One shadow ray per path per
-  // iteration at most, so the payload lives at the path's own slot.
-  P.sh_o[p] = mk4(pos, kEps);
+  // iteration at most, so the payload lives at the path's own slot.  Its origin and tmin are those of the path's next ray
+  // (the same surface point, the same 1e-3 offset), so they are read from ray_o; a path that ends here still stores them.
+  static_assert(kEps == 1e-3f, "shadow rays share (origin, tmin) with the continuation ray");
+  if (!alive) P.ray_o[p] = mk4(pos, kEps);
   P.sh_d[p] = mk4(n.dir, smax(kEps, n.dist - kEps));
-  P.sh_c[p] = mk4(c_vis, 0.f);
-  P.sh_e[p] = mk4(c_occ, __uint_as_float(mode));
+  P.sh_c[p] = mk4(c_vis, __uint_as_float(mode));
+  if (mode == kShSssExit) P.sh_e[p] = mk4(c_occ, 0.f);  // what to add when the ray is occluded (only a medium exit has one)
 }
 
 // ------------------------------------------------------------------ k_shade_principled
@@ -495,7 +498,7 @@ __device__ __forceinline__ uint32_t shade_principled_path(const PathState& P, co
         }
       }
     }
-    if (shadow) put_shadow(P, sh_pos, nee, c_vis, V3(0.f), p, sh_mode);
+    if (shadow) put_shadow(P, sh_pos, nee, c_vis, V3(0.f), p, sh_mode, alive);
     return (shadow ? kRShadow : 0u) | (alive ? kRAlive : 0u) | qbit;
   }
 }
@@ -575,7 +578,7 @@ __device__ __forceinline__ uint32_t shade_hair_path(const PathState& P, const DS
         }
       }
     }
-    if (shadow) put_shadow(P, sh_pos, nee, c_vis, V3(0.f), p, kShNormal);
+    if (shadow) put_shadow(P, sh_pos, nee, c_vis, V3(0.f), p, kShNormal, alive);
     return (shadow ? kRShadow : 0u) | (alive ? kRAlive : 0u) | qbit;
   }
 }
@@ -723,7 +726,7 @@ __device__ __forceinline__ uint32_t sss_step_path(const PathState& P, const DSce
         P.L[p] = mk4(ld3(L4) + thr * (A + V3(0.f)), L4.w);
       }
     }
-    if (shadow) put_shadow(P, sh_pos, nee, c_vis, c_occ, p, kShSssExit);
+    if (shadow) put_shadow(P, sh_pos, nee, c_vis, c_occ, p, kShSssExit, alive);
     return (shadow ? kRShadow : 0u) | (alive ? kRAlive : 0u) | qbit;
   }
 }
@@ -772,7 +775,7 @@ __global__ __launch_bounds__(kBlock) void k_tail(PathState P, DScene sc, uint64_
         r = (slot & kHitHair) ? shade_hair_path(P, sc, p, rng_inc) : shade_principled_path(P, sc, p, rng_inc);
       }
       if (r & kRShadow) {
-        const float4 o4 = P.sh_o[p], d4 = P.sh_d[p];
+        const float4 o4 = P.ray_o[p], d4 = P.sh_d[p];
         Hit h;
         const bool occluded = traverse<true, false, CURVES>(sc, ld3(o4), ld3(d4), o4.w, d4.w, h, stack, kBlock, st, &overflow);
         sink.done(p | 0x80000000u, h, occluded);
