@@ -28,6 +28,10 @@ struct PathState {
   uint32_t* spill;               // traversal-stack spill area: (kStackDepth - LDS part) x resident threads
   uint32_t* counts;              // kCnt*
   unsigned long long* stats;     // kStat*; null unless the render collects statistics
+  // First bounce of a chunk: every path still has the camera position as its origin (tmin 0), throughput (1,1,1), pdf 0 and
+  // flags 0, so k_generate does not store ray_o / thr / flags and the first trace and shading do not load them.
+  float cam_org[3];
+  uint32_t first;
 };
 
 enum : uint32_t { kFlagNotFirst = 1u };

@@ -48,12 +48,9 @@ __global__ __launch_bounds__(kBlock) void k_generate(PathState P, Camera cam, co
     V3 org(cam.org[0], cam.org[1], cam.org[2]);
     V3 target(cam.x_corner + cam.dx * ((float)x + jx), cam.y_corner - cam.dy * ((float)y + jy), cam.z_corner);
     V3 dir = normalize_raw(target - org);
-    P.ray_o[i] = mk4(org, 0.0f);
-    P.ray_d[i] = mk4(dir, kInf);
-    P.thr[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+    P.ray_d[i] = mk4(dir, kInf);  // origin (org, tmin 0), throughput (1, 1, 1, pdf 0) and flags 0 are implied (PathState::first)
     P.L[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     P.rng[i] = rng.state;
-    P.flags[i] = 0u;
     P.q_in[j] = i;
   }
 }
@@ -73,7 +70,8 @@ struct TraceSink {
   __device__ __forceinline__ bool load(uint32_t idx, uint32_t& tag, V3& o, V3& d, float& tmin, float& tmax) const {
     if (idx < n_closest) {
       tag = P.q_in[idx] & kQPathMask;
-      float4 o4 = P.ray_o[tag], d4 = P.ray_d[tag];
+      float4 o4 = make_float4(P.cam_org[0], P.cam_org[1], P.cam_org[2], 0.0f), d4 = P.ray_d[tag];
+      if (!P.first) o4 = P.ray_o[tag];
       o = ld3(o4), d = ld3(d4), tmin = o4.w, tmax = d4.w;
       return false;
     }
@@ -275,13 +273,15 @@ struct PathHead {
   Rng rng;
   uint32_t flags;
 };
-__device__ __forceinline__ bool path_head(const PathState& P, const DScene& sc, uint32_t p, uint64_t rng_inc, PathHead& c) {
-  float4 h4 = P.hit[p], o4 = P.ray_o[p], d4 = P.ray_d[p], t4 = P.thr[p];
+__device__ __forceinline__ bool path_head(const PathState& P, const DScene& sc, uint32_t p, uint64_t rng_inc, PathHead& c, bool first) {
+  float4 h4 = P.hit[p], d4 = P.ray_d[p];
+  float4 o4 = make_float4(P.cam_org[0], P.cam_org[1], P.cam_org[2], 0.0f), t4 = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+  c.flags = 0u;
+  if (!first) o4 = P.ray_o[p], t4 = P.thr[p], c.flags = P.flags[p];  // the camera ray's values are implied (PathState::first)
   c.h.t = h4.x, c.h.u = h4.y, c.h.v = h4.z, c.h.slot = __float_as_uint(h4.w);
   c.dir = ld3(d4);
   c.s = make_surface(sc, ld3(o4), c.dir, c.h);
   c.thr = ld3(t4);
-  c.flags = P.flags[p];
   if (c.s.face == kFront && c.s.lightrec != kNone) {  // render.cc:43-62, LightManager::ImplicitAreaLight
     const float4* lr = reinterpret_cast<const float4*>(sc.lrecs + c.s.lightrec);
     float pdf_area = lr[0].w;
@@ -360,7 +360,7 @@ __device__ __forceinline__ void put_shadow(const PathState& P, V3 pos, const Nee
 // PLAIN: the scene has no material that can enter a medium and no textured material (neither branch can be taken), so that
 // code -- and the registers it holds -- is compiled out of the wavefront kernel.
 template <bool PLAIN = false>
-__device__ __forceinline__ uint32_t shade_principled_path(const PathState& P, const DScene& sc, uint32_t p, uint64_t rng_inc) {
+__device__ __forceinline__ uint32_t shade_principled_path(const PathState& P, const DScene& sc, uint32_t p, uint64_t rng_inc, bool first) {
   {
     const bool active = true;
     bool alive = false, shadow = false;
@@ -369,7 +369,7 @@ __device__ __forceinline__ uint32_t shade_principled_path(const PathState& P, co
     nee.dir = V3(0.f), nee.emission = V3(0.f), nee.dist = 0.f, nee.pdf_sigma = 0.f;
     uint32_t sh_mode = kShNormal, qbit = 0u;
     PathHead c;
-    if (active && path_head(P, sc, p, rng_inc, c)) {
+    if (active && path_head(P, sc, p, rng_inc, c, first)) {
       const Hit& h = c.h;
       const V3 dir = c.dir, thr = c.thr;
       const Surface& s = c.s;
@@ -510,12 +510,12 @@ __global__ __launch_bounds__(kBlock, PB_SHADE_WAVES) void k_shade_principled(Pat
   const uint32_t n = P.counts[kCntPrincipled];
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
     const uint32_t p = P.q_principled[i];
-    P.q_principled[i] = p | shade_principled_path<PLAIN>(P, sc, p, rng_inc);
+    P.q_principled[i] = p | shade_principled_path<PLAIN>(P, sc, p, rng_inc, P.first != 0u);
   }
 }
 
 // ------------------------------------------------------------------ k_shade_hair (hair-shader.cc:153-229)
-__device__ __forceinline__ uint32_t shade_hair_path(const PathState& P, const DScene& sc, uint32_t p, uint64_t rng_inc) {
+__device__ __forceinline__ uint32_t shade_hair_path(const PathState& P, const DScene& sc, uint32_t p, uint64_t rng_inc, bool first) {
   {
     const bool active = true;
     bool alive = false, shadow = false;
@@ -524,7 +524,7 @@ __device__ __forceinline__ uint32_t shade_hair_path(const PathState& P, const DS
     Nee nee;
     nee.dir = V3(0.f), nee.emission = V3(0.f), nee.dist = 0.f, nee.pdf_sigma = 0.f;
     PathHead c;
-    if (active && path_head(P, sc, p, rng_inc, c)) {
+    if (active && path_head(P, sc, p, rng_inc, c, first)) {
       const Hit& h = c.h;
       const V3 dir = c.dir, thr = c.thr;
       const Surface& s = c.s;
@@ -586,7 +586,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_hair(PathState P, DScene sc, u
   const uint32_t n = P.counts[kCntHair];
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
     const uint32_t p = P.q_hair[i];
-    P.q_hair[i] = p | shade_hair_path(P, sc, p, rng_inc);
+    P.q_hair[i] = p | shade_hair_path(P, sc, p, rng_inc, P.first != 0u);
   }
 }
 
@@ -765,6 +765,7 @@ __global__ __launch_bounds__(kBlock) void k_tail(PathState P, DScene sc, uint64_
     const uint32_t e = P.q_in[i];
     const uint32_t p = e & kQPathMask;
     bool in_medium = (e & kQSssBit) != 0u;
+    bool first = P.first != 0u;  // the tail starts at the very first bounce of tiny renders
     for (;;) {
       uint32_t r;
       if (in_medium) {
@@ -772,8 +773,9 @@ __global__ __launch_bounds__(kBlock) void k_tail(PathState P, DScene sc, uint64_
       } else {
         const uint32_t slot = __float_as_uint(P.hit[p].w);
         if (slot == kNone) break;  // miss: the path ends (render.cc:34)
-        r = (slot & kHitHair) ? shade_hair_path(P, sc, p, rng_inc) : shade_principled_path(P, sc, p, rng_inc);
+        r = (slot & kHitHair) ? shade_hair_path(P, sc, p, rng_inc, first) : shade_principled_path(P, sc, p, rng_inc, first);
       }
+      first = false;
       if (r & kRShadow) {
         const float4 o4 = P.ray_o[p], d4 = P.sh_d[p];
         Hit h;

@@ -917,6 +917,7 @@ static int render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volat
     P.q_in = s->q[0].p, P.q_out = s->q[1].p, P.q_principled = s->q[2].p, P.q_hair = s->q[3].p, P.q_sss = s->q[4].p, P.q_shadow = s->q[5].p, P.q_shadow_in = s->q[6].p;
     P.sh_d = s->sh[0].p, P.sh_c = s->sh[1].p, P.sh_e = s->sh[2].p;
     P.counts = s->counts.p, P.stats = want_stats ? s->stats.p : nullptr, P.spill = s->spill.p;
+    P.first = 0u, P.cam_org[0] = P.cam_org[1] = P.cam_org[2] = 0.f;
     HIPCHK(hipMemsetAsync(s->stats.p, 0, sizeof(unsigned long long) * kStatNum, st));
     const Camera cam = make_camera(s, d->width, d->height);
     const uint64_t rng_inc = (d->seed_seq << 1u) | 1u;  // pcg32_srandom (rng.h:30-36)
@@ -941,6 +942,7 @@ static int render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volat
       uint32_t* h_counts;
       uint32_t n, first_pass, npass, slot0;
       Timer tm;
+      uint32_t iters = 0;
     };
 
     for (uint32_t done = 0; done < d->num_sample;) {
@@ -957,6 +959,8 @@ static int render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volat
         const size_t off = gr.slot0;
         gr.P.q_in += off, gr.P.q_out += off, gr.P.q_principled += off, gr.P.q_hair += off, gr.P.q_sss += off, gr.P.q_shadow += off, gr.P.q_shadow_in += off;
         gr.P.counts = s->counts.p + g * kCntNum;
+        gr.P.first = 0u;
+        for (int k = 0; k < 3; k++) gr.P.cam_org[k] = cam.org[k];
         gr.P.spill = s->spill.p + (size_t)g * kStackDepth * kTraceGridCap * 256;
         G.push_back(gr);
       }
@@ -967,6 +971,7 @@ static int render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volat
         const uint32_t n = std::max(gr.n, 1u);
         if (gr.n <= tail_paths) {
           // few live paths: trace this bounce (and the pending shadow rays), then finish every path in one launch
+          gr.P.first = gr.iters++ == 0 ? 1u : 0u;
           HIPCHK(gr.tm.begin(&S.ms_trace_closest));
           launch_trace(gr.st, gr.P, sc, 2 * n, want_stats);
           HIPCHK(gr.tm.end());
@@ -979,6 +984,7 @@ static int render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volat
           return PBRHIP_OK;
         }
         for (int it = 0; it < burst; it++) {
+          gr.P.first = gr.iters++ == 0 ? 1u : 0u;
           HIPCHK(gr.tm.begin(&S.ms_trace_closest));
           launch_trace(gr.st, gr.P, sc, 2 * n, want_stats);  // this bounce's closest rays + last bounce's shadow rays
           HIPCHK(gr.tm.end());
