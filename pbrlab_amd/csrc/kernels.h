@@ -11,7 +11,7 @@ namespace pb {
 // Per-path state, SoA, float4-packed so that a wave reads/writes 1 KiB per instruction.
 // N = paths of one chunk (pixels of this rank's tiles x passes in the chunk); slot = pass_local*npix + pixel.
 //   ray_o (org.xyz, tmin) | ray_d (dir.xyz, tmax) | thr (throughput.rgb, bsdf pdf) | L (contribution.rgb, -)
-//   hit (t, u, v, slot bits) | rng (PCG32 state, u64) | flags (u32)                                = 92 B
+//   hit (t, u, v, slot bits) | rng (PCG32 state, u64)                                              = 88 B
 //   random-walk state, touched only by paths inside a medium:                                       96 B
 //     sss_sigt (sigma_t.rgb, step index) | sss_sigs (sigma_s.rgb, entry instance id) | sss_thr (walk throughput)
 //     sss_pdf (channel pdf of the pending step) | sss_ez (entry frame normal) | sss_A (resolved first NEE)
@@ -21,15 +21,15 @@ namespace pb {
 struct PathState {
   float4 *ray_o, *ray_d, *thr, *L, *hit;
   uint64_t* rng;
-  uint32_t* flags;
   float4 *sss_sigt, *sss_sigs, *sss_thr, *sss_pdf, *sss_ez, *sss_A;
   uint32_t *q_in, *q_out, *q_principled, *q_hair, *q_sss, *q_shadow, *q_shadow_in;
   float4 *sh_d, *sh_c, *sh_e;
   uint32_t* spill;               // traversal-stack spill area: (kStackDepth - LDS part) x resident threads
   uint32_t* counts;              // kCnt*
   unsigned long long* stats;     // kStat*; null unless the render collects statistics
-  // First bounce of a chunk: every path still has the camera position as its origin (tmin 0), throughput (1,1,1), pdf 0 and
-  // flags 0, so k_generate does not store ray_o / thr / flags and the first trace and shading do not load them.
+  // First bounce of a chunk: every path still has the camera position as its origin (tmin 0), throughput (1,1,1) and pdf 0,
+  // so k_generate does not store ray_o / thr and the first trace and shading do not load them; the only per-path flag
+  // ("not the first bounce", MIS weight of emission) is the same bit.
   float cam_org[3];
   uint32_t first;
 };

@@ -276,8 +276,8 @@ struct PathHead {
 __device__ __forceinline__ bool path_head(const PathState& P, const DScene& sc, uint32_t p, uint64_t rng_inc, PathHead& c, bool first) {
   float4 h4 = P.hit[p], d4 = P.ray_d[p];
   float4 o4 = make_float4(P.cam_org[0], P.cam_org[1], P.cam_org[2], 0.0f), t4 = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-  c.flags = 0u;
-  if (!first) o4 = P.ray_o[p], t4 = P.thr[p], c.flags = P.flags[p];  // the camera ray's values are implied (PathState::first)
+  c.flags = first ? 0u : kFlagNotFirst;  // set by every head after the first (render.cc:43-61: depth-0 emission has weight 1)
+  if (!first) o4 = P.ray_o[p], t4 = P.thr[p];  // the camera ray's values are implied (PathState::first)
   c.h.t = h4.x, c.h.u = h4.y, c.h.v = h4.z, c.h.slot = __float_as_uint(h4.w);
   c.dir = ld3(d4);
   c.s = make_surface(sc, ld3(o4), c.dir, c.h);
@@ -454,7 +454,6 @@ __device__ __forceinline__ uint32_t shade_principled_path(const PathState& P, co
               P.sss_ez[p] = mk4(fr.ez, 0.f);
               P.sss_A[p] = make_float4(0.f, 0.f, 0.f, 0.f);
               P.thr[p] = mk4(thr, 0.f);  // Russian-roulette-scaled path throughput, used again at the exit
-              P.flags[p] = c.flags;
               P.rng[p] = rng.state;
               alive = true;
               qbit = kQSssBit;
@@ -489,7 +488,6 @@ __device__ __forceinline__ uint32_t shade_principled_path(const PathState& P, co
               P.ray_d[p] = mk4(next_dir, kInf);
               P.thr[p] = mk4(t2, new_pdf);
               P.rng[p] = rng.state;
-              P.flags[p] = c.flags;
             } else {
               qbit = 0u;
               count_pruned(P);
@@ -570,7 +568,6 @@ __device__ __forceinline__ uint32_t shade_hair_path(const PathState& P, const DS
             P.ray_d[p] = mk4(next_dir, kInf);
             P.thr[p] = mk4(t2, pdf);
             P.rng[p] = rng.state;
-            P.flags[p] = c.flags;
           } else {
             qbit = 0u;
             count_pruned(P);

@@ -124,7 +124,7 @@ struct pbrhip_scene {
   // render working set (grown on demand, reused across calls)
   DevBuf<float4> ray_o, ray_d, thr, L, hit, sss[6], sh[3];
   DevBuf<uint64_t> rng;
-  DevBuf<uint32_t> flags, q[7], counts, pix_index, spill;
+  DevBuf<uint32_t> q[7], counts, pix_index, spill;
   DevBuf<unsigned long long> stats;
   DevBuf<float> own_rgba;
   DevBuf<uint32_t> own_count;
@@ -765,7 +765,7 @@ static Camera make_camera(const pbrhip_scene* s, uint32_t width, uint32_t height
 }
 
 // ------------------------------------------------------------------ render
-static constexpr uint64_t kBytesPerPath = 5 * 16 + 8 + 4 + 6 * 16 + 7 * 4 + 3 * 16;  // ensure_paths()
+static constexpr uint64_t kBytesPerPath = 5 * 16 + 8 + 6 * 16 + 7 * 4 + 3 * 16;  // ensure_paths()
 namespace {
 struct Timer {
   pbrhip_scene* s;
@@ -856,7 +856,6 @@ static int ensure_paths(pbrhip_scene* s, size_t n) {
   for (auto& b : s->sss) HIPCHK(b.reserve(n));
   for (auto& b : s->sh) HIPCHK(b.reserve(n));
   HIPCHK(s->rng.reserve(n));
-  HIPCHK(s->flags.reserve(n));
   for (auto& b : s->q) HIPCHK(b.reserve(n));
   HIPCHK(s->counts.reserve(kCntNum * kMaxGroups));
   HIPCHK(s->stats.reserve(kStatNum));
@@ -886,13 +885,13 @@ static int render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volat
   const bool want_stats = (d->flags & PBRHIP_RENDER_STATS) != 0;
   if (npix > 0 && d->num_sample > 0) {
     // default: as many paths in flight as half of the free HBM holds (288 GB: a whole 1080p x 64 spp frame,
-    // 132.7 M paths x ~272 B, is one chunk) -- fewer, larger launches and one tail instead of many
+    // 132.7 M paths x 260 B, is one chunk) -- fewer, larger launches and one tail instead of many
     uint64_t max_paths = d->max_paths_in_flight;
     if (!max_paths) {
       size_t free_b = 0, total_b = 0;
       HIPCHK(hipMemGetInfo(&free_b, &total_b));
       // what this scene already holds for path state counts as available
-      size_t have = (s->ray_o.n + s->ray_d.n + s->thr.n + s->L.n + s->hit.n) * 16 + s->rng.n * 8 + s->flags.n * 4;
+      size_t have = (s->ray_o.n + s->ray_d.n + s->thr.n + s->L.n + s->hit.n) * 16 + s->rng.n * 8;
       for (auto& b : s->sss) have += b.n * 16;
       for (auto& b : s->sh) have += b.n * 16;
       for (auto& b : s->q) have += b.n * 4;
@@ -911,7 +910,7 @@ static int render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volat
     if (int rc = ensure_paths(s, (size_t)chunk_passes * npix)) return rc;
     PathState P;
     P.ray_o = s->ray_o.p, P.ray_d = s->ray_d.p, P.thr = s->thr.p, P.L = s->L.p, P.hit = s->hit.p;
-    P.rng = s->rng.p, P.flags = s->flags.p;
+    P.rng = s->rng.p;
     P.sss_sigt = s->sss[0].p, P.sss_sigs = s->sss[1].p, P.sss_thr = s->sss[2].p, P.sss_pdf = s->sss[3].p;
     P.sss_ez = s->sss[4].p, P.sss_A = s->sss[5].p;
     P.q_in = s->q[0].p, P.q_out = s->q[1].p, P.q_principled = s->q[2].p, P.q_hair = s->q[3].p, P.q_sss = s->q[4].p, P.q_shadow = s->q[5].p, P.q_shadow_in = s->q[6].p;
