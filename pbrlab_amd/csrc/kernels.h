@@ -13,7 +13,7 @@ namespace pb {
 //   ray_o (org.xyz, tmin) | ray_d (dir.xyz, tmax) | thr (throughput.rgb, bsdf pdf) | L (contribution.rgb, -)
 //   hit (t, u, v, slot bits) | rng (PCG32 state, u64)                                              = 88 B
 //   random-walk state, touched only by paths inside a medium:                                       96 B
-//     sss_sigt (sigma_t.rgb, step index) | sss_sigs (sigma_s.rgb, entry instance id) | sss_thr (walk throughput)
+//     sss_sigt (sigma_t.rgb) | sss_sigs (sigma_s.rgb, entry instance id) | sss_thr (walk throughput, step index)
 //     sss_pdf (channel pdf of the pending step) | sss_ez (entry frame normal) | sss_A (resolved first NEE)
 //   queues (u32 path slots): q_in/q_out (ping-pong), q_principled, q_hair, q_sss, q_shadow; the shadow-ray payload
 //     sits at the path's own slot: sh_d (dir, tmax) | sh_c (contribution if visible, mode) | sh_e (contribution if occluded:

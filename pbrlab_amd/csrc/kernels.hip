@@ -447,9 +447,9 @@ __device__ __forceinline__ uint32_t shade_principled_path(const PathState& P, co
               float t_scatter = sample_scatter_distance(wthr, sigs, sigt, e0, e1, chpdf);
               P.ray_o[p] = mk4(s.pos, 1e-3f);
               P.ray_d[p] = mk4(gdir, t_scatter);
-              P.sss_sigt[p] = mk4(sigt, __uint_as_float(0u));                      // .w = bounce index
+              P.sss_sigt[p] = mk4(sigt, 0.f);
               P.sss_sigs[p] = mk4(sigs, __uint_as_float(sc.shade[h.slot & kHitSlotMask].instance_id));  // .w = entry instance id
-              P.sss_thr[p] = mk4(wthr, 0.f);
+              P.sss_thr[p] = mk4(wthr, __uint_as_float(0u));  // .w = step index (kept with the data every step rewrites)
               P.sss_pdf[p] = mk4(chpdf, 0.f);
               P.sss_ez[p] = mk4(fr.ez, 0.f);
               P.sss_A[p] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -604,7 +604,7 @@ __device__ __forceinline__ uint32_t sss_step_path(const PathState& P, const DSce
       float4 st4 = P.sss_sigt[p], ss4 = P.sss_sigs[p], wt4 = P.sss_thr[p], cp4 = P.sss_pdf[p];
       Hit h = {h4.x, h4.y, h4.z, __float_as_uint(h4.w)};
       V3 org = ld3(o4), dir = ld3(d4), sigt = ld3(st4), sigs = ld3(ss4), wthr = ld3(wt4), chpdf = ld3(cp4);
-      uint32_t bounce = __float_as_uint(st4.w), entry_inst = __float_as_uint(ss4.w);
+      uint32_t bounce = __float_as_uint(wt4.w), entry_inst = __float_as_uint(ss4.w);
       Rng rng = {P.rng[p], rng_inc};
       bool hit = (h.slot != kNone);
       float t = hit ? h.t : d4.w;  // d4.w = t_scatter
@@ -641,8 +641,7 @@ __device__ __forceinline__ uint32_t sss_step_path(const PathState& P, const DSce
         float t_scatter = sample_scatter_distance(wthr, sigs, sigt, e0, e1, chpdf);
         P.ray_o[p] = mk4(org, 0.f);
         P.ray_d[p] = mk4(wi, t_scatter);
-        P.sss_sigt[p] = mk4(sigt, __uint_as_float(bounce));
-        P.sss_thr[p] = mk4(wthr, 0.f);
+        P.sss_thr[p] = mk4(wthr, __uint_as_float(bounce));
         P.sss_pdf[p] = mk4(chpdf, 0.f);
         P.rng[p] = rng.state;
         alive = true;
