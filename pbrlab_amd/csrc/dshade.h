@@ -339,14 +339,17 @@ PB_HD void scattering_from_albedo(float A, float d, float& sigma_t, float& sigma
   sigma_s = sigma_t * a;
 }
 // SampleScatterDistance + SampleChannel (:141-188)
-PB_HD float sample_scatter_distance(V3 throughput, V3 sigma_s, V3 sigma_t, float u0, float u1, V3& channel_pdf) {
+// the channel pdf is a function of (walk throughput, sigma_s, sigma_t) alone: the step that consumes it recomputes it from the
+// stored throughput instead of keeping it in the path state
+PB_HD V3 scatter_channel_pdf(V3 throughput, V3 sigma_s, V3 sigma_t) {
   V3 albedo = safe_divide_spectrum(sigma_s, sigma_t);
   V3 w(fabsf(throughput.x * albedo.x), fabsf(throughput.y * albedo.y), fabsf(throughput.z * albedo.z));
   float sum = w.x + w.y + w.z;
-  if (sum > 0.0f)
-    channel_pdf = V3(w.x / sum, w.y / sum, w.z / sum);
-  else
-    channel_pdf = V3(1.0f / 3.0f, 1.0f / 3.0f, 1.0f / 3.0f);
+  if (sum > 0.0f) return V3(w.x / sum, w.y / sum, w.z / sum);
+  return V3(1.0f / 3.0f, 1.0f / 3.0f, 1.0f / 3.0f);
+}
+PB_HD float sample_scatter_distance(V3 throughput, V3 sigma_s, V3 sigma_t, float u0, float u1, V3& channel_pdf) {
+  channel_pdf = scatter_channel_pdf(throughput, sigma_s, sigma_t);
   float st = (u0 < channel_pdf.x) ? sigma_t.x : ((u0 < channel_pdf.x + channel_pdf.y) ? sigma_t.y : sigma_t.z);
   return -f_log(1.0f - u1) / st;
 }

@@ -12,16 +12,16 @@ namespace pb {
 // N = paths of one chunk (pixels of this rank's tiles x passes in the chunk); slot = pass_local*npix + pixel.
 //   ray_o (org.xyz, tmin) | ray_d (dir.xyz, tmax) | thr (throughput.rgb, bsdf pdf) | L (contribution.rgb, -)
 //   hit (t, u, v, slot bits) | rng (PCG32 state, u64)                                              = 88 B
-//   random-walk state, touched only by paths inside a medium:                                       96 B
+//   random-walk state, touched only by paths inside a medium:                                       80 B
 //     sss_sigt (sigma_t.rgb) | sss_sigs (sigma_s.rgb, entry instance id) | sss_thr (walk throughput, step index)
-//     sss_pdf (channel pdf of the pending step) | sss_ez (entry frame normal) | sss_A (resolved first NEE)
+//     sss_ez (entry frame normal) | sss_A (resolved first NEE)
 //   queues (u32 path slots): q_in/q_out (ping-pong), q_principled, q_hair, q_sss, q_shadow; the shadow-ray payload
 //     sits at the path's own slot: sh_d (dir, tmax) | sh_c (contribution if visible, mode) | sh_e (contribution if occluded:
 //     medium exits only); origin and tmin are ray_o's (the shadow ray starts where the continuation ray starts)
 struct PathState {
   float4 *ray_o, *ray_d, *thr, *L, *hit;
   uint64_t* rng;
-  float4 *sss_sigt, *sss_sigs, *sss_thr, *sss_pdf, *sss_ez, *sss_A;
+  float4 *sss_sigt, *sss_sigs, *sss_thr, *sss_ez, *sss_A;
   uint32_t *q_in, *q_out, *q_principled, *q_hair, *q_sss, *q_shadow, *q_shadow_in;
   float4 *sh_d, *sh_c, *sh_e;
   uint32_t* spill;               // traversal-stack spill area: (kStackDepth - LDS part) x resident threads

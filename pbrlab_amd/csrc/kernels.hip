@@ -450,7 +450,6 @@ __device__ __forceinline__ uint32_t shade_principled_path(const PathState& P, co
               P.sss_sigt[p] = mk4(sigt, 0.f);
               P.sss_sigs[p] = mk4(sigs, __uint_as_float(sc.shade[h.slot & kHitSlotMask].instance_id));  // .w = entry instance id
               P.sss_thr[p] = mk4(wthr, __uint_as_float(0u));  // .w = step index (kept with the data every step rewrites)
-              P.sss_pdf[p] = mk4(chpdf, 0.f);
               P.sss_ez[p] = mk4(fr.ez, 0.f);
               P.sss_A[p] = make_float4(0.f, 0.f, 0.f, 0.f);
               P.thr[p] = mk4(thr, 0.f);  // Russian-roulette-scaled path throughput, used again at the exit
@@ -601,9 +600,10 @@ __device__ __forceinline__ uint32_t sss_step_path(const PathState& P, const DSce
     nee.dir = V3(0.f), nee.emission = V3(0.f), nee.dist = 0.f, nee.pdf_sigma = 0.f;
     if (active) {
       float4 h4 = P.hit[p], o4 = P.ray_o[p], d4 = P.ray_d[p];
-      float4 st4 = P.sss_sigt[p], ss4 = P.sss_sigs[p], wt4 = P.sss_thr[p], cp4 = P.sss_pdf[p];
+      float4 st4 = P.sss_sigt[p], ss4 = P.sss_sigs[p], wt4 = P.sss_thr[p];
       Hit h = {h4.x, h4.y, h4.z, __float_as_uint(h4.w)};
-      V3 org = ld3(o4), dir = ld3(d4), sigt = ld3(st4), sigs = ld3(ss4), wthr = ld3(wt4), chpdf = ld3(cp4);
+      V3 org = ld3(o4), dir = ld3(d4), sigt = ld3(st4), sigs = ld3(ss4), wthr = ld3(wt4);
+      V3 chpdf = scatter_channel_pdf(wthr, sigs, sigt);  // what sample_scatter_distance computed when it drew this step's distance
       uint32_t bounce = __float_as_uint(wt4.w), entry_inst = __float_as_uint(ss4.w);
       Rng rng = {P.rng[p], rng_inc};
       bool hit = (h.slot != kNone);
@@ -642,7 +642,6 @@ __device__ __forceinline__ uint32_t sss_step_path(const PathState& P, const DSce
         P.ray_o[p] = mk4(org, 0.f);
         P.ray_d[p] = mk4(wi, t_scatter);
         P.sss_thr[p] = mk4(wthr, __uint_as_float(bounce));
-        P.sss_pdf[p] = mk4(chpdf, 0.f);
         P.rng[p] = rng.state;
         alive = true;
         qbit = kQSssBit;

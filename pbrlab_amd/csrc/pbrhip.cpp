@@ -122,7 +122,7 @@ struct pbrhip_scene {
   DevBuf<BvhNode> d_light_boxes;
   DScene dscene;
   // render working set (grown on demand, reused across calls)
-  DevBuf<float4> ray_o, ray_d, thr, L, hit, sss[6], sh[3];
+  DevBuf<float4> ray_o, ray_d, thr, L, hit, sss[5], sh[3];
   DevBuf<uint64_t> rng;
   DevBuf<uint32_t> q[7], counts, pix_index, spill;
   DevBuf<unsigned long long> stats;
@@ -765,7 +765,7 @@ static Camera make_camera(const pbrhip_scene* s, uint32_t width, uint32_t height
 }
 
 // ------------------------------------------------------------------ render
-static constexpr uint64_t kBytesPerPath = 5 * 16 + 8 + 6 * 16 + 7 * 4 + 3 * 16;  // ensure_paths()
+static constexpr uint64_t kBytesPerPath = 5 * 16 + 8 + 5 * 16 + 7 * 4 + 3 * 16;  // ensure_paths()
 namespace {
 struct Timer {
   pbrhip_scene* s;
@@ -885,7 +885,7 @@ static int render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volat
   const bool want_stats = (d->flags & PBRHIP_RENDER_STATS) != 0;
   if (npix > 0 && d->num_sample > 0) {
     // default: as many paths in flight as half of the free HBM holds (288 GB: a whole 1080p x 64 spp frame,
-    // 132.7 M paths x 260 B, is one chunk) -- fewer, larger launches and one tail instead of many
+    // 132.7 M paths x 244 B, is one chunk) -- fewer, larger launches and one tail instead of many
     uint64_t max_paths = d->max_paths_in_flight;
     if (!max_paths) {
       size_t free_b = 0, total_b = 0;
@@ -911,8 +911,8 @@ static int render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volat
     PathState P;
     P.ray_o = s->ray_o.p, P.ray_d = s->ray_d.p, P.thr = s->thr.p, P.L = s->L.p, P.hit = s->hit.p;
     P.rng = s->rng.p;
-    P.sss_sigt = s->sss[0].p, P.sss_sigs = s->sss[1].p, P.sss_thr = s->sss[2].p, P.sss_pdf = s->sss[3].p;
-    P.sss_ez = s->sss[4].p, P.sss_A = s->sss[5].p;
+    P.sss_sigt = s->sss[0].p, P.sss_sigs = s->sss[1].p, P.sss_thr = s->sss[2].p;
+    P.sss_ez = s->sss[3].p, P.sss_A = s->sss[4].p;
     P.q_in = s->q[0].p, P.q_out = s->q[1].p, P.q_principled = s->q[2].p, P.q_hair = s->q[3].p, P.q_sss = s->q[4].p, P.q_shadow = s->q[5].p, P.q_shadow_in = s->q[6].p;
     P.sh_d = s->sh[0].p, P.sh_c = s->sh[1].p, P.sh_e = s->sh[2].p;
     P.counts = s->counts.p, P.stats = want_stats ? s->stats.p : nullptr, P.spill = s->spill.p;
