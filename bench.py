@@ -43,8 +43,8 @@ WORKLOADS = {
 
 # algorithmic bytes of the traversal kernel k_trace: 64 B per BVH node visited, 48 B per
 # triangle tested, 64 B per curve tested; per closest-hit ray 32 B ray + 16 B hit record + 4 B queue entry; per
-# shadow ray 32 B ray + 4 B queue entry + 32 B pending-contribution payload
-NODE_B, TRI_B, CURVE_B, RAY_B, SHADOW_RAY_B = 64, 48, 64, 52, 68
+# shadow ray 32 B ray (origin shared with the continuation ray) + 4 B queue entry + 16 B pending contribution
+NODE_B, TRI_B, CURVE_B, RAY_B, SHADOW_RAY_B = 64, 48, 64, 52, 52
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
@@ -205,7 +205,7 @@ def main():
             achieved = bytes_step / (ms_step * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": "k_trace (closest-hit rays of bounce k + shadow rays of bounce k-1)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                        "note": "achieved = ALGORITHMIC bytes (64 B per node visit, 48 B per triangle test, rays) / kernel time as "
+                        "note": "achieved = ALGORITHMIC bytes (64 B per node visit, 48 B per triangle test, 52 B per ray) / kernel time as "
                                 "SURVEY 8d defines it; the 128 MB scene is served from L2 / Infinity Cache, so this can exceed the HBM "
                                 "peak -- the HBM-side bytes per launch measured with PMC counters are `traffic`.  By default the "
                                 "frame runs as two path groups on two HIP streams: their k_trace launches overlap each other and the "
