@@ -57,12 +57,29 @@ __device__ __forceinline__ V3 bezier_tangent(const float4 cp[4], float u) {
 // Ray-facing flat ribbon, 4 linear pieces per cubic (RTC_GEOMETRY_TYPE_FLAT_BEZIER_CURVE, raytracer_impl.cc:158-159);
 // every piece is its own traversal primitive: a = B(i/4), b = B((i+1)/4) (xyz + radius, evaluated at commit).
 // u = curve parameter, v in [-1,1] across the width.
+// The part of the test that depends on the ray alone: unit direction, the two axes of the ray-facing plane, 1/|d|.  The
+// phase-voting traversal computes it once per ray (at the refill) and keeps it in LDS; every piece test of that ray reads it.
+struct RayFrame {
+  V3 dn, bx, by;
+  float inv_len;
+};
+__device__ __forceinline__ RayFrame ray_frame(V3 d) {
+  RayFrame f;
+  f.inv_len = 1.0f / sqrtf(dot(d, d));
+  f.dn = d * f.inv_len;
+  branchless_onb(f.dn, f.bx, f.by);
+  return f;
+}
+__device__ __forceinline__ bool segment_test(const float4& a, const float4& b, uint32_t i, V3 o, const RayFrame& f, float tmin, float tmax,
+                                             float& t, float& u, float& v);
 __device__ __forceinline__ bool segment_test(const float4& a, const float4& b, uint32_t i, V3 o, V3 d, float tmin, float tmax,
                                              float& t, float& u, float& v) {
-  float inv_len = 1.0f / sqrtf(dot(d, d));
-  V3 dn = d * inv_len;
-  V3 bx, by;
-  branchless_onb(dn, bx, by);
+  return segment_test(a, b, i, o, ray_frame(d), tmin, tmax, t, u, v);
+}
+__device__ __forceinline__ bool segment_test(const float4& a, const float4& b, uint32_t i, V3 o, const RayFrame& f, float tmin, float tmax,
+                                             float& t, float& u, float& v) {
+  const float inv_len = f.inv_len;
+  const V3 dn = f.dn, bx = f.bx, by = f.by;
   V3 ra = V3(a.x, a.y, a.z) - o, rb = V3(b.x, b.y, b.z) - o;
   float pxa = dot(ra, bx), pya = dot(ra, by), pza = dot(ra, dn);
   float pxb = dot(rb, bx), pyb = dot(rb, by), pzb = dot(rb, dn);

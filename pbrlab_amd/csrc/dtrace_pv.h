@@ -56,7 +56,8 @@ enum : uint32_t { kStIdle = 0, kStNode = 1, kStTri = 2, kStCurve = 3, kStDone = 
 template <int MODE, bool STATS, bool CURVES, typename Sink>
 __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t* head, Sink& sink, uint32_t* stk_base,
                                          uint32_t stride, uint32_t* spill, uint32_t spill_stride, TravStats& st,
-                                         uint32_t* overflow) {
+                                         uint32_t* overflow, float* frame = nullptr) {
+  // frame (CURVES): 10 words per lane in LDS (frame[k * stride]), the ray's RayFrame, written when the ray is fetched
   const uint32_t lane = __lane_id();
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   // wave-uniform batch cursor.  Rays are grabbed kPvBatch at a time when there are plenty; when the queue is
@@ -135,6 +136,12 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
         bool a = sink.load(batch_cur + rank, tag, o, d, tmin, tmax);
         any_ray = (MODE == 1) || (MODE == 2 && a);
         inv = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        if (CURVES) {
+          const RayFrame f = ray_frame(d);
+          const float w[10] = {f.dn.x, f.dn.y, f.dn.z, f.bx.x, f.bx.y, f.bx.z, f.by.x, f.by.y, f.by.z, f.inv_len};
+#pragma unroll
+          for (int k = 0; k < 10; k++) frame[(uint32_t)k * stride] = w[k];
+        }
         hit.t = tmax, hit.u = 0.f, hit.v = 0.f, hit.slot = kNone;
         sp = 0;
         advance = true, have_next = true, next = 0u;  // root is always an internal node
@@ -191,7 +198,10 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
             ok = tri_test(ld3(D0), ld3(D1), ld3(D2), o, d, tmin, t, u, v) && (t <= hit.t);
           } else {
             if (STATS) (any_ray ? st.acurves : st.curves)++;
-            ok = segment_test(D0, D1, __float_as_uint(D2.x), o, d, tmin, hit.t, t, u, v);
+            RayFrame f;
+            f.dn = V3(frame[0], frame[stride], frame[2 * stride]), f.bx = V3(frame[3 * stride], frame[4 * stride], frame[5 * stride]);
+            f.by = V3(frame[6 * stride], frame[7 * stride], frame[8 * stride]), f.inv_len = frame[9 * stride];
+            ok = segment_test(D0, D1, __float_as_uint(D2.x), o, f, tmin, hit.t, t, u, v);
           }
           if (ok && !any_ray && t == hit.t && hit.slot != kNone) ok = sc.shade[cur - sc.num_nodes].gid < sc.shade[hit.slot & kHitSlotMask].gid;
           if (ok) {

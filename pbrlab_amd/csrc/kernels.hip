@@ -103,12 +103,14 @@ struct TraceSink {
 template <bool STATS, bool CURVES>
 __global__ __launch_bounds__(kBlock, (CURVES ? kTraceBlocksPerCUCurves : kTraceBlocksPerCU)) void k_trace(PathState P, DScene sc) {
   __shared__ uint32_t stk[kPvLdsStack * kBlock];
+  __shared__ float frm[CURVES ? 10 * kBlock : 1];
   const uint32_t n_closest = P.counts[kCntIn], n_shadow = P.counts[kCntShadowIn];
   TravStats st = {};
   uint32_t overflow = 0u;
   TraceSink sink = {P, n_closest};
   trace_pv<2, STATS, CURVES>(sc, n_closest + n_shadow, &P.counts[kCntHead], sink, stk + threadIdx.x, kBlock,
-                             P.spill + blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, st, &overflow);
+                             P.spill + blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, st, &overflow,
+                             CURVES ? frm + threadIdx.x : nullptr);
   if (overflow) P.counts[kCntOverflow] = 1u;
   if (STATS) {
     uint32_t v[13] = {st.nodes, st.tris, st.curves, st.anodes, st.atris, st.acurves, st.it_node, st.it_tri, st.it_curve,
@@ -849,11 +851,12 @@ template <bool ANY>
 __global__ __launch_bounds__(kBlock) void k_hook_pv(DScene sc, const float4* __restrict__ rays, uint32_t n, HookHit* hits,
                                                     uint8_t* occ, uint32_t* counts, uint32_t* spill) {
   __shared__ uint32_t stk[kPvLdsStack * kBlock];
+  __shared__ float frm[10 * kBlock];
   TravStats st = {};
   uint32_t overflow = 0u;
   HookSink sink = {sc, rays, hits, occ};
   trace_pv<ANY ? 1 : 0, false, true>(sc, n, &counts[kCntHead], sink, stk + threadIdx.x, kBlock,
-                             spill + blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, st, &overflow);
+                             spill + blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, st, &overflow, frm + threadIdx.x);
   if (overflow) counts[kCntOverflow] = 1u;
 }
 // One ray per thread, plain stack traversal (dtrace.h): an independent second implementation, selected with
