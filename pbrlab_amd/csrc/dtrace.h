@@ -202,95 +202,4 @@ __device__ __forceinline__ bool traverse(const DScene& sc, V3 o, V3 d, float tmi
   }
 }
 
-// Two rays of one lane traversed together: the shadow ray of a bounce and the ray that continues the path are both known
-// when shading ends, and a lone traversal is a chain of dependent loads (k_tail: a few lanes per wave, nothing to hide the
-// latency behind).  Each ray is a small state machine over "items" -- a node or a primitive slot, both 64 bytes in one
-// array -- and every round loads the current item of BOTH rays before either is consumed, so the two chains overlap.  The
-// tests, the tie rule and the conservative box logic are the ones of traverse() / trace_pv(): same results.
-struct TravLane {
-  V3 o, d, inv;
-  float tmin;
-  Hit hit;            // hit.t doubles as the current tmax
-  uint32_t cur, end;  // item index (node, or num_nodes + slot) and end of the leaf being tested
-  int sp;
-  uint32_t kind;      // 0 node, 1 triangle, 2 curve piece, 3 finished
-  bool any, occluded;
-};
-enum : uint32_t { kTlNode = 0, kTlTri = 1, kTlCurve = 2, kTlDone = 3 };
-
-__device__ __forceinline__ void trav_begin(TravLane& L, const DScene& sc, V3 o, V3 d, float tmin, float tmax, bool any) {
-  L.o = o, L.d = d, L.inv = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z), L.tmin = tmin;
-  L.hit.t = tmax, L.hit.u = 0.f, L.hit.v = 0.f, L.hit.slot = kNone;
-  L.cur = 0, L.end = 0, L.sp = 0, L.any = any, L.occluded = false;
-  L.kind = sc.num_nodes ? kTlNode : kTlDone;
-}
-// moves on to `next` (a child reference) or, when there is none, to the top of the stack
-template <bool CURVES>
-__device__ __forceinline__ void trav_advance(TravLane& L, const DScene& sc, bool have_next, uint32_t next, const uint32_t* stack, uint32_t stride) {
-  if (!have_next) {
-    if (L.sp == 0) {
-      L.kind = kTlDone;
-      return;
-    }
-    L.sp--;
-    next = stack[(uint32_t)L.sp * stride];
-  }
-  if (next & kLeafBit) {
-    L.cur = ((next & 0x3FFFFFFFu) >> 3) + sc.num_nodes;
-    L.end = L.cur + (next & 7u) + 1u;
-    L.kind = (CURVES && (next & kCurveBit)) ? kTlCurve : kTlTri;
-  } else {
-    L.cur = next, L.kind = kTlNode;
-  }
-}
-template <bool CURVES>
-__device__ __forceinline__ void trav_step(TravLane& L, const DScene& sc, const float4& D0, const float4& D1, const float4& D2, const float4& D3,
-                                          uint32_t* stack, uint32_t stride, uint32_t* overflow) {
-  if (L.kind == kTlNode) {
-    const uint32_t c0 = __float_as_uint(D3.x), c1 = __float_as_uint(D3.y);
-    float t0, t1;
-    bool h0, h1;
-    box_test2(D0, D1, D2, L.o, L.inv, L.tmin, L.hit.t, h0, h1, t0, t1);
-    const bool swap = h1 && (!h0 || t1 < t0);
-    const uint32_t nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
-    if (h0 && h1) {
-      if (L.sp < kStackDepth) stack[(uint32_t)L.sp * stride] = farc, L.sp++;
-      else *overflow = 1u;
-    }
-    trav_advance<CURVES>(L, sc, h0 || h1, nearc, stack, stride);
-    return;
-  }
-  float t, u, v;
-  bool ok;
-  if (!CURVES || L.kind == kTlTri) ok = tri_test(ld3(D0), ld3(D1), ld3(D2), L.o, L.d, L.tmin, t, u, v) && (t <= L.hit.t);
-  else ok = segment_test(D0, D1, __float_as_uint(D2.x), L.o, L.d, L.tmin, L.hit.t, t, u, v);
-  if (ok && !L.any && t == L.hit.t && L.hit.slot != kNone) ok = sc.shade[L.cur - sc.num_nodes].gid < sc.shade[L.hit.slot & kHitSlotMask].gid;
-  if (ok) L.hit.t = t, L.hit.u = u, L.hit.v = v, L.hit.slot = (L.cur - sc.num_nodes) | __float_as_uint(D2.w);
-  if (ok && L.any) {
-    L.occluded = true, L.kind = kTlDone;
-    return;
-  }
-  L.cur++;
-  if (L.cur >= L.end) trav_advance<CURVES>(L, sc, false, 0u, stack, stride);
-}
-// closest hit of ray A into hit_a, occlusion of ray B as the return value; stack_a / stack_b: kStackDepth entries each
-template <bool CURVES>
-__device__ __forceinline__ bool traverse2(const DScene& sc, V3 oa, V3 da, float tmin_a, float tmax_a, Hit& hit_a, V3 ob, V3 db, float tmin_b,
-                                          float tmax_b, uint32_t* stack_a, uint32_t* stack_b, uint32_t stride, uint32_t* overflow) {
-  TravLane A, B;
-  trav_begin(A, sc, oa, da, tmin_a, tmax_a, false);
-  trav_begin(B, sc, ob, db, tmin_b, tmax_b, true);
-  while (A.kind != kTlDone || B.kind != kTlDone) {
-    // both loads first (a finished ray re-reads item 0: harmless, keeps the code straight-line)
-    const float4* ga = reinterpret_cast<const float4*>(sc.nodes + (A.kind != kTlDone ? A.cur : 0u));
-    const float4* gb = reinterpret_cast<const float4*>(sc.nodes + (B.kind != kTlDone ? B.cur : 0u));
-    const float4 a0 = ga[0], a1 = ga[1], a2 = ga[2], a3 = ga[3];
-    const float4 b0 = gb[0], b1 = gb[1], b2 = gb[2], b3 = gb[3];
-    if (A.kind != kTlDone) trav_step<CURVES>(A, sc, a0, a1, a2, a3, stack_a, stride, overflow);
-    if (B.kind != kTlDone) trav_step<CURVES>(B, sc, b0, b1, b2, b3, stack_b, stride, overflow);
-  }
-  hit_a = A.hit;
-  return B.occluded;
-}
-
 }  // namespace pb

@@ -746,7 +746,7 @@ __global__ __launch_bounds__(kBlock) void k_sss_step(PathState P, DScene sc, uin
 // one (dtrace.h::traverse): with a handful of lanes per wave there is nothing to vote on.
 template <bool CURVES, bool STATS>
 __global__ __launch_bounds__(kBlock) void k_tail(PathState P, DScene sc, uint64_t rng_inc) {
-  __shared__ uint32_t stk[2 * kStackDepth * kBlock];  // two traversal stacks per lane (traverse2)
+  __shared__ uint32_t stk[kStackDepth * kBlock];
   const uint32_t n = P.counts[kCntIn];
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, nwaves = gridDim.x * (kBlock >> 6);
@@ -773,18 +773,6 @@ __global__ __launch_bounds__(kBlock) void k_tail(PathState P, DScene sc, uint64_
         r = (slot & kHitHair) ? shade_hair_path(P, sc, p, rng_inc, first) : shade_principled_path(P, sc, p, rng_inc, first);
       }
       first = false;
-      if ((r & kRShadow) && (r & kRAlive)) {
-        // the shadow ray of this bounce and the ray of the next one start at the same point: traversed together
-        const float4 o4 = P.ray_o[p], d4 = P.ray_d[p], s4 = P.sh_d[p];
-        Hit h, none = {0.f, 0.f, 0.f, kNone};
-        const bool occluded = traverse2<CURVES>(sc, ld3(o4), ld3(d4), o4.w, d4.w, h, ld3(o4), ld3(s4), o4.w, s4.w, stack,
-                                                stack + kStackDepth * kBlock, kBlock, &overflow);
-        sink.done(p | 0x80000000u, none, occluded);
-        P.hit[p] = make_float4(h.t, h.u, h.v, __uint_as_float(h.slot));
-        n_shadow++, n_closest++;
-        in_medium = (r & kQSssBit) != 0u;
-        continue;
-      }
       if (r & kRShadow) {
         const float4 o4 = P.ray_o[p], d4 = P.sh_d[p];
         Hit h;
