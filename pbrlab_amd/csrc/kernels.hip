@@ -134,11 +134,13 @@ __global__ __launch_bounds__(kBlock, (CURVES ? kTraceBlocksPerCUCurves : kTraceB
 // atomics/us on this chip: a per-wave atomicAdd per append cost ~45 ms per kernel at 289 M entries).
 // A block reads kItemsPerThread strided entries per thread, ranks them with wave ballots, reduces the
 // per-(item row, wave) counts in LDS, reserves the tile's output range once, and scatters in input order.
-constexpr int kItemsPerThread = 8;
-constexpr int kTileItems = kItemsPerThread * kBlock;
+// Tile sizes: k_classify gathers (its loads depend on the queue entry), more items per thread only cost it occupancy; k_compact
+// streams, and at 8 items per thread its two counters were the bottleneck (51 k atomics per launch on one word: 0.84 ms for
+// 105 M entries; 16 items -> 0.45, 32 -> 0.3).
+constexpr int kClassifyItems = 8, kCompactItems = 32;
 constexpr int kWavesPerBlock = kBlock / 64;
 
-template <int NQ>
+template <int NQ, int kItemsPerThread>
 struct TileCompactor {
   uint32_t (*wcount)[kItemsPerThread][kWavesPerBlock];  // [NQ] in LDS
   uint32_t* base;                                        // [NQ] in LDS
@@ -185,6 +187,7 @@ struct TileCompactor {
 // ends at the head of its shading without storing anything (path_head returns false), so it is dropped here instead of
 // idling in a shading wave; likewise a hit on a primitive without material.  The routing bits come with the hit code.
 __global__ __launch_bounds__(kBlock) void k_classify(PathState P, DScene sc) {
+  constexpr int kItemsPerThread = kClassifyItems, kTileItems = kItemsPerThread * kBlock;
   __shared__ uint32_t wcount[3][kItemsPerThread][kWavesPerBlock];
   __shared__ uint32_t base[3];
   const uint32_t n = P.counts[kCntIn];
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(kBlock) void k_classify(PathState P, DScene sc) {
         dest[j] = (code & kHitHair) ? 3u : 2u;
         if (code == kNone || (!(code & kHitLight) && (doomed[j] || (code & kHitNoMaterial)))) dest[j] = 0u;
       }
-    TileCompactor<3> tc = {wcount, base, {}};
+    TileCompactor<3, kItemsPerThread> tc = {wcount, base, {}};
     tc.run(dest, counters);
 #pragma unroll
     for (int j = 0; j < kItemsPerThread; j++)
@@ -225,6 +228,7 @@ __global__ __launch_bounds__(kBlock) void k_classify(PathState P, DScene sc) {
 // The shade kernels overwrite their queue entry with  path | kRShadow | kRAlive | kQSssBit | kQDoomed  instead of
 // appending; this pass turns the three result lists into the next trace queue and the shadow-ray queue.
 __global__ __launch_bounds__(kBlock) void k_compact(PathState P) {
+  constexpr int kItemsPerThread = kCompactItems, kTileItems = kItemsPerThread * kBlock;
   __shared__ uint32_t wcount[2][kItemsPerThread][kWavesPerBlock];
   __shared__ uint32_t base[2];
   const uint32_t n0 = P.counts[kCntPrincipled], n1 = P.counts[kCntHair], n2 = P.counts[kCntSss];
@@ -242,7 +246,7 @@ __global__ __launch_bounds__(kBlock) void k_compact(PathState P) {
       d_sh[j] = (e[j] & kRShadow) ? 2u : 0u;
     }
     // two independent streams share one pass: run the compactor once per stream
-    TileCompactor<2> ta = {wcount, base, {}};
+    TileCompactor<2, kItemsPerThread> ta = {wcount, base, {}};
     {
       uint32_t dest[kItemsPerThread];
 #pragma unroll
@@ -923,15 +927,16 @@ void launch_trace(hipStream_t s, const PathState& P, const DScene& sc, uint32_t 
   else if (curves) hipLaunchKernelGGL((k_trace<false, true>), g, dim3(kBlock), 0, s, P, sc);
   else hipLaunchKernelGGL((k_trace<false, false>), g, dim3(kBlock), 0, s, P, sc);
 }
-static inline uint32_t tiles_grid(uint32_t n_upper) {
-  uint32_t g = (n_upper + kTileItems - 1) / kTileItems;
+static inline uint32_t tiles_grid(uint32_t n_upper, int items_per_thread) {
+  const uint32_t tile = (uint32_t)items_per_thread * kBlock;
+  uint32_t g = (n_upper + tile - 1) / tile;
   return g < 1 ? 1 : (g < kShadeGridCap ? g : kShadeGridCap);
 }
 void launch_classify(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper) {
-  hipLaunchKernelGGL(k_classify, dim3(tiles_grid(n_upper)), dim3(kBlock), 0, s, P, sc);
+  hipLaunchKernelGGL(k_classify, dim3(tiles_grid(n_upper, kClassifyItems)), dim3(kBlock), 0, s, P, sc);
 }
 void launch_compact(hipStream_t s, const PathState& P, uint32_t n_upper) {
-  hipLaunchKernelGGL(k_compact, dim3(tiles_grid(n_upper)), dim3(kBlock), 0, s, P);
+  hipLaunchKernelGGL(k_compact, dim3(tiles_grid(n_upper, kCompactItems)), dim3(kBlock), 0, s, P);
 }
 void launch_shade_principled(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc, bool plain) {
   if (plain) hipLaunchKernelGGL(k_shade_principled<true>, dim3(grid_for(n_upper, kShadeGridCap)), dim3(kBlock), 0, s, P, sc, rng_inc);
