@@ -1,0 +1,25 @@
+"""whole 1920x1080 frames of the benchmark scenes, GPU vs oracle, every pixel compared bit for bit (SPP env, default 2)"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import pbrlab_amd as pa
+from pbrlab_amd import scenes
+import _oracle as O
+SPP = int(os.environ.get("SPP", "2"))
+W, H = 1920, 1080
+for name, mk in (("c2", lambda: scenes.cornell_scene("ggx", seed=1)), ("c3", lambda: scenes.cornell_scene("sss", seed=1)), ("c4", lambda: scenes.hair_scene(seed=1))):
+    desc = mk()
+    sg = pa.scene_from_desc(desc)
+    so = O.oracle_scene_from_desc(desc)
+    a = pa.RenderLayer()
+    pa.Render(sg, W, H, SPP, layer=a)
+    t = time.time()
+    rgba, cnt, _ = so.render(W, H, SPP, threads=os.cpu_count() or 8, math_mode=O.MATH_F64R)
+    d = (a.rgba.view(np.uint32) != rgba.view(np.uint32)).any(axis=2)
+    rel = np.linalg.norm(a.rgba[..., :3] - rgba[..., :3]) / max(np.linalg.norm(rgba[..., :3]), 1e-30)
+    print(f"{name}: {W}x{H}x{SPP} = {W*H*SPP/1e6:.1f} M samples, differing pixels {int(d.sum())}, rel L2 {rel:.3e}, oracle {time.time()-t:.1f} s", flush=True)
+    if d.any():
+        ys, xs = np.nonzero(d)
+        for y, x in list(zip(ys, xs))[:5]:
+            print("   ", x, y, a.rgba[y, x], rgba[y, x])
