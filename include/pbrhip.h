@@ -99,8 +99,8 @@ typedef struct {
   double ms_total; /* wall time of the call measured on the host */
   uint64_t tail_closest_rays, tail_shadow_rays; /* PBRHIP_RENDER_STATS: rays traced inside k_tail (not part of the k_trace counts above) */
   uint64_t pruned_rays; /* PBRHIP_RENDER_STATS: closest-hit rays of the reference that were never traced: the path's next
-                           Russian roulette was already known to fail and the ray misses every area-light primitive, so
-                           nothing it could find changes the image (closest + tail_closest + pruned = the reference's count) */
+                           Russian roulette was already known to fail and the ray cannot reach an area light (it misses every
+                           light primitive, or the bounding box of every light), so nothing it could find changes the image (closest + tail_closest + pruned = the reference's count) */
 } pbrhip_render_stats;
 
 const char* pbrhip_last_error(void);
