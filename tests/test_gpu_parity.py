@@ -200,6 +200,27 @@ def test_material_update_and_errors(pa, pairs):
     assert not lay.rgba[..., :3].any() and (lay.count == 2).all()
 
 
+def test_material_update_switches_on_subsurface(pa):
+    """A scene committed without any subsurface material runs the PLAIN shading kernel (medium entry compiled out); a material
+    edit that switches subsurface scattering on must take the general kernel from then on: the image equals the oracle's for
+    the edited scene, and differs from the image before the edit."""
+    from pbrlab_amd import scenes
+    desc = scenes.cornell_scene("ggx", monkey_subdiv=1, lucy_nu=24, lucy_nv=8)
+    assert not any(m.get("subsurface", 0.0) > 0 for m in desc.materials if m["kind"] == "principled")
+    sg = pa.scene_from_desc(desc)
+    a, b = pa.RenderLayer(), pa.RenderLayer()
+    pa.Render(sg, 64, 48, 3, layer=a)
+    idx = next(i for i, m in enumerate(desc.materials) if m["name"] == "Lucy")
+    m = dict(desc.materials[idx], subsurface=1.0, subsurface_radius=(1.0, 0.2, 0.1), subsurface_color=(1.0, 0.8, 0.8))
+    sg.UpdateMaterialParam(idx, pa.make_principled(m))
+    pa.Render(sg, 64, 48, 3, layer=b)
+    assert a.rgba.tobytes() != b.rgba.tobytes()
+    d2 = scenes.cornell_scene("ggx", monkey_subdiv=1, lucy_nu=24, lucy_nv=8)
+    d2.materials[idx].update(subsurface=1.0, subsurface_radius=(1.0, 0.2, 0.1), subsurface_color=(1.0, 0.8, 0.8))
+    rgba, cnt, _ = O.oracle_scene_from_desc(d2).render(64, 48, 3, threads=4, math_mode=O.MATH_F64R)
+    assert b.rgba.tobytes() == rgba.tobytes()
+
+
 def test_texture_errors(pa):
     from pbrlab_amd import scenes
     s = pa.Scene()
