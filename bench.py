@@ -105,6 +105,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--max-paths", type=int, default=0)
     ap.add_argument("--streams", type=int, default=0, help="concurrent path groups (0 = the library's default)")
+    ap.add_argument("--shard-block", type=int, default=16,
+                    help="edge of the pixel blocks dealt to the ranks at N > 1 (the reference's tile is 64; smaller balances better)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = spp x N (per-GPU work fixed, default); strong = the fixed 64-spp frame split over N GPUs")
     args = ap.parse_args()
@@ -149,9 +151,11 @@ def main():
     torch.cuda.synchronize()
     ptrs = (rgba.data_ptr(), count.data_ptr())
 
+    shard_block = args.shard_block if world > 1 else 0   # one rank: the library's default order (64 x 64 tiles)
+
     def step(flags=0):
         _, st = api.Render(scene, W, H, spp, tile_rank=rank, tile_world=world, device_out=ptrs, flags=flags,
-                           max_paths_in_flight=args.max_paths, num_streams=args.streams)
+                           max_paths_in_flight=args.max_paths, num_streams=args.streams, shard_block=shard_block)
         if dist is not None:                   # the only exchange step: framebuffer reduce over xGMI
             reduce_layer(rgba, count, dst=0)
         if rank == 0:                          # RenderLayer lives on the host
@@ -190,11 +194,11 @@ def main():
     if not args.no_roofline:
         # untimed pass with traversal counters (deterministic: identical work to the timed steps)
         _, sst = api.Render(scene, W, H, spp, tile_rank=rank, tile_world=world, device_out=ptrs,
-                            flags=api.RENDER_STATS, max_paths_in_flight=args.max_paths, num_streams=args.streams)
+                            flags=api.RENDER_STATS, max_paths_in_flight=args.max_paths, num_streams=args.streams, shard_block=shard_block)
         torch.cuda.synchronize()
         # untimed: the same frame with ONE path group, i.e. every k_trace launch has the GPU to itself
         _, solo = api.Render(scene, W, H, spp, tile_rank=rank, tile_world=world, device_out=ptrs,
-                             flags=api.RENDER_TIMING, max_paths_in_flight=args.max_paths, num_streams=1)
+                             flags=api.RENDER_TIMING, max_paths_in_flight=args.max_paths, num_streams=1, shard_block=shard_block)
         torch.cuda.synchronize()
         bytes_step = (NODE_B * (sst["closest_nodes"] + sst["shadow_nodes"]) + TRI_B * (sst["closest_tris"] + sst["shadow_tris"]) +
                       CURVE_B * (sst["closest_curves"] + sst["shadow_curves"]) + RAY_B * sst["closest_rays"] +
@@ -236,7 +240,7 @@ def main():
             "config": {"workload": w["desc"] + (f" x {world} (spp scaled with the GPU count)" if (world > 1 and weak) else ""), "width": W, "height": H, "spp": spp,
                        "triangles": desc.num_triangles(), "curve_segments": desc.num_segments(),
                        "bvh_nodes": info["num_nodes"], "bvh_depth": info["depth"], "scene_bytes": info["device_bytes"],
-                       "parallelism": f"tiles%{world}" if world > 1 else "1gpu",
+                       "parallelism": f"{shard_block}x{shard_block} pixel blocks, block index % {world}" if world > 1 else "1gpu",
                        "rng": "PCG32((pass<<32)+pixel, 1234567890)"},
             "roofline": roofline, "cpu_baseline": cpu,
         }

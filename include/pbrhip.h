@@ -81,6 +81,9 @@ typedef struct {
   uint32_t num_streams;               /* concurrent path groups, one HIP stream each (0 = default: 2 when a chunk holds >= 16 Mi paths, else 1; max 8) */
   uint32_t tail_paths;                /* once a group has at most this many live paths, the rest of every path runs in ONE launch
                                          (k_tail) instead of one set of launches per bounce; 0 = default 262144, 0xFFFFFFFF = never */
+  uint32_t shard_block;               /* edge of the square pixel blocks dealt to ranks (block index % tile_world == tile_rank);
+                                         0 = 64, the reference's tile (render-tile.cc:29-41).  Smaller blocks balance the load of
+                                         many GPUs better; the image does not depend on it */
 } pbrhip_render_desc;
 
 #define PBRHIP_RENDER_STATS 1u   /* count BVH nodes / primitives visited (slower; for algorithmic bytes) */

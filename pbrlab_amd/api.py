@@ -43,7 +43,7 @@ class RenderDesc(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("num_sample", C.c_uint32),
                 ("first_pass", C.c_uint32), ("seed_seq", C.c_uint64), ("tile_rank", C.c_uint32),
                 ("tile_world", C.c_uint32), ("max_paths_in_flight", C.c_uint32), ("flags", C.c_uint32),
-                ("num_streams", C.c_uint32), ("tail_paths", C.c_uint32)]
+                ("num_streams", C.c_uint32), ("tail_paths", C.c_uint32), ("shard_block", C.c_uint32)]
 
 
 BVH_HOST_SAH, BVH_GPU_LBVH = 0, 1
@@ -277,7 +277,7 @@ class Scene:
 
 def Render(scene, width, height, num_sample, cancel_render_flag=None, layer=None, finish_pass=None, *,
            first_pass=0, seed_seq=1234567890, tile_rank=0, tile_world=1, max_paths_in_flight=0, flags=0,
-           device_out=None, num_streams=0, tail_paths=0):
+           device_out=None, num_streams=0, tail_paths=0, shard_block=0):
     """pbrlab::Render (src/render.h:14-17).  Resizes and clears `layer`, renders `num_sample` passes, and
     returns (True, stats) -- the reference always returns true (render.cc:240).
 
@@ -287,7 +287,7 @@ def Render(scene, width, height, num_sample, cancel_render_flag=None, layer=None
     nothing is copied to the host (used with torch tensors + RCCL reduce)."""
     L = _lib.lib()
     desc = RenderDesc(width, height, num_sample, first_pass, seed_seq, tile_rank, tile_world, max_paths_in_flight,
-                      flags, num_streams, tail_paths)
+                      flags, num_streams, tail_paths, shard_block)
     st = RenderStats()
     fin = finish_pass if finish_pass is not None else C.c_size_t(0)
     cancel = C.byref(cancel_render_flag) if cancel_render_flag is not None else None

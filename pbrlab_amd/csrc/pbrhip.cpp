@@ -134,7 +134,7 @@ struct pbrhip_scene {
   uint32_t* h_counts = nullptr;  // pinned, kMaxGroups x kCntNum
   std::vector<hipStream_t> group_streams;  // streams of path groups 1.. (group 0 uses `stream`)
   // pixel list cache key
-  uint32_t pk_w = 0, pk_h = 0, pk_rank = 0, pk_world = 0, pk_npix = 0;
+  uint32_t pk_w = 0, pk_h = 0, pk_rank = 0, pk_world = 0, pk_block = 0, pk_npix = 0;
   std::vector<hipEvent_t> events;
 
   size_t device_bytes() const {
@@ -818,21 +818,20 @@ struct Timer {
 };
 }  // namespace
 
-static int ensure_pixels(pbrhip_scene* s, uint32_t w, uint32_t h, uint32_t rank, uint32_t world) {
-  if (s->pk_w == w && s->pk_h == h && s->pk_rank == rank && s->pk_world == world && s->pix_index.p) return PBRHIP_OK;
-  uint32_t nt = 0;
-  pbrhip_create_tiles(w, h, nullptr, &nt);
-  std::vector<uint32_t> tiles(4 * (size_t)nt);
-  pbrhip_create_tiles(w, h, tiles.data(), &nt);
+static int ensure_pixels(pbrhip_scene* s, uint32_t w, uint32_t h, uint32_t rank, uint32_t world, uint32_t block) {
+  if (block == 0) block = 64;  // CreateTiles' tile (pbrhip_create_tiles enumerates the same blocks in the same order)
+  if (s->pk_w == w && s->pk_h == h && s->pk_rank == rank && s->pk_world == world && s->pk_block == block && s->pix_index.p) return PBRHIP_OK;
   std::vector<uint32_t> pix;
-  for (uint32_t t = 0; t < nt; t++) {
-    if (t % world != rank) continue;  // interleaved tile -> GPU map
-    for (uint32_t y = tiles[4 * t + 2]; y < tiles[4 * t + 3]; y++)
-      for (uint32_t x = tiles[4 * t + 0]; x < tiles[4 * t + 1]; x++) pix.push_back(y * w + x);
-  }
+  uint32_t t = 0;
+  for (uint32_t by = 0; by < h; by += block)
+    for (uint32_t bx = 0; bx < w; bx += block, t++) {
+      if (t % world != rank) continue;  // interleaved block -> GPU map
+      for (uint32_t y = by; y < std::min(by + block, h); y++)
+        for (uint32_t x = bx; x < std::min(bx + block, w); x++) pix.push_back(y * w + x);
+    }
   HIPCHK(s->pix_index.upload(pix, s->stream));
   HIPCHK(hipStreamSynchronize(s->stream));
-  s->pk_w = w, s->pk_h = h, s->pk_rank = rank, s->pk_world = world, s->pk_npix = (uint32_t)pix.size();
+  s->pk_w = w, s->pk_h = h, s->pk_rank = rank, s->pk_world = world, s->pk_block = block, s->pk_npix = (uint32_t)pix.size();
   return PBRHIP_OK;
 }
 
@@ -880,7 +879,8 @@ static int render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volat
   if (finish_pass) *finish_pass = 0;
   pbrhip_render_stats S;
   memset(&S, 0, sizeof(S));
-  if (int rc = ensure_pixels(s, d->width, d->height, d->tile_rank, world)) return rc;
+  if (d->shard_block > 4096) return fail(PBRHIP_EINVAL, "shard_block %u is not a sensible block edge", d->shard_block);
+  if (int rc = ensure_pixels(s, d->width, d->height, d->tile_rank, world, d->shard_block)) return rc;
   const uint32_t npix = s->pk_npix;
   const bool want_stats = (d->flags & PBRHIP_RENDER_STATS) != 0;
   if (npix > 0 && d->num_sample > 0) {

@@ -29,3 +29,14 @@ for world in (2, 4, 8):
         _, st = api.Render(s, W, H, SPP * world, tile_rank=0, tile_world=world, device_out=(rgba.data_ptr(), cnt.data_ptr()))
         best = min(best, (time.perf_counter() - t) * 1e3)
     print(f"weak proxy world {world}: rank 0 renders its tiles at {SPP * world} spp in {best:.1f} ms (1-GPU frame {base:.1f} ms)")
+# load balance of the weak-scaling job for different shard blocks: per-rank ms of the 8-rank job at 512 spp
+for block in (64, 32, 16, 8):
+    ts = []
+    for rank in range(8):
+        best = 1e9
+        for rep in range(2):
+            t = time.perf_counter()
+            api.Render(s, W, H, SPP * 8, tile_rank=rank, tile_world=8, device_out=(rgba.data_ptr(), cnt.data_ptr()), shard_block=block)
+            best = min(best, (time.perf_counter() - t) * 1e3)
+        ts.append(best)
+    print(f"shard_block {block}: per-rank ms {[round(x,1) for x in ts]} max {max(ts):.1f} mean {sum(ts)/8:.1f} (imbalance {max(ts)/(sum(ts)/8)-1:.1%})")

@@ -170,6 +170,25 @@ def test_tile_sharding_matches_single(pa, pairs):
     assert acc.tobytes() == full.rgba.tobytes() and np.array_equal(cacc, full.count)
 
 
+@pytest.mark.parametrize("block", [8, 16, 64, 100])
+def test_shard_block_sizes(pa, pairs, block):
+    """pbrhip_render_desc.shard_block: the pixel blocks dealt to ranks can be smaller (or larger) than the reference's 64 x 64
+    tile; every rank's layer is disjoint from the others' and their sum is the one-rank frame, bit for bit"""
+    desc, sg, so = pairs["ggx"]
+    full = pa.RenderLayer()
+    pa.Render(sg, 200, 136, 3, layer=full)
+    for world in (2, 3, 8):
+        acc = np.zeros_like(full.rgba)
+        cnt = np.zeros_like(full.count)
+        for r in range(world):
+            p = pa.RenderLayer()
+            pa.Render(sg, 200, 136, 3, layer=p, tile_rank=r, tile_world=world, shard_block=block)
+            assert not (cnt.astype(bool) & p.count.astype(bool)).any()
+            acc += p.rgba
+            cnt += p.count
+        assert acc.tobytes() == full.rgba.tobytes() and (cnt == 3).all(), (block, world)
+
+
 def test_material_update_and_errors(pa, pairs):
     from pbrlab_amd import scenes
     desc = scenes.cornell_scene("lambert", monkey_subdiv=1, lucy_nu=16, lucy_nv=6)
