@@ -6,13 +6,13 @@ through the whole hot path (camera ray -> GetRadiance bounce loop -> RenderLayer
 materials, light tables) is already resident in HBM when the timed region starts; the step ends with
 the framebuffer on the host of rank 0 (RenderLayer is host memory in pbrlab's API).
 
-N GPUs: one process per GPU (torch.distributed / RCCL).  64x64 tiles are interleaved over the ranks
-(tile i -> rank i % N), every rank renders its tiles into a zero-initialised full-size device
-framebuffer, and ONE RCCL reduce (sum) of rgba + count lands the frame on rank 0.  The frame's sample
-count grows with the node: spp = 64 x N (what more GPUs buy a path tracer is more samples per pixel in the
-same time), so every rank traces the 132.7 M paths of the 1-GPU workload: per-GPU work is fixed =>
-"scaling": "weak".  (Strong scaling of the fixed 64-spp frame is latency-limited -- an 85 ms frame has a
-4 ms serial tail -- and is reported in DESIGN.md from the tile_world proxy, not here.)
+N GPUs: one process per GPU (launched by torch.distributed.run; torch.distributed is used for the rendezvous, the
+barrier and the max-over-ranks of the time).  16x16 pixel blocks are dealt to the ranks (block i -> rank i % N), every
+rank renders its blocks of the SAME 1920x1080 x 64 spp frame into a zeroed full-size device framebuffer ("scaling":
+"strong": BASELINE's metric is this frame at 1/2/4/8 GPUs), and the library's own RCCL communicator (pbrhip_comm_*,
+include/pbrhip.h) lands the frame on rank 0: by default a gather of the ranks' shards (every shard over its own xGMI link;
+--exchange reduce = ncclReduce of the full layers, --exchange torch = torch.distributed.reduce).  The weak-scaling figure
+(spp = 64 x N, per-GPU work fixed) is measured in the same run and reported as the secondary object "weak".
 
   python bench.py --gpus 1 --steps 3 --warmup 1
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -107,8 +107,12 @@ def main():
     ap.add_argument("--streams", type=int, default=0, help="concurrent path groups (0 = the library's default)")
     ap.add_argument("--shard-block", type=int, default=16,
                     help="edge of the pixel blocks dealt to the ranks at N > 1 (the reference's tile is 64; smaller balances better)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="N > 1: weak = spp x N (per-GPU work fixed, default); strong = the fixed 64-spp frame split over N GPUs")
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
+                    help="N > 1: strong = the fixed 64-spp frame split over N GPUs (default: BASELINE's metric); "
+                         "weak = spp x N (per-GPU work fixed).  The other one is reported as a secondary object")
+    ap.add_argument("--exchange", default="gather", choices=["gather", "reduce", "torch"],
+                    help="N > 1: how the RenderLayer reaches rank 0: gather / reduce = RCCL inside libpbrhip "
+                         "(pbrhip_comm_gather_layer / pbrhip_comm_reduce_layer), torch = torch.distributed.reduce")
     args = ap.parse_args()
 
     import numpy as np
@@ -139,7 +143,7 @@ def main():
         w["spp"] = args.spp
     W, H = w["width"], w["height"]
     weak = args.scaling == "weak"
-    spp = w["spp"] * (world if weak else 1)   # weak scaling: per-GPU work fixed (W*H/N pixels x 64*N spp)
+    spp = w["spp"] * (world if weak else 1)   # strong (default): the frame is fixed; weak: W*H/N pixels x 64*N spp per GPU
     desc = make_desc(w)
     scene = pa.scene_from_desc(desc)          # upload + BVH: outside the timed region
     info = scene.info()
@@ -153,11 +157,33 @@ def main():
 
     shard_block = args.shard_block if world > 1 else 0   # one rank: the library's default order (64 x 64 tiles)
 
-    def step(flags=0):
+    # the exchange step: the library's RCCL communicator (one rank makes the id, torch.distributed hands it round)
+    comm, exchange = None, args.exchange
+    if dist is not None and exchange != "torch":
+        try:                                 # every rank checks that the library finds its RCCL before any collective call
+            my_id, usable = pa.Comm.unique_id(), 1
+        except Exception as e:
+            print(f"bench: library communicator unavailable on rank {rank} ({e})", file=sys.stderr)
+            my_id, usable = None, 0
+        flag = torch.tensor([usable], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()):
+            uid = [my_id if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            comm = pa.Comm(uid[0], rank, world)      # ncclCommInitRank: collective
+        else:
+            exchange = "torch"                       # reported in config.exchange
+
+    def step(spp, flags=0):
         _, st = api.Render(scene, W, H, spp, tile_rank=rank, tile_world=world, device_out=ptrs, flags=flags,
                            max_paths_in_flight=args.max_paths, num_streams=args.streams, shard_block=shard_block)
-        if dist is not None:                   # the only exchange step: framebuffer reduce over xGMI
-            reduce_layer(rgba, count, dst=0)
+        if dist is not None:                   # the only exchange step: the framebuffer, over xGMI
+            if exchange == "gather":
+                comm.gather_layer(scene, W, H, ptrs[0], ptrs[1], shard_block=shard_block, root=0)
+            elif exchange == "reduce":
+                comm.reduce_layer(ptrs[0], ptrs[1], W * H, root=0)
+            else:
+                reduce_layer(rgba, count, dst=0)
         if rank == 0:                          # RenderLayer lives on the host
             h_rgba.copy_(rgba, non_blocking=True)
             h_count.copy_(count, non_blocking=True)
@@ -169,26 +195,34 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    agg = {}
-    for _ in range(args.steps):
-        st = step(flags=0 if args.no_roofline else api.RENDER_TIMING)
-        for k, v in st.items():
-            agg[k] = agg.get(k, 0) + v
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed(spp, steps, warmup, flags):
+        for _ in range(warmup):
+            step(spp)
+        barrier()
+        t0 = time.perf_counter()
+        agg = {}
+        for _ in range(steps):
+            st = step(spp, flags=flags)
+            for k, v in st.items():
+                agg[k] = agg.get(k, 0) + v
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        if rank == 0:   # sanity: every pixel got spp samples
+            assert int(h_count.min()) == spp and int(h_count.max()) == spp, "framebuffer incomplete"
+            assert bool(torch.isfinite(h_rgba).all())
+        return elapsed, agg
 
-    # sanity: every pixel got spp samples
-    if rank == 0:
-        assert int(h_count.min()) == spp and int(h_count.max()) == spp, "framebuffer incomplete"
-        assert bool(torch.isfinite(h_rgba).all())
+    elapsed, agg = timed(spp, args.steps, args.warmup, 0 if args.no_roofline else api.RENDER_TIMING)
+    other = None
+    if world > 1:   # the other scaling mode, same run, as a secondary figure
+        o_spp = w["spp"] * (1 if weak else world)
+        o_elapsed, _ = timed(o_spp, args.steps, 1, 0)
+        other = {"scaling": "strong" if weak else "weak", "spp": o_spp, "ms_per_step": o_elapsed / args.steps * 1e3,
+                 "value": W * H * o_spp * args.steps / o_elapsed / 1e6, "unit": "Msamples/s"}
 
     roofline = None
     if not args.no_roofline:
@@ -238,13 +272,20 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": w["desc"] + (f" x {world} (spp scaled with the GPU count)" if (world > 1 and weak) else ""), "width": W, "height": H, "spp": spp,
+                       "exchange": None if world == 1 else {"gather": "pbrhip_comm_gather_layer (RCCL send/recv of the ranks' shards)",
+                                                            "reduce": "pbrhip_comm_reduce_layer (ncclReduce f32 + u32)",
+                                                            "torch": "torch.distributed.reduce"}[exchange],
                        "triangles": desc.num_triangles(), "curve_segments": desc.num_segments(),
                        "bvh_nodes": info["num_nodes"], "bvh_depth": info["depth"], "scene_bytes": info["device_bytes"],
                        "parallelism": f"{shard_block}x{shard_block} pixel blocks, block index % {world}" if world > 1 else "1gpu",
                        "rng": "PCG32((pass<<32)+pixel, 1234567890)"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if other is not None:
+            out["weak" if not weak else "strong"] = other
         print(json.dumps(out))
+    if comm is not None:
+        comm.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -30,6 +30,8 @@ extern "C" {
 #define PBRHIP_EUNSUPPORTED (-5)
 #define PBRHIP_ESTATE (-6)    /* scene not committed / already committed */
 #define PBRHIP_EOVERFLOW (-7) /* traversal stack overflow (BVH deeper than the kernel supports) */
+#define PBRHIP_ENOMEM (-8)    /* host allocation failed (std::bad_alloc) */
+#define PBRHIP_ECOMM (-9)     /* RCCL is unavailable or one of its calls failed */
 
 #define PBRHIP_NONE 0xFFFFFFFFu
 
@@ -78,7 +80,8 @@ typedef struct {
   uint32_t tile_rank, tile_world;     /* 64x64 tiles (render.cc:107-108) with index % world == rank */
   uint32_t max_paths_in_flight;       /* 0 = default (half of the free HBM, <= 256 Mi): passes are rendered in chunks of this many paths */
   uint32_t flags;                     /* PBRHIP_RENDER_* */
-  uint32_t num_streams;               /* concurrent path groups, one HIP stream each (0 = default: 2 when a chunk holds >= 16 Mi paths, else 1; max 8) */
+  uint32_t num_streams;               /* 0 = default: the passes of a chunk are split into path groups of geometrically shrinking size that run as a
+                                         pipeline (one HIP stream each; pbrhip.cpp::plan_groups); n > 0: n equal groups, all started at once (max 16) */
   uint32_t tail_paths;                /* once a group has at most this many live paths, the rest of every path runs in ONE launch
                                          (k_tail) instead of one set of launches per bounce; 0 = default 262144, 0xFFFFFFFF = never */
   uint32_t shard_block;               /* edge of the square pixel blocks dealt to ranks (block index % tile_world == tile_rank);
@@ -104,6 +107,7 @@ typedef struct {
   uint64_t pruned_rays; /* PBRHIP_RENDER_STATS: closest-hit rays of the reference that were never traced: the path's next
                            Russian roulette was already known to fail and the ray cannot reach an area light (it misses every
                            light primitive, or the bounding box of every light), so nothing it could find changes the image (closest + tail_closest + pruned = the reference's count) */
+  uint64_t passes_done; /* passes every pixel of this rank holds when the call returns (= num_sample unless cancelled) */
 } pbrhip_render_stats;
 
 const char* pbrhip_last_error(void);
@@ -175,15 +179,58 @@ int pbrhip_scene_info(const pbrhip_scene*, uint64_t* num_nodes, uint64_t* num_sl
 
 /* ---- the hot path ---- */
 /* pbrlab::Render (src/render.h:14-17, render.cc:192-241).  Blocking.  rgba: width*height*4 floats (sum of
- * radiance, A = sample count), count: width*height (RenderLayer, render-layer.h:11-26).  *cancel is polled
- * between chunks of passes; *finish_pass is advanced as passes complete (monotone, render.cc:224-231).
+ * radiance, A = sample count), count: width*height (RenderLayer, render-layer.h:11-26).
+ *
+ * cancel: NULL or the address of a byte another thread may set non-zero while the call runs -- the object
+ * representation of the reference's `const std::atomic_bool& cancel_render_flag` (a lock-free byte).  It is read live
+ * at every host round trip of the render loop (once per wavefront iteration of a path group, i.e. every few
+ * milliseconds at most; the reference polls before every tile job, render.cc:217).  A cancelled call drains what is in
+ * flight, drops the passes that are not complete and returns PBRHIP_OK with a consistent layer: every pixel of this rank
+ * holds exactly *finish_pass passes.
+ * finish_pass: NULL or a size_t (the reference's std::atomic_size_t, render.cc:224-231) that is stored to (atomically,
+ * monotone) while the call runs, each time a further group of passes is complete for every pixel.
  * Per-sample RNG: RNG((pass << 32) + y*width + x, seed_seq). */
-int pbrhip_render(pbrhip_scene*, const pbrhip_render_desc*, const volatile int* cancel, float* rgba, uint32_t* count,
-                  size_t* finish_pass, pbrhip_render_stats* stats);
-/* Same, writing into DEVICE buffers owned by the caller (e.g. a torch tensor that is then reduced over RCCL):
+int pbrhip_render(pbrhip_scene*, const pbrhip_render_desc*, const volatile unsigned char* cancel, float* rgba,
+                  uint32_t* count, size_t* finish_pass, pbrhip_render_stats* stats);
+/* Same, writing into DEVICE buffers owned by the caller (e.g. a torch tensor that is then exchanged over RCCL):
  * d_rgba / d_count are device pointers on the scene's device; nothing is copied to the host. */
-int pbrhip_render_device(pbrhip_scene*, const pbrhip_render_desc*, const volatile int* cancel, float* d_rgba,
+int pbrhip_render_device(pbrhip_scene*, const pbrhip_render_desc*, const volatile unsigned char* cancel, float* d_rgba,
                          uint32_t* d_count, size_t* finish_pass, pbrhip_render_stats* stats);
+
+/* ---- multi-GPU (new: the reference has one process and std::threads, render.cc:203-238) ----
+ * Pixels are independent, so the only exchange is the RenderLayer at the end of a frame: rank r renders the pixel blocks
+ * with index % world == r (pbrhip_render_desc.tile_rank / tile_world / shard_block) into a zeroed full-size layer, then the
+ * layers are combined on one rank.  Disjoint blocks + zeros: the combined frame is bit-identical to the one-GPU frame. */
+
+/* (1) one process, several GPUs: scenes[i] is a committed copy of the same scene on its own device (pbrhip_scene_replicate;
+ * several scenes may share a device).  One host thread per scene renders rank desc->tile_rank * n + i of
+ * desc->tile_world * n; the shards are then copied device-to-device (xGMI peer copies: only the blocks a rank rendered
+ * travel) into scenes[0]'s layer and from there to the host.  cancel / finish_pass as in pbrhip_render (*finish_pass = the
+ * passes complete on EVERY device); stats: NULL or n records. */
+int pbrhip_render_multi(pbrhip_scene* const* scenes, uint32_t n, const pbrhip_render_desc*,
+                        const volatile unsigned char* cancel, float* rgba, uint32_t* count, size_t* finish_pass,
+                        pbrhip_render_stats* stats);
+/* A committed scene's copy on another device (device memory is copied device-to-device: no second ingestion, no second
+ * BVH build); what `pbrlab-hip-cli --gpus N` calls per extra GPU. */
+int pbrhip_scene_replicate(const pbrhip_scene* src, int device, pbrhip_scene** out);
+
+/* (2) one process per GPU (torch.distributed / MPI launchers): an RCCL communicator inside the library.
+ * pbrhip_comm_unique_id: ncclGetUniqueId on one rank; the launcher hands the 128 bytes to every rank.
+ * pbrhip_comm_create: ncclCommInitRank on the device selected with pbrhip_set_device (collective: every rank calls it). */
+#define PBRHIP_COMM_ID_BYTES 128
+typedef struct pbrhip_comm pbrhip_comm;
+int pbrhip_comm_unique_id(unsigned char id[PBRHIP_COMM_ID_BYTES]);
+int pbrhip_comm_create(pbrhip_comm** out, const unsigned char id[PBRHIP_COMM_ID_BYTES], int rank, int world);
+int pbrhip_comm_destroy(pbrhip_comm*);
+/* ncclReduce(sum) of rgba (f32) and count (u32) to `root`, in place, in one RCCL group: what SURVEY 8e specifies.  Works
+ * for any layers (e.g. different passes of the same pixels on different ranks).  Blocking. */
+int pbrhip_comm_reduce_layer(pbrhip_comm*, float* d_rgba, uint32_t* d_count, size_t num_pixels, int root);
+/* The same result for layers rendered with (tile_rank, tile_world) = (rank, world) of the communicator and `desc`'s
+ * width / height / shard_block: a reduce whose zero terms do not travel.  Every rank packs the pixels of its own blocks
+ * (20 bytes per pixel) and sends them straight to `root` (ncclSend / ncclRecv in one group: xGMI is point-to-point, so
+ * the N - 1 shards arrive over N - 1 different links at once), root scatters them into its layer.  Blocking. */
+int pbrhip_comm_gather_layer(pbrhip_comm*, pbrhip_scene*, const pbrhip_render_desc* desc, float* d_rgba,
+                             uint32_t* d_count, int root);
 
 /* Raytracer::FirstHitTrace1 / AnyHit1 (src/raytracer/raytracer.h:95-111, raytracer_impl.cc:268-287) over an
  * array of rays: test hooks for hit-index parity */

@@ -8,12 +8,15 @@
 #define PBRLAB_HIP_HPP_
 
 #include <atomic>
+#include <chrono>
 #include <cstddef>
 #include <cstdint>
 #include <iostream>
+#include <memory>
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "pbrhip.h"
@@ -145,16 +148,54 @@ public:
 
   pbrhip_scene* handle() const { return h_; }
 
+  // A copy of this committed scene on another GPU (device memory is copied device-to-device: no second ingestion or
+  // BVH build); for the multi-GPU Render() overload below.
+  std::unique_ptr<Scene> Replicate(int device) const {
+    pbrhip_scene* h = nullptr;
+    Check(pbrhip_scene_replicate(h_, device, &h));
+    return std::unique_ptr<Scene>(new Scene(h));
+  }
+
 private:
+  explicit Scene(pbrhip_scene* h) : h_(h) {}
   static void Check(int rc) {
     if (rc != PBRHIP_OK) throw std::runtime_error(pbrhip_last_error());
   }
   pbrhip_scene* h_ = nullptr;
 };
 
-// src/render.h:14-17.  Blocking; clears and resizes *layer; polls cancel_render_flag between chunks of
-// passes; *finish_pass ends at the number of completed passes.  Returns true like the reference
-// (render.cc:240); a library error is reported on std::cerr and returns false.
+namespace detail {
+static_assert(sizeof(std::atomic_bool) == 1 && sizeof(std::atomic_size_t) == sizeof(size_t),
+              "the library reads std::atomic_bool as a byte and stores std::atomic_size_t as a size_t");
+// While the library renders, a watcher prints "finish pass N" as *finish_pass advances (render.cc:229 prints from the
+// worker that completes a pass).
+struct ProgressPrinter {
+  explicit ProgressPrinter(const std::atomic_size_t* fin) : fin_(fin) {
+    if (fin_) th_ = std::thread([this]() {
+      size_t shown = 0;
+      for (;;) {
+        const bool last = stop_.load();
+        for (const size_t now = fin_->load(); shown < now;) printf("finish pass %lu\n", (unsigned long)++shown);
+        if (last) return;
+        std::this_thread::sleep_for(std::chrono::milliseconds(2));
+      }
+    });
+  }
+  ~ProgressPrinter() {
+    stop_.store(true);
+    if (th_.joinable()) th_.join();
+  }
+  const std::atomic_size_t* fin_;
+  std::atomic_bool stop_{false};
+  std::thread th_;
+};
+}  // namespace detail
+
+// src/render.h:14-17.  Blocking; clears and resizes *layer.  cancel_render_flag is read live by the library (at every
+// host round trip of its render loop; the reference polls it before every tile job, render.cc:217): setting it from
+// another thread ends the call early with the completed passes in *layer.  *finish_pass advances while the call runs
+// (render.cc:224-231).  Returns true like the reference (render.cc:240); a library error is reported on std::cerr and
+// returns false.
 inline bool Render(const Scene& scene, const uint32_t width, const uint32_t height, const uint32_t num_sample,
                    const std::atomic_bool& cancel_render_flag, RenderLayer* layer, std::atomic_size_t* finish_pass) {
   layer->Resize(width, height);  // PrepareRendering, render.cc:99-100 (the library clears)
@@ -162,16 +203,47 @@ inline bool Render(const Scene& scene, const uint32_t width, const uint32_t heig
   d.width = width, d.height = height, d.num_sample = num_sample;
   d.seed_seq = 1234567890;  // render.cc:215
   d.tile_world = 1;
-  // std::atomic_bool has no portable int view: mirror it into a volatile int around the call
-  volatile int cancel = cancel_render_flag.load() ? 1 : 0;
-  size_t fin = 0;
-  const int rc = pbrhip_render(scene.handle(), &d, &cancel, layer->rgba.data(), layer->count.data(), &fin, nullptr);
-  if (finish_pass) *finish_pass = fin;
+  std::atomic_size_t local_fin(0);
+  std::atomic_size_t* fin = finish_pass ? finish_pass : &local_fin;
+  int rc;
+  {
+    detail::ProgressPrinter progress(fin);
+    rc = pbrhip_render(scene.handle(), &d, reinterpret_cast<const volatile unsigned char*>(&cancel_render_flag),
+                       layer->rgba.data(), layer->count.data(), reinterpret_cast<size_t*>(fin), nullptr);
+  }
   if (rc != PBRHIP_OK) {
     std::cerr << "pbrlab::Render: " << pbrhip_last_error() << std::endl;
     return false;
   }
-  for (size_t p = 1; p <= fin; ++p) printf("finish pass %lu\n", (unsigned long)p);  // render.cc:229
+  return true;
+}
+
+// The same frame over several GPUs of this process: `scenes` = the committed scene and its replicas
+// (Scene::Replicate), one per device.  Pixel blocks are dealt to the devices, the shards are gathered device-to-device
+// over xGMI inside the library (pbrhip_render_multi); the image is bit-identical to the one-GPU frame.
+inline bool Render(const std::vector<const Scene*>& scenes, const uint32_t width, const uint32_t height,
+                   const uint32_t num_sample, const std::atomic_bool& cancel_render_flag, RenderLayer* layer,
+                   std::atomic_size_t* finish_pass) {
+  layer->Resize(width, height);
+  pbrhip_render_desc d = {};
+  d.width = width, d.height = height, d.num_sample = num_sample;
+  d.seed_seq = 1234567890;
+  d.tile_world = 1;
+  std::vector<pbrhip_scene*> hs;
+  for (const Scene* s : scenes) hs.push_back(s->handle());
+  std::atomic_size_t local_fin(0);
+  std::atomic_size_t* fin = finish_pass ? finish_pass : &local_fin;
+  int rc;
+  {
+    detail::ProgressPrinter progress(fin);
+    rc = pbrhip_render_multi(hs.data(), uint32_t(hs.size()), &d,
+                             reinterpret_cast<const volatile unsigned char*>(&cancel_render_flag), layer->rgba.data(),
+                             layer->count.data(), reinterpret_cast<size_t*>(fin), nullptr);
+  }
+  if (rc != PBRHIP_OK) {
+    std::cerr << "pbrlab::Render: " << pbrhip_last_error() << std::endl;
+    return false;
+  }
   return true;
 }
 

@@ -57,7 +57,7 @@ class RenderStats(C.Structure):
                                            "ms_shade_hair", "ms_sss_step", "ms_tail", "ms_accumulate", "ms_compact")] +
                 [(n, C.c_uint64) for n in ("n_trace_closest", "n_tail", "n_surface", "n_shade_principled",
                                            "n_shade_hair", "n_sss_step")] + [("ms_total", C.c_double)] +
-                [(n, C.c_uint64) for n in ("tail_closest_rays", "tail_shadow_rays", "pruned_rays")])
+                [(n, C.c_uint64) for n in ("tail_closest_rays", "tail_shadow_rays", "pruned_rays", "passes_done")])
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -281,8 +281,9 @@ def Render(scene, width, height, num_sample, cancel_render_flag=None, layer=None
     """pbrlab::Render (src/render.h:14-17).  Resizes and clears `layer`, renders `num_sample` passes, and
     returns (True, stats) -- the reference always returns true (render.cc:240).
 
-    cancel_render_flag: optional ctypes.c_int polled between chunks of passes.
-    finish_pass: optional ctypes.c_size_t advanced as passes complete.
+    cancel_render_flag: optional ctypes.c_ubyte (the byte of the reference's std::atomic_bool) another thread may set
+    while the call runs; it is read at every host round trip of the render loop.
+    finish_pass: optional ctypes.c_size_t, stored to while the call runs as groups of passes complete.
     device_out: optional (rgba_ptr, count_ptr) DEVICE pointers (ints); then the layer is not touched and
     nothing is copied to the host (used with torch tensors + RCCL reduce)."""
     L = _lib.lib()
@@ -302,6 +303,75 @@ def Render(scene, width, height, num_sample, cancel_render_flag=None, layer=None
     _chk(L.pbrhip_render(scene.h, C.byref(desc), cancel, _ptr(layer.rgba), _ptr(layer.count, u32p), C.byref(fin),
                          C.byref(st)))
     return True, st.as_dict()
+
+
+def _desc(width, height, num_sample, first_pass=0, seed_seq=1234567890, tile_rank=0, tile_world=1,
+          max_paths_in_flight=0, flags=0, num_streams=0, tail_paths=0, shard_block=0):
+    return RenderDesc(width, height, num_sample, first_pass, seed_seq, tile_rank, tile_world, max_paths_in_flight,
+                      flags, num_streams, tail_paths, shard_block)
+
+
+def replicate(scene, device):
+    """pbrhip_scene_replicate: a committed scene's copy on `device` (device-to-device, no second BVH build)."""
+    out = Scene.__new__(Scene)
+    out.L = _lib.lib()
+    h = C.c_void_p()
+    _chk(out.L.pbrhip_scene_replicate(scene.h, int(device), C.byref(h)))
+    out.h = h
+    return out
+
+
+def RenderMulti(scenes, width, height, num_sample, cancel_render_flag=None, layer=None, finish_pass=None, **kw):
+    """pbrhip_render_multi: one frame over several devices of this process (scenes[i] = the scene on device i);
+    returns (True, [stats per device])."""
+    L = _lib.lib()
+    desc = _desc(width, height, num_sample, **kw)
+    n = len(scenes)
+    hs = (C.c_void_p * n)(*[s.h for s in scenes])
+    st = (RenderStats * n)()
+    fin = finish_pass if finish_pass is not None else C.c_size_t(0)
+    cancel = C.byref(cancel_render_flag) if cancel_render_flag is not None else None
+    if not (desc.flags & RENDER_NO_CLEAR):
+        layer.Resize(width, height)
+    _chk(L.pbrhip_render_multi(hs, n, C.byref(desc), cancel, _ptr(layer.rgba), _ptr(layer.count, u32p), C.byref(fin), st))
+    return True, [x.as_dict() for x in st]
+
+
+class Comm:
+    """pbrhip_comm: the library's RCCL communicator for one-process-per-GPU jobs.  `unique_id()` on one rank, hand the
+    bytes to every rank (e.g. torch.distributed.broadcast_object_list), then Comm(id, rank, world) on every rank."""
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_ubyte * 128)()
+        _chk(_lib.lib().pbrhip_comm_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, uid, rank, world):
+        self.L = _lib.lib()
+        self.rank, self.world = int(rank), int(world)
+        h = C.c_void_p()
+        buf = (C.c_ubyte * 128)(*uid)
+        _chk(self.L.pbrhip_comm_create(C.byref(h), buf, self.rank, self.world))
+        self.h = h
+
+    def reduce_layer(self, rgba_ptr, count_ptr, num_pixels, root=0):
+        _chk(self.L.pbrhip_comm_reduce_layer(self.h, C.c_void_p(rgba_ptr), C.c_void_p(count_ptr), C.c_size_t(num_pixels), int(root)))
+
+    def gather_layer(self, scene, width, height, rgba_ptr, count_ptr, shard_block=0, root=0):
+        desc = _desc(width, height, 0, tile_rank=self.rank, tile_world=self.world, shard_block=shard_block)
+        _chk(self.L.pbrhip_comm_gather_layer(self.h, scene.h, C.byref(desc), C.c_void_p(rgba_ptr), C.c_void_p(count_ptr), int(root)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.pbrhip_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def scene_from_desc(desc, bvh_builder=BVH_HOST_SAH):

@@ -4,10 +4,12 @@
 //                  [--gpus N] [--bvh host|gpu]
 //
 // Without options it does what the reference binary does: 512 x 512, 32 samples per pixel, "rgba.png" in the current
-// directory = sRGB(rgba / count) quantised as byte(x * 256).  --gpus N renders tile i on GPU i % N (one host thread and
-// one scene copy per GPU; the disjoint per-GPU layers are added on the host).  --bvh gpu builds the acceleration structure
+// directory = sRGB(rgba / count) quantised as byte(x * 256).  --gpus N deals 16 x 16 pixel blocks to N ranks, rank g on
+// GPU g % (GPUs present): one host thread per rank, the scene is ingested once and copied device-to-device, the shards
+// are gathered on the first GPU over xGMI inside the library (pbrhip_render_multi).  --bvh gpu builds the acceleration structure
 // on the GPU (faster commit, slightly slower traversal, same image).
 #include <atomic>
+#include <cerrno>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -35,11 +37,23 @@ int main(int argc, char** argv) {
       }
       return argv[++i];
     };
-    if (a == "--width") width = size_t(atol(value("--width")));
-    else if (a == "--height") height = size_t(atol(value("--height")));
-    else if (a == "--spp") samples = size_t(atol(value("--spp")));
+    // a positive integer that fits the library's uint32_t fields
+    auto number = [&](const char* name, unsigned long max) -> size_t {
+      const char* v = value(name);
+      char* end = nullptr;
+      errno = 0;
+      const unsigned long n = strtoul(v, &end, 10);
+      if (errno || end == v || *end || v[0] == '-' || n == 0 || n > max) {
+        std::cerr << name << " needs an integer in 1.." << max << ", got '" << v << "'" << std::endl;
+        exit(EXIT_FAILURE);
+      }
+      return size_t(n);
+    };
+    if (a == "--width") width = number("--width", 0xFFFFFFFFul);
+    else if (a == "--height") height = number("--height", 0xFFFFFFFFul);
+    else if (a == "--spp") samples = number("--spp", 0xFFFFFFFFul);
     else if (a == "--out") out = value("--out");
-    else if (a == "--gpus") gpus = atoi(value("--gpus"));
+    else if (a == "--gpus") gpus = int(number("--gpus", 1024));
     else if (a == "--bvh") bvh = std::string(value("--bvh")) == "gpu" ? PBRHIP_BVH_GPU_LBVH : PBRHIP_BVH_HOST_SAH;
     else files.push_back(argv[i]);
   }
@@ -47,8 +61,8 @@ int main(int argc, char** argv) {
     std::cerr << "not specified obj filename" << std::endl;
     return EXIT_FAILURE;
   }
-  if (width == 0 || height == 0 || samples == 0 || gpus < 1) {
-    std::cerr << "width, height, spp and gpus must be positive" << std::endl;
+  if (uint64_t(width) * uint64_t(height) >= (1ull << 32)) {
+    std::cerr << "width x height must stay below 2^32 pixels" << std::endl;
     return EXIT_FAILURE;
   }
   int ndev = 0;
@@ -57,60 +71,33 @@ int main(int argc, char** argv) {
     return EXIT_FAILURE;
   }
 
+  // the scene is ingested and its BVH built once; the other GPUs get device-to-device copies
   pbrlab::RenderLayer layer;
+  pbrlab::Scene scene;
+  pbrhip_scene_set_bvh_builder(scene.handle(), bvh);
+  if (pbrio_create_scene(int(files.size()), files.data(), scene.handle()) != PBRHIP_OK) {
+    std::cerr << "scene: " << pbrio_last_error() << std::endl;
+    return EXIT_FAILURE;
+  }
+  std::atomic_bool cancel_render_flag(false);
+  std::atomic_size_t finish_pass(0);
   if (gpus == 1) {
-    pbrlab::Scene scene;
-    pbrhip_scene_set_bvh_builder(scene.handle(), bvh);
-    if (pbrio_create_scene(int(files.size()), files.data(), scene.handle()) != PBRHIP_OK) {
-      std::cerr << "scene: " << pbrio_last_error() << std::endl;
-      return EXIT_FAILURE;
-    }
-    std::atomic_bool cancel_render_flag(false);
-    std::atomic_size_t finish_pass(0);
     if (!pbrlab::Render(scene, uint32_t(width), uint32_t(height), uint32_t(samples), cancel_render_flag, &layer, &finish_pass))
       return EXIT_FAILURE;
   } else {
-    layer.Resize(width, height);
-    layer.Clear();
-    const size_t ng = size_t(gpus);
-    std::vector<pbrlab::RenderLayer> parts(ng);
-    std::vector<std::unique_ptr<pbrlab::Scene>> scenes;
-    for (int g = 0; g < gpus; ++g) {  // ingestion is repeated per GPU: each device holds its own copy of the scene
-      pbrhip_set_device(g % ndev);
-      scenes.emplace_back(new pbrlab::Scene());
-      pbrhip_scene_set_bvh_builder(scenes.back()->handle(), bvh);
-      if (pbrio_create_scene(int(files.size()), files.data(), scenes.back()->handle()) != PBRHIP_OK) {
-        std::cerr << "scene: " << pbrio_last_error() << std::endl;
-        return EXIT_FAILURE;
+    std::vector<std::unique_ptr<pbrlab::Scene>> replicas;
+    std::vector<const pbrlab::Scene*> scenes{&scene};
+    try {
+      for (int g = 1; g < gpus; ++g) {  // rank g renders on GPU g % ndev
+        replicas.push_back(scene.Replicate(g % ndev));
+        scenes.push_back(replicas.back().get());
       }
+    } catch (const std::exception& e) {
+      std::cerr << "scene copy: " << e.what() << std::endl;
+      return EXIT_FAILURE;
     }
-    std::vector<int> rc(ng, PBRHIP_OK);
-    std::vector<std::string> msg(ng);
-    std::vector<std::thread> workers;
-    for (int g = 0; g < gpus; ++g) {
-      workers.emplace_back([&, g]() {
-        parts[size_t(g)].Resize(width, height);
-        pbrhip_render_desc d = {};
-        d.width = uint32_t(width), d.height = uint32_t(height), d.num_sample = uint32_t(samples);
-        d.seed_seq = 1234567890;
-        d.tile_rank = uint32_t(g), d.tile_world = uint32_t(gpus);
-        d.shard_block = 16;  // finer than the 64 x 64 tile: evens out the load of the GPUs (the image does not depend on it)
-        size_t fin = 0;
-        rc[size_t(g)] = pbrhip_render(scenes[size_t(g)]->handle(), &d, nullptr, parts[size_t(g)].rgba.data(),
-                                      parts[size_t(g)].count.data(), &fin, nullptr);
-        if (rc[size_t(g)] != PBRHIP_OK) msg[size_t(g)] = pbrhip_last_error();
-      });
-    }
-    for (std::thread& t : workers) t.join();
-    for (int g = 0; g < gpus; ++g) {
-      if (rc[size_t(g)] != PBRHIP_OK) {
-        std::cerr << "render on GPU " << g % ndev << ": " << msg[size_t(g)] << std::endl;
-        return EXIT_FAILURE;
-      }
-      for (size_t i = 0; i < layer.rgba.size(); ++i) layer.rgba[i] += parts[size_t(g)].rgba[i];  // disjoint tiles + zeros
-      for (size_t i = 0; i < layer.count.size(); ++i) layer.count[i] += parts[size_t(g)].count[i];
-    }
-    for (size_t p = 1; p <= samples; ++p) printf("finish pass %lu\n", (unsigned long)p);
+    if (!pbrlab::Render(scenes, uint32_t(width), uint32_t(height), uint32_t(samples), cancel_render_flag, &layer, &finish_pass))
+      return EXIT_FAILURE;
   }
 
   const size_t slash = out.find_last_of('/');

@@ -84,6 +84,9 @@ void launch_sss_step(hipStream_t s, const PathState& P, const DScene& sc, uint32
 void launch_accumulate(hipStream_t s, const PathState& P, const uint32_t* pix_index, uint32_t npix, uint32_t npass,
                        float* rgba, uint32_t* count);
 void launch_advance(hipStream_t s, const PathState& P);
+// RenderLayer shard of a pixel list: shard = npix x rgba (16 B) followed by npix x count (4 B); 16-byte aligned
+void launch_layer_pack(hipStream_t s, const uint32_t* pix, uint32_t npix, const float* rgba, const uint32_t* count, float* shard);
+void launch_layer_unpack_add(hipStream_t s, const uint32_t* pix, uint32_t npix, const float* shard, float* rgba, uint32_t* count);
 void launch_hook_closest(hipStream_t s, const DScene& sc, const float4* rays, uint32_t n, HookHit* out, uint32_t* counts,
                          uint32_t* spill, bool simple);
 void launch_hook_any(hipStream_t s, const DScene& sc, const float4* rays, uint32_t n, uint8_t* out, uint32_t* counts,

@@ -855,6 +855,30 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(PathState P, const uint32
   }
 }
 
+// ------------------------------------------------------------------ RenderLayer shards (multi-GPU exchange, multi.cpp)
+// A rank's share of the frame is the pixel list `pix` (the blocks dealt to it).  pack: shard = [rgba of every listed
+// pixel | count of every listed pixel]; unpack_add: layer[pix[i]] += shard[i] (the receiving layer holds zeros there, so
+// this is the reduce(sum) of SURVEY 8e restricted to the terms that are not zero by construction).
+__global__ __launch_bounds__(kBlock) void k_layer_pack(const uint32_t* __restrict__ pix, uint32_t npix,
+                                                       const float4* __restrict__ rgba, const uint32_t* __restrict__ count,
+                                                       float4* __restrict__ out_rgba, uint32_t* __restrict__ out_count) {
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < npix; i += gridDim.x * kBlock) {
+    const uint32_t g = pix[i];
+    out_rgba[i] = rgba[g];
+    out_count[i] = count[g];
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_layer_unpack_add(const uint32_t* __restrict__ pix, uint32_t npix,
+                                                             const float4* __restrict__ in_rgba, const uint32_t* __restrict__ in_count,
+                                                             float4* __restrict__ rgba, uint32_t* __restrict__ count) {
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < npix; i += gridDim.x * kBlock) {
+    const uint32_t g = pix[i];
+    const float4 a = rgba[g], b = in_rgba[i];
+    rgba[g] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    count[g] += in_count[i];
+  }
+}
+
 // ------------------------------------------------------------------ test hooks: Raytracer::FirstHitTrace1 / AnyHit1
 // Same persistent phase-voting traversal as the render path, fed from a caller-supplied ray array.
 __device__ __forceinline__ HookHit hook_result(const DScene& sc, V3 o, V3 d, const Hit& h) {
@@ -998,6 +1022,17 @@ void launch_tail(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n
   else if (stats) hipLaunchKernelGGL((k_tail<false, true>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
   else if (curves) hipLaunchKernelGGL((k_tail<true, false>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
   else hipLaunchKernelGGL((k_tail<false, false>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
+}
+void launch_layer_pack(hipStream_t s, const uint32_t* pix, uint32_t npix, const float* rgba, const uint32_t* count, float* shard) {
+  if (!npix) return;
+  hipLaunchKernelGGL(k_layer_pack, dim3(grid_for(npix, 8192)), dim3(kBlock), 0, s, pix, npix, reinterpret_cast<const float4*>(rgba),
+                     count, reinterpret_cast<float4*>(shard), reinterpret_cast<uint32_t*>(shard + 4 * (size_t)npix));
+}
+void launch_layer_unpack_add(hipStream_t s, const uint32_t* pix, uint32_t npix, const float* shard, float* rgba, uint32_t* count) {
+  if (!npix) return;
+  hipLaunchKernelGGL(k_layer_unpack_add, dim3(grid_for(npix, 8192)), dim3(kBlock), 0, s, pix, npix,
+                     reinterpret_cast<const float4*>(shard), reinterpret_cast<const uint32_t*>(shard + 4 * (size_t)npix),
+                     reinterpret_cast<float4*>(rgba), count);
 }
 void launch_advance(hipStream_t s, const PathState& P) { hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, s, P.counts); }
 // counts: kCntNum zeroed words (queue head + overflow flag); spill: traversal-stack spill area

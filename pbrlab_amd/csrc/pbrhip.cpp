@@ -1,7 +1,5 @@
 // pbrhip.cpp -- C ABI (include/pbrhip.h): host scene store, commit (light tables, BVH, upload) and the
 // wavefront render loop that drives kernels.hip.  Host C++ only; device code lives in kernels.hip.
-#include "../../include/pbrhip.h"
-
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdarg.h>
@@ -14,10 +12,10 @@
 #include <memory>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
-#include "host_scene.h"
-#include "kernels.h"
+#include "scene_impl.h"
 
 using namespace pb;
 
@@ -31,7 +29,7 @@ static_assert(sizeof(LightRec) == 80, "light record layout");
 static thread_local std::string g_err;
 static int g_device = 0;
 
-static int fail(int code, const char* fmt, ...) {
+int pb::fail(int code, const char* fmt, ...) {
   char buf[512];
   va_list ap;
   va_start(ap, fmt);
@@ -40,12 +38,7 @@ static int fail(int code, const char* fmt, ...) {
   g_err = buf;
   return code;
 }
-#define HIPCHK(expr)                                                                                      \
-  do {                                                                                                    \
-    hipError_t e_ = (expr);                                                                               \
-    if (e_ != hipSuccess) return fail(PBRHIP_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
-                                      __FILE__, __LINE__);                                                \
-  } while (0)
+int pb::current_device() { return g_device; }
 
 extern "C" const char* pbrhip_last_error(void) { return g_err.c_str(); }
 
@@ -69,82 +62,9 @@ extern "C" int pbrhip_set_device(int device) {
   return PBRHIP_OK;
 }
 
-// ------------------------------------------------------------------ device buffers
-template <typename T>
-struct DevBuf {
-  T* p = nullptr;
-  size_t n = 0;
-  ~DevBuf() { release(); }
-  void release() {
-    if (p) (void)hipFree(p);
-    p = nullptr, n = 0;
-  }
-  hipError_t reserve(size_t count) {
-    if (count <= n) return hipSuccess;
-    release();
-    hipError_t e = hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T));
-    if (e == hipSuccess) n = count;
-    return e;
-  }
-  hipError_t upload(const std::vector<T>& h, hipStream_t s) {
-    hipError_t e = reserve(h.size());
-    if (e != hipSuccess || h.empty()) return e;
-    return hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s);
-  }
-};
-
-struct pbrhip_scene {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  // host model
-  std::vector<HostMesh> meshes;
-  std::vector<std::vector<uint32_t>> locals;
-  std::vector<HostInstance> instances;
-  std::vector<HostMaterial> materials;
-  std::vector<V3> light_params;
-  std::vector<TexDesc> tex_descs;      // Scene::AddTexture
-  std::vector<float> tex_pixels;
-  std::vector<HostLight> lights;
-  std::vector<float> light_cdf;
-  bool committed = false, has_hair = false, has_sss = false;
-  float bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0};
-  uint32_t bvh_depth = 0;
-  int bvh_builder = PBRHIP_BVH_HOST_SAH;
-  bool bvh_built_on_gpu = false;
-  // device scene
-  DevBuf<BvhNode> d_nodes;
-  DevBuf<ShadeRec> d_shade;
-  DevBuf<Material> d_materials;
-  DevBuf<float> d_light_cdf, d_lprim_cdf, d_tex_pixels;
-  DevBuf<TexDesc> d_tex_descs;
-  DevBuf<LightHead> d_heads;
-  DevBuf<LightRec> d_lrecs;
-  DevBuf<BvhNode> d_light_boxes;
-  DScene dscene;
-  // render working set (grown on demand, reused across calls)
-  DevBuf<float4> ray_o, ray_d, thr, L, hit, sss[5], sh[3];
-  DevBuf<uint64_t> rng;
-  DevBuf<uint32_t> q[7], counts, pix_index, spill;
-  DevBuf<unsigned long long> stats;
-  DevBuf<float> own_rgba;
-  DevBuf<uint32_t> own_count;
-  DevBuf<float4> hook_rays;
-  DevBuf<HookHit> hook_hits;
-  DevBuf<uint8_t> hook_occ;
-  uint32_t* h_counts = nullptr;  // pinned, kMaxGroups x kCntNum
-  std::vector<hipStream_t> group_streams;  // streams of path groups 1.. (group 0 uses `stream`)
-  // pixel list cache key
-  uint32_t pk_w = 0, pk_h = 0, pk_rank = 0, pk_world = 0, pk_block = 0, pk_npix = 0;
-  std::vector<hipEvent_t> events;
-
-  size_t device_bytes() const {
-    return d_nodes.n * sizeof(BvhNode) + d_shade.n * sizeof(ShadeRec) +
-           d_materials.n * sizeof(Material) + d_lrecs.n * sizeof(LightRec);
-  }
-};
-
 // ------------------------------------------------------------------ scene construction
 extern "C" int pbrhip_scene_create(pbrhip_scene** out) {
+  return guarded([&]() -> int {
   if (!out) return fail(PBRHIP_EINVAL, "out is NULL");
   int n = 0;
   int rc = pbrhip_device_count(&n);
@@ -158,9 +78,11 @@ extern "C" int pbrhip_scene_create(pbrhip_scene** out) {
   memset(&s->dscene, 0, sizeof(s->dscene));
   *out = s.release();
   return PBRHIP_OK;
+  });
 }
 
 extern "C" int pbrhip_scene_destroy(pbrhip_scene* s) {
+  return guarded([&]() -> int {
   if (!s) return PBRHIP_OK;
   (void)hipSetDevice(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
@@ -171,6 +93,7 @@ extern "C" int pbrhip_scene_destroy(pbrhip_scene* s) {
   delete s;
   if (st) (void)hipStreamDestroy(st);
   return PBRHIP_OK;
+  });
 }
 
 extern "C" int pbrhip_scene_add_triangle_mesh(pbrhip_scene* s, const float* vertices_xyzw, uint32_t num_vertices,
@@ -179,6 +102,7 @@ extern "C" int pbrhip_scene_add_triangle_mesh(pbrhip_scene* s, const float* vert
                                               const uint32_t* vertex_ids, const uint32_t* normal_ids,
                                               const uint32_t* texcoord_ids, const uint32_t* material_ids,
                                               uint32_t num_faces, uint32_t* mesh_id) {
+  return guarded([&]() -> int {
   if (!s || !mesh_id || (!vertices_xyzw && num_vertices) || (!vertex_ids && num_faces))
     return fail(PBRHIP_EINVAL, "add_triangle_mesh: NULL argument");
   if (s->committed) return fail(PBRHIP_ESTATE, "scene already committed");
@@ -209,11 +133,13 @@ extern "C" int pbrhip_scene_add_triangle_mesh(pbrhip_scene* s, const float* vert
   *mesh_id = (uint32_t)s->meshes.size();
   s->meshes.push_back(std::move(m));
   return PBRHIP_OK;
+  });
 }
 
 extern "C" int pbrhip_scene_add_curve_mesh(pbrhip_scene* s, const float* vertices_xyzr, uint32_t num_vertices,
                                            const uint32_t* indices, const uint32_t* material_ids,
                                            uint32_t num_segments, uint32_t* mesh_id) {
+  return guarded([&]() -> int {
   if (!s || !mesh_id || (!vertices_xyzr && num_vertices) || (!indices && num_segments))
     return fail(PBRHIP_EINVAL, "add_curve_mesh: NULL argument");
   if (s->committed) return fail(PBRHIP_ESTATE, "scene already committed");
@@ -228,6 +154,7 @@ extern "C" int pbrhip_scene_add_curve_mesh(pbrhip_scene* s, const float* vertice
   *mesh_id = (uint32_t)s->meshes.size();
   s->meshes.push_back(std::move(m));
   return PBRHIP_OK;
+  });
 }
 
 // texture ids are validated at commit (pc/pc-common.cc:116-139 adds materials first, textures after)
@@ -235,6 +162,7 @@ static int check_tex(const pbrhip_principled_param*) { return PBRHIP_OK; }
 // Scene::AddTexture (scene.h:46-51) with Texture(pixels, width, height, channels) (texture.cc:10-21)
 extern "C" int pbrhip_scene_add_texture(pbrhip_scene* s, const float* pixels, uint32_t width, uint32_t height,
                                         uint32_t channels, uint32_t* texture_id) {
+  return guarded([&]() -> int {
   if (!s || !pixels || !texture_id) return fail(PBRHIP_EINVAL, "add_texture: NULL argument");
   if (width == 0 || height == 0 || channels == 0 || channels > 4) return fail(PBRHIP_EINVAL, "add_texture: bad shape");
   if (s->committed) return fail(PBRHIP_ESTATE, "scene already committed");
@@ -245,8 +173,10 @@ extern "C" int pbrhip_scene_add_texture(pbrhip_scene* s, const float* pixels, ui
   *texture_id = (uint32_t)s->tex_descs.size();
   s->tex_descs.push_back(t);
   return PBRHIP_OK;
+  });
 }
 extern "C" int pbrhip_scene_add_principled_material(pbrhip_scene* s, const pbrhip_principled_param* p, uint32_t* id) {
+  return guarded([&]() -> int {
   if (!s || !p || !id) return fail(PBRHIP_EINVAL, "add_principled_material: NULL argument");
   if (int rc = check_tex(p)) return rc;
   HostMaterial m;
@@ -256,8 +186,10 @@ extern "C" int pbrhip_scene_add_principled_material(pbrhip_scene* s, const pbrhi
   *id = (uint32_t)s->materials.size();
   s->materials.push_back(m);
   return PBRHIP_OK;
+  });
 }
 extern "C" int pbrhip_scene_add_hair_material(pbrhip_scene* s, const pbrhip_hair_param* p, uint32_t* id) {
+  return guarded([&]() -> int {
   if (!s || !p || !id) return fail(PBRHIP_EINVAL, "add_hair_material: NULL argument");
   HostMaterial m;
   m.kind = kMatHair;
@@ -266,30 +198,38 @@ extern "C" int pbrhip_scene_add_hair_material(pbrhip_scene* s, const pbrhip_hair
   *id = (uint32_t)s->materials.size();
   s->materials.push_back(m);
   return PBRHIP_OK;
+  });
 }
 extern "C" int pbrhip_scene_add_area_light(pbrhip_scene* s, const float emission[3], uint32_t* id) {
+  return guarded([&]() -> int {
   if (!s || !emission || !id) return fail(PBRHIP_EINVAL, "add_area_light: NULL argument");
   *id = (uint32_t)s->light_params.size();
   s->light_params.push_back(V3(emission[0], emission[1], emission[2]));
   return PBRHIP_OK;
+  });
 }
 extern "C" int pbrhip_scene_create_local_scene(pbrhip_scene* s, uint32_t* id) {
+  return guarded([&]() -> int {
   if (!s || !id) return fail(PBRHIP_EINVAL, "create_local_scene: NULL argument");
   *id = (uint32_t)s->locals.size();
   s->locals.emplace_back();
   return PBRHIP_OK;
+  });
 }
 extern "C" int pbrhip_scene_add_mesh_to_local_scene(pbrhip_scene* s, uint32_t local_scene_id, uint32_t mesh_id,
                                                     uint32_t* geom_id) {
+  return guarded([&]() -> int {
   if (!s || !geom_id) return fail(PBRHIP_EINVAL, "add_mesh_to_local_scene: NULL argument");
   if (local_scene_id >= s->locals.size() || mesh_id >= s->meshes.size())
     return fail(PBRHIP_EINVAL, "local scene %u / mesh %u out of range", local_scene_id, mesh_id);
   *geom_id = (uint32_t)s->locals[local_scene_id].size();
   s->locals[local_scene_id].push_back(mesh_id);
   return PBRHIP_OK;
+  });
 }
 extern "C" int pbrhip_scene_create_instance(pbrhip_scene* s, uint32_t local_scene_id, const float* transform,
                                             uint32_t* instance_id) {
+  return guarded([&]() -> int {
   if (!s || !instance_id) return fail(PBRHIP_EINVAL, "create_instance: NULL argument");
   if (local_scene_id >= s->locals.size()) return fail(PBRHIP_EINVAL, "local scene %u out of range", local_scene_id);
   static const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
@@ -307,6 +247,7 @@ extern "C" int pbrhip_scene_create_instance(pbrhip_scene* s, uint32_t local_scen
   *instance_id = (uint32_t)s->instances.size();
   s->instances.push_back(std::move(in));
   return PBRHIP_OK;
+  });
 }
 static const HostMesh* inst_mesh(const pbrhip_scene* s, uint32_t instance_id, uint32_t geom_id) {
   const HostInstance& in = s->instances[instance_id];
@@ -314,6 +255,7 @@ static const HostMesh* inst_mesh(const pbrhip_scene* s, uint32_t instance_id, ui
 }
 extern "C" int pbrhip_scene_attach_light_ids(pbrhip_scene* s, uint32_t instance_id, uint32_t geom_id,
                                              const uint32_t* ids, uint32_t n) {
+  return guarded([&]() -> int {
   if (!s || (!ids && n)) return fail(PBRHIP_EINVAL, "attach_light_ids: NULL argument");
   if (instance_id >= s->instances.size() || geom_id >= s->instances[instance_id].light_ids.size())
     return fail(PBRHIP_EINVAL, "instance %u / geom %u out of range", instance_id, geom_id);
@@ -322,15 +264,18 @@ extern "C" int pbrhip_scene_attach_light_ids(pbrhip_scene* s, uint32_t instance_
     if (ids[i] != kNone && ids[i] >= s->light_params.size()) return fail(PBRHIP_EINVAL, "light id %u out of range", ids[i]);
   s->instances[instance_id].light_ids[geom_id].assign(ids, ids + n);
   return PBRHIP_OK;
+  });
 }
 extern "C" int pbrhip_scene_attach_material_ids(pbrhip_scene* s, uint32_t instance_id, uint32_t geom_id,
                                                 const uint32_t* ids, uint32_t n) {
+  return guarded([&]() -> int {
   if (!s || (!ids && n)) return fail(PBRHIP_EINVAL, "attach_material_ids: NULL argument");
   if (instance_id >= s->instances.size() || geom_id >= s->instances[instance_id].material_ids.size())
     return fail(PBRHIP_EINVAL, "instance %u / geom %u out of range", instance_id, geom_id);
   if (n != inst_mesh(s, instance_id, geom_id)->num_prims()) return fail(PBRHIP_ESIZE, "material param error");
   s->instances[instance_id].material_ids[geom_id].assign(ids, ids + n);
   return PBRHIP_OK;
+  });
 }
 
 // ------------------------------------------------------------------ commit
@@ -429,6 +374,7 @@ static void curve_piece(const float* cp, uint32_t sub, float a[4], float b[4]) {
 }
 
 extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
+  return guarded([&]() -> int {
   if (!s) return fail(PBRHIP_EINVAL, "scene is NULL");
   HIPCHK(hipSetDevice(s->device));
   for (uint32_t i = 0; i < s->instances.size(); i++) register_lights(s, i);
@@ -664,49 +610,58 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
   for (uint8_t kd : kinds) d.num_curves += kd ? 1u : 0u;
   s->committed = true;
   return PBRHIP_OK;
+  });
 }
 
 extern "C" int pbrhip_scene_set_bvh_builder(pbrhip_scene* s, int builder) {
+  return guarded([&]() -> int {
   if (!s) return fail(PBRHIP_EINVAL, "scene is NULL");
   if (builder != PBRHIP_BVH_HOST_SAH && builder != PBRHIP_BVH_GPU_LBVH) return fail(PBRHIP_EINVAL, "unknown BVH builder %d", builder);
   if (s->committed) return fail(PBRHIP_ESTATE, "scene already committed");
   s->bvh_builder = builder;
   return PBRHIP_OK;
+  });
 }
 
 extern "C" int pbrhip_scene_aabb(const pbrhip_scene* s, float bmin[3], float bmax[3]) {
+  return guarded([&]() -> int {
   if (!s || !bmin || !bmax) return fail(PBRHIP_EINVAL, "scene_aabb: NULL argument");
   if (!s->committed) return fail(PBRHIP_ESTATE, "scene not committed");
   memcpy(bmin, s->bmin, 12), memcpy(bmax, s->bmax, 12);
   return PBRHIP_OK;
+  });
 }
 extern "C" int pbrhip_scene_info(const pbrhip_scene* s, uint64_t* num_nodes, uint64_t* num_slots, uint32_t* depth,
                                  uint64_t* device_bytes) {
+  return guarded([&]() -> int {
   if (!s) return fail(PBRHIP_EINVAL, "scene is NULL");
   if (num_nodes) *num_nodes = s->dscene.num_nodes;
   if (num_slots) *num_slots = s->dscene.num_slots;
   if (depth) *depth = s->bvh_depth;
   if (device_bytes) *device_bytes = s->device_bytes();
   return PBRHIP_OK;
+  });
 }
 
 static int update_material(pbrhip_scene* s, uint32_t id, const HostMaterial& hm) {
+  // validate everything first: a rejected call leaves the host material, has_sss and the device copy as they were
   if (id >= s->materials.size()) return fail(PBRHIP_EINVAL, "material id %u out of range", id);
   if (s->materials[id].kind != hm.kind) return fail(PBRHIP_EINVAL, "material %u is of the other kind", id);
-  s->materials[id] = hm;
+  if (s->committed && hm.kind == kMatPrincipled)
+    for (uint32_t t : {hm.pr.base_color_tex_id, hm.pr.subsurface_color_tex_id})
+      if (t != kNone && t >= s->tex_descs.size()) return fail(PBRHIP_EINVAL, "texture id %u out of range", t);
   if (s->committed) {
     HIPCHK(hipSetDevice(s->device));
-    Material m = make_material(hm);
-    s->has_sss = s->has_sss || (m.kind == kMatPrincipled && (m.bsdf.enable_subsurface || m.textured));
-    if (m.kind == kMatPrincipled)
-      for (uint32_t t : {hm.pr.base_color_tex_id, hm.pr.subsurface_color_tex_id})
-        if (t != kNone && t >= s->tex_descs.size()) return fail(PBRHIP_EINVAL, "texture id %u out of range", t);
+    const Material m = make_material(hm);
     HIPCHK(hipMemcpyAsync(s->d_materials.p + id, &m, sizeof(m), hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
+    s->has_sss = s->has_sss || (m.kind == kMatPrincipled && (m.bsdf.enable_subsurface || m.textured));
   }
+  s->materials[id] = hm;
   return PBRHIP_OK;
 }
 extern "C" int pbrhip_scene_update_principled_material(pbrhip_scene* s, uint32_t id, const pbrhip_principled_param* p) {
+  return guarded([&]() -> int {
   if (!s || !p) return fail(PBRHIP_EINVAL, "update_material: NULL argument");
   if (int rc = check_tex(p)) return rc;
   HostMaterial m;
@@ -714,18 +669,22 @@ extern "C" int pbrhip_scene_update_principled_material(pbrhip_scene* s, uint32_t
   memcpy(&m.pr, p, sizeof(m.pr));
   memset(&m.hr, 0, sizeof(m.hr));
   return update_material(s, id, m);
+  });
 }
 extern "C" int pbrhip_scene_update_hair_material(pbrhip_scene* s, uint32_t id, const pbrhip_hair_param* p) {
+  return guarded([&]() -> int {
   if (!s || !p) return fail(PBRHIP_EINVAL, "update_material: NULL argument");
   HostMaterial m;
   m.kind = kMatHair;
   memset(&m.pr, 0, sizeof(m.pr));
   memcpy(&m.hr, p, sizeof(m.hr));
   return update_material(s, id, m);
+  });
 }
 
 // ------------------------------------------------------------------ tiles (render-tile.cc:29-41)
 extern "C" int pbrhip_create_tiles(uint32_t width, uint32_t height, uint32_t* out, uint32_t* num_tiles) {
+  return guarded([&]() -> int {
   if (!num_tiles) return fail(PBRHIP_EINVAL, "num_tiles is NULL");
   const uint32_t kTile = 64;
   uint32_t n = 0;
@@ -739,6 +698,7 @@ extern "C" int pbrhip_create_tiles(uint32_t width, uint32_t height, uint32_t* ou
     }
   *num_tiles = n;
   return PBRHIP_OK;
+  });
 }
 
 // camera of RenderingTile (render.cc:132-158)
@@ -818,17 +778,23 @@ struct Timer {
 };
 }  // namespace
 
-static int ensure_pixels(pbrhip_scene* s, uint32_t w, uint32_t h, uint32_t rank, uint32_t world, uint32_t block) {
+void pb::shard_pixels(uint32_t w, uint32_t h, uint32_t rank, uint32_t world, uint32_t block, std::vector<uint32_t>* out) {
   if (block == 0) block = 64;  // CreateTiles' tile (pbrhip_create_tiles enumerates the same blocks in the same order)
-  if (s->pk_w == w && s->pk_h == h && s->pk_rank == rank && s->pk_world == world && s->pk_block == block && s->pix_index.p) return PBRHIP_OK;
-  std::vector<uint32_t> pix;
+  out->clear();
   uint32_t t = 0;
   for (uint32_t by = 0; by < h; by += block)
     for (uint32_t bx = 0; bx < w; bx += block, t++) {
       if (t % world != rank) continue;  // interleaved block -> GPU map
       for (uint32_t y = by; y < std::min(by + block, h); y++)
-        for (uint32_t x = bx; x < std::min(bx + block, w); x++) pix.push_back(y * w + x);
+        for (uint32_t x = bx; x < std::min(bx + block, w); x++) out->push_back(y * w + x);
     }
+}
+
+int pb::ensure_pixels(pbrhip_scene* s, uint32_t w, uint32_t h, uint32_t rank, uint32_t world, uint32_t block) {
+  if (block == 0) block = 64;
+  if (s->pk_w == w && s->pk_h == h && s->pk_rank == rank && s->pk_world == world && s->pk_block == block && s->pix_index.p) return PBRHIP_OK;
+  std::vector<uint32_t> pix;
+  shard_pixels(w, h, rank, world, block, &pix);
   HIPCHK(s->pix_index.upload(pix, s->stream));
   HIPCHK(hipStreamSynchronize(s->stream));
   s->pk_w = w, s->pk_h = h, s->pk_rank = rank, s->pk_world = world, s->pk_block = block, s->pk_npix = (uint32_t)pix.size();
@@ -861,14 +827,64 @@ static int ensure_paths(pbrhip_scene* s, size_t n) {
   return PBRHIP_OK;
 }
 
-static int render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile int* cancel, float* d_rgba,
-                       uint32_t* d_count, size_t* finish_pass, pbrhip_render_stats* stats) {
+static uint32_t env_u32(const char* name, uint32_t dflt) {
+  const char* e = getenv(name);
+  return e ? (uint32_t)strtoul(e, nullptr, 10) : dflt;
+}
+
+// How the passes of a chunk are split into path groups (each group = its own queues, counters and HIP stream).
+// The end of every group is latency-bound: a few launch-bound wavefront iterations, then k_tail, whose duration is the
+// dependent chain of the group's longest path (tens of bounces).  Groups therefore run as a pipeline: the first, largest
+// one starts alone; the next one starts as soon as fewer than `window` groups are still in their bulk phase, so one
+// group's tail hides behind the next one's bulk work; sizes shrink geometrically so that the last group -- the only
+// one whose tail nothing can hide -- is small (short bulk, shorter longest path).  Path slots stay global and passes are
+// accumulated in ascending order, so the image does not depend on the split (GPU test).
+static std::vector<uint32_t> plan_groups(uint32_t np, uint32_t npix, uint32_t want_groups) {
+  std::vector<uint32_t> g;
+  if (const char* e = getenv("PBRHIP_GROUPS")) {  // explicit passes per group, e.g. "32,16,8,4,2,1,1" (the rest joins the last)
+    uint32_t left = np;
+    for (const char* p = e; *p && left;) {
+      uint32_t v = (uint32_t)strtoul(p, (char**)&p, 10);
+      if (*p == ',') p++;
+      v = std::max(1u, std::min(v, left));
+      g.push_back(v), left -= v;
+    }
+    if (left) {
+      if (g.empty()) g.push_back(left);
+      else g.back() += left;
+    }
+    return g;
+  }
+  if (want_groups) {  // pbrhip_render_desc.num_streams: that many equal groups
+    const uint32_t ng = std::min(std::min(want_groups, (uint32_t)kMaxGroups * 2u), np);
+    for (uint32_t k = 0; k < ng; k++) g.push_back((uint32_t)((uint64_t)np * (k + 1) / ng) - (uint32_t)((uint64_t)np * k / ng));
+    return g;
+  }
+  // default: halve until a group would hold fewer than min_paths paths
+  const uint64_t min_paths = env_u32("PBRHIP_GROUP_MIN_PATHS", 1u << 20);
+  uint32_t left = np;
+  while (left) {
+    uint32_t v = (left + 1) / 2;
+    if ((uint64_t)v * npix < min_paths || g.size() + 1 >= (size_t)kMaxGroups * 2) v = left;
+    else if ((uint64_t)(left - v) * npix < min_paths) v = left;
+    g.push_back(v), left -= v;
+  }
+  return g;
+}
+
+int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile unsigned char* cancel, float* d_rgba,
+                    uint32_t* d_count, size_t* finish_pass, pbrhip_render_stats* stats) {
   auto t_begin = std::chrono::steady_clock::now();
   if (!s->committed) return fail(PBRHIP_ESTATE, "scene not committed");
   if (d->width == 0 || d->height == 0) return fail(PBRHIP_EINVAL, "empty image");
   if ((uint64_t)d->width * d->height >= (1ull << 32)) return fail(PBRHIP_EINVAL, "image too large");
   uint32_t world = d->tile_world ? d->tile_world : 1;
   if (d->tile_rank >= world) return fail(PBRHIP_EINVAL, "tile_rank %u >= tile_world %u", d->tile_rank, world);
+  if (d->shard_block > 4096) return fail(PBRHIP_EINVAL, "shard_block %u is not a sensible block edge", d->shard_block);
+  auto cancelled = [&]() { return cancel && __atomic_load_n(cancel, __ATOMIC_RELAXED) != 0; };
+  auto publish = [&](size_t passes) {
+    if (finish_pass) __atomic_store_n(finish_pass, passes, __ATOMIC_RELEASE);
+  };
   HIPCHK(hipSetDevice(s->device));
   hipStream_t st = s->stream;
   const size_t npx_img = (size_t)d->width * d->height;
@@ -876,15 +892,16 @@ static int render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volat
     HIPCHK(hipMemsetAsync(d_rgba, 0, npx_img * 4 * sizeof(float), st));
     HIPCHK(hipMemsetAsync(d_count, 0, npx_img * sizeof(uint32_t), st));
   }
-  if (finish_pass) *finish_pass = 0;
+  publish(0);
   pbrhip_render_stats S;
   memset(&S, 0, sizeof(S));
-  if (d->shard_block > 4096) return fail(PBRHIP_EINVAL, "shard_block %u is not a sensible block edge", d->shard_block);
   if (int rc = ensure_pixels(s, d->width, d->height, d->tile_rank, world, d->shard_block)) return rc;
   const uint32_t npix = s->pk_npix;
   const bool want_stats = (d->flags & PBRHIP_RENDER_STATS) != 0;
+  const bool want_timing = (d->flags & PBRHIP_RENDER_TIMING) != 0;
+  uint32_t done = 0;  // passes accumulated into the layer
   if (npix > 0 && d->num_sample > 0) {
-    // default: as many paths in flight as half of the free HBM holds (288 GB: a whole 1080p x 64 spp frame,
+    // default: as many paths in flight as 60 % of the free HBM holds (288 GB: a whole 1080p x 64 spp frame,
     // 132.7 M paths x 244 B, is one chunk) -- fewer, larger launches and one tail instead of many
     uint64_t max_paths = d->max_paths_in_flight;
     if (!max_paths) {
@@ -922,48 +939,44 @@ static int render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volat
     const uint64_t rng_inc = (d->seed_seq << 1u) | 1u;  // pcg32_srandom (rng.h:30-36)
     const DScene& sc = s->dscene;
 
-    // Path GROUPS: the passes of a chunk are split into up to kMaxGroups independent sub-populations, each with
-    // its own queues, counters and HIP stream.  Every wavefront iteration ends in a latency-bound drain (the
-    // slowest ray's dependent-load chain: 0.1-0.4 ms with the GPU almost idle); with several groups in flight
-    // one group's drain overlaps the others' bulk work.  Path slots stay global, so results are unchanged.
     uint32_t tail_paths = d->tail_paths == 0xFFFFFFFFu ? 0u : (d->tail_paths ? d->tail_paths : 262144u);
     if (const char* e = getenv("PBRHIP_TAIL_PATHS")) tail_paths = (uint32_t)strtoul(e, nullptr, 10);  // 0 = never
-    // default: two groups once a chunk holds >= 16 Mi paths (A/B on C2, 132.7 M paths: 1 -> 72.5 ms, 2 -> 69.7, 3 -> 70.6,
-    // 4 -> 78.1: one group's latency-bound k_tail and drains hide behind the other's bulk work; more groups only add launches)
-    const uint64_t chunk_paths = (uint64_t)chunk_passes * npix;
-    uint32_t want_groups = d->num_streams ? d->num_streams : (chunk_paths >= (16ull << 20) ? 2u : 1u);
+    uint32_t want_groups = d->num_streams;
     if (const char* e = getenv("PBRHIP_STREAMS")) want_groups = (uint32_t)atoi(e);
-    want_groups = std::max(1u, std::min(want_groups, (uint32_t)kMaxGroups));
-    if (int rc = ensure_groups(s, want_groups)) return rc;
+    // at most `window` groups in their bulk phase (more live paths than bulk_frac of what they started with) at a time
+    const uint32_t window = std::max(1u, env_u32("PBRHIP_WINDOW", want_groups ? kMaxGroups : 2u));
+    const double bulk_frac = 1.0 / std::max(1u, env_u32("PBRHIP_BULK_DIV", 8u));
+    if (int rc = ensure_groups(s, kMaxGroups)) return rc;
     struct Group {
       PathState P;
-      hipStream_t st;
-      uint32_t* h_counts;
-      uint32_t n, first_pass, npass, slot0;
+      uint32_t n0, first_pass, npass, slot0;  // paths at the start, pass range, first path slot
+      uint32_t n = 0, iters = 0;
+      int lane = -1;  // stream / counter / spill slot while active
+      bool started = false, finished = false;
       Timer tm;
-      uint32_t iters = 0;
     };
 
-    for (uint32_t done = 0; done < d->num_sample;) {
-      if (cancel && *cancel) break;  // render.cc:217 (cooperative, chunk granularity)
-      uint32_t np = std::min(chunk_passes, d->num_sample - done);
-      const uint32_t ng = std::min(want_groups, np);
-      HIPCHK(hipStreamSynchronize(st));  // clears / previous chunk's accumulate are done before groups start
-      std::vector<Group> G;
-      G.reserve(ng);
-      for (uint32_t g = 0; g < ng; g++) {
-        uint32_t p0 = (uint32_t)((uint64_t)np * g / ng), p1 = (uint32_t)((uint64_t)np * (g + 1) / ng);
-        Group gr{P, g == 0 ? st : s->group_streams[g - 1], s->h_counts + g * kCntNum, (p1 - p0) * npix,
-                 d->first_pass + done + p0, p1 - p0, p0 * npix, Timer{s, (d->flags & PBRHIP_RENDER_TIMING) != 0, g == 0 ? st : s->group_streams[g - 1]}};
+    bool stop = false;
+    for (; done < d->num_sample && !stop;) {
+      if (cancelled()) break;  // render.cc:217
+      const uint32_t np = std::min(chunk_passes, d->num_sample - done);
+      HIPCHK(hipStreamSynchronize(st));  // clears / the previous chunk's accumulates are done before groups start
+      const std::vector<uint32_t> plan = plan_groups(np, npix, want_groups);
+      const uint32_t ng = (uint32_t)plan.size();
+      std::vector<Group> G(ng);
+      for (uint32_t g = 0, p0 = 0; g < ng; p0 += plan[g], g++) {
+        Group& gr = G[g];
+        gr.P = P, gr.n0 = plan[g] * npix, gr.first_pass = d->first_pass + done + p0, gr.npass = plan[g], gr.slot0 = p0 * npix;
         const size_t off = gr.slot0;
         gr.P.q_in += off, gr.P.q_out += off, gr.P.q_principled += off, gr.P.q_hair += off, gr.P.q_sss += off, gr.P.q_shadow += off, gr.P.q_shadow_in += off;
-        gr.P.counts = s->counts.p + g * kCntNum;
-        gr.P.first = 0u;
         for (int k = 0; k < 3; k++) gr.P.cam_org[k] = cam.org[k];
-        gr.P.spill = s->spill.p + (size_t)g * kStackDepth * kTraceGridCap * 256;
-        G.push_back(gr);
+        gr.tm = Timer{s, want_timing, nullptr};
       }
+      bool lane_busy[kMaxGroups] = {};
+      auto lane_stream = [&](int lane) { return lane == 0 ? st : s->group_streams[lane - 1]; };
+      auto lane_hcounts = [&](int lane) { return s->h_counts + lane * kCntNum; };
       auto enqueue = [&](Group& gr) -> int {
+        hipStream_t gst = lane_stream(gr.lane);
         // Long tails (few paths, many bounces) are latency-bound: below 256 Ki active paths several iterations
         // are queued per host round trip (kernels read their counts on the device and fall through when empty).
         const int burst = gr.n < (1u << 18) ? 8 : 1;
@@ -972,86 +985,130 @@ static int render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volat
           // few live paths: trace this bounce (and the pending shadow rays), then finish every path in one launch
           gr.P.first = gr.iters++ == 0 ? 1u : 0u;
           HIPCHK(gr.tm.begin(&S.ms_trace_closest));
-          launch_trace(gr.st, gr.P, sc, 2 * n, want_stats);
+          launch_trace(gst, gr.P, sc, 2 * n, want_stats);
           HIPCHK(gr.tm.end());
           HIPCHK(gr.tm.begin(&S.ms_tail));
-          launch_tail(gr.st, gr.P, sc, n, rng_inc, want_stats);
+          launch_tail(gst, gr.P, sc, n, rng_inc, want_stats);
           HIPCHK(gr.tm.end());
-          launch_advance(gr.st, gr.P);  // nothing was queued: both "in" counts become 0
+          launch_advance(gst, gr.P);  // nothing was queued: both "in" counts become 0
           S.n_trace_closest++, S.n_tail++, S.iterations++;
-          HIPCHK(hipMemcpyAsync(gr.h_counts, gr.P.counts, sizeof(uint32_t) * kCntNum, hipMemcpyDeviceToHost, gr.st));
+          HIPCHK(hipMemcpyAsync(lane_hcounts(gr.lane), gr.P.counts, sizeof(uint32_t) * kCntNum, hipMemcpyDeviceToHost, gst));
           return PBRHIP_OK;
         }
         for (int it = 0; it < burst; it++) {
           gr.P.first = gr.iters++ == 0 ? 1u : 0u;
           HIPCHK(gr.tm.begin(&S.ms_trace_closest));
-          launch_trace(gr.st, gr.P, sc, 2 * n, want_stats);  // this bounce's closest rays + last bounce's shadow rays
+          launch_trace(gst, gr.P, sc, 2 * n, want_stats);  // this bounce's closest rays + last bounce's shadow rays
           HIPCHK(gr.tm.end());
           HIPCHK(gr.tm.begin(&S.ms_surface));
-          launch_classify(gr.st, gr.P, sc, n);
+          launch_classify(gst, gr.P, sc, n);
           HIPCHK(gr.tm.end());
           HIPCHK(gr.tm.begin(&S.ms_shade_principled));
-          launch_shade_principled(gr.st, gr.P, sc, n, rng_inc, !s->has_sss);
+          launch_shade_principled(gst, gr.P, sc, n, rng_inc, !s->has_sss);
           HIPCHK(gr.tm.end());
           if (s->has_hair) {
             HIPCHK(gr.tm.begin(&S.ms_shade_hair));
-            launch_shade_hair(gr.st, gr.P, sc, n, rng_inc);
+            launch_shade_hair(gst, gr.P, sc, n, rng_inc);
             HIPCHK(gr.tm.end());
             S.n_shade_hair++;
           }
           if (s->has_sss) {
             HIPCHK(gr.tm.begin(&S.ms_sss_step));
-            launch_sss_step(gr.st, gr.P, sc, n, rng_inc);
+            launch_sss_step(gst, gr.P, sc, n, rng_inc);
             HIPCHK(gr.tm.end());
             S.n_sss_step++;
           }
           HIPCHK(gr.tm.begin(&S.ms_compact));
-          launch_compact(gr.st, gr.P, n);
+          launch_compact(gst, gr.P, n);
           HIPCHK(gr.tm.end());
           S.n_trace_closest++, S.n_surface++, S.n_shade_principled++;
-          launch_advance(gr.st, gr.P);
+          launch_advance(gst, gr.P);
           std::swap(gr.P.q_in, gr.P.q_out);
           std::swap(gr.P.q_shadow, gr.P.q_shadow_in);
           S.iterations++;
         }
-        HIPCHK(hipMemcpyAsync(gr.h_counts, gr.P.counts, sizeof(uint32_t) * kCntNum, hipMemcpyDeviceToHost, gr.st));
+        HIPCHK(hipMemcpyAsync(lane_hcounts(gr.lane), gr.P.counts, sizeof(uint32_t) * kCntNum, hipMemcpyDeviceToHost, gst));
         return PBRHIP_OK;
       };
-      for (Group& gr : G) {
-        memset(gr.h_counts, 0, sizeof(uint32_t) * kCntNum);
-        gr.h_counts[kCntIn] = gr.n;
-        HIPCHK(hipMemcpyAsync(gr.P.counts, gr.h_counts, sizeof(uint32_t) * kCntNum, hipMemcpyHostToDevice, gr.st));
+      auto start = [&](Group& gr, int lane) -> int {
+        gr.lane = lane, gr.started = true, gr.n = gr.n0, lane_busy[lane] = true;
+        hipStream_t gst = lane_stream(lane);
+        gr.tm.stream = gst;
+        gr.P.counts = s->counts.p + lane * kCntNum;
+        gr.P.spill = s->spill.p + (size_t)lane * kStackDepth * kTraceGridCap * 256;
+        uint32_t* hc = lane_hcounts(lane);
+        memset(hc, 0, sizeof(uint32_t) * kCntNum);
+        hc[kCntIn] = gr.n0;
+        HIPCHK(hipMemcpyAsync(gr.P.counts, hc, sizeof(uint32_t) * kCntNum, hipMemcpyHostToDevice, gst));
         HIPCHK(gr.tm.begin(&S.ms_generate));
-        launch_generate(gr.st, gr.P, cam, s->pix_index.p, npix, gr.n, gr.slot0, d->width, gr.first_pass, d->seed_seq);
+        launch_generate(gst, gr.P, cam, s->pix_index.p, npix, gr.n0, gr.slot0, d->width, gr.first_pass, d->seed_seq);
         HIPCHK(gr.tm.end());
-        if (int rc = enqueue(gr)) return rc;
-      }
-      // round-robin: wait for a group's burst, queue its next one, move on -- every live group keeps work in flight
-      for (uint32_t live = ng; live > 0;) {
+        return enqueue(gr);
+      };
+      // Scheduler: poll the active groups' streams; a group whose burst has drained gets its next one; a finished
+      // group frees its lane; passes are accumulated (ascending, on the main stream) as soon as every earlier group
+      // of the chunk is complete, and *finish_pass follows.  *cancel is read on every turn.
+      uint32_t next_start = 0, acc_prefix = 0, active = 0, acc_passes = 0;
+      for (;;) {
+        if (!stop && cancelled()) stop = true;
+        // start groups while the window allows
+        while (!stop && next_start < ng) {
+          uint32_t bulk = 0;
+          for (const Group& gr : G)
+            if (gr.started && !gr.finished && (double)gr.n > bulk_frac * (double)gr.n0) bulk++;
+          int lane = -1;
+          for (int l = 0; l < kMaxGroups; l++)
+            if (!lane_busy[l]) {
+              lane = l;
+              break;
+            }
+          if (bulk >= window || lane < 0) break;
+          if (int rc = start(G[next_start], lane)) return rc;
+          next_start++, active++;
+        }
+        if (active == 0) break;
+        bool progressed = false;
         for (Group& gr : G) {
-          if (gr.n == 0) continue;
-          HIPCHK(hipStreamSynchronize(gr.st));
+          if (!gr.started || gr.finished) continue;
+          hipError_t q = hipStreamQuery(lane_stream(gr.lane));
+          if (q == hipErrorNotReady) continue;
+          HIPCHK(q);
+          progressed = true;
           HIPCHK(gr.tm.collect());
-          if (gr.h_counts[kCntOverflow]) return fail(PBRHIP_EOVERFLOW, "BVH traversal stack overflow");
-          gr.n = std::max(gr.h_counts[kCntIn], gr.h_counts[kCntShadowIn]);  // pending shadow rays need one more trace
-          if (gr.n == 0) {
-            live--;
+          const uint32_t* hc = lane_hcounts(gr.lane);
+          if (hc[kCntOverflow]) return fail(PBRHIP_EOVERFLOW, "BVH traversal stack overflow");
+          gr.n = std::max(hc[kCntIn], hc[kCntShadowIn]);  // pending shadow rays need one more trace
+          if (gr.n == 0 || stop) {  // complete -- or abandoned: a cancelled render drops what is in flight
+            gr.finished = gr.n == 0;
+            if (!gr.finished) gr.started = false;
+            lane_busy[gr.lane] = false, active--;
             continue;
           }
           if (int rc = enqueue(gr)) return rc;
         }
+        // accumulate the complete prefix of the chunk's groups
+        while (acc_prefix < ng && G[acc_prefix].finished) {
+          const Group& gr = G[acc_prefix];
+          PathState PA = P;
+          PA.L = P.L + gr.slot0;
+          Timer tm{s, want_timing, st};
+          HIPCHK(tm.begin(&S.ms_accumulate));
+          launch_accumulate(st, PA, s->pix_index.p, npix, gr.npass, d_rgba, d_count);
+          HIPCHK(tm.end());
+          HIPCHK(hipGetLastError());
+          if (want_timing) {
+            HIPCHK(hipStreamSynchronize(st));
+            HIPCHK(tm.collect());
+          }
+          acc_passes += gr.npass, acc_prefix++;
+          S.samples += (uint64_t)gr.npass * npix;
+          publish((size_t)done + acc_passes);  // render.cc:224-231
+        }
+        if (!progressed) std::this_thread::yield();
       }
-      Timer tm{s, (d->flags & PBRHIP_RENDER_TIMING) != 0, st};
-      HIPCHK(tm.begin(&S.ms_accumulate));
-      launch_accumulate(st, P, s->pix_index.p, npix, np, d_rgba, d_count);
-      HIPCHK(tm.end());
-      HIPCHK(hipGetLastError());
       HIPCHK(hipStreamSynchronize(st));
-      HIPCHK(tm.collect());
-      done += np;
+      done += acc_passes;
       S.chunks++;
-      S.samples += (uint64_t)np * npix;
-      if (finish_pass) *finish_pass = done;  // render.cc:224-231
     }
     HIPCHK(hipStreamSynchronize(st));
     if (want_stats) {
@@ -1072,42 +1129,49 @@ static int render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volat
     }
   } else {
     HIPCHK(hipStreamSynchronize(st));
-    if (finish_pass) *finish_pass = d->num_sample;
+    done = d->num_sample;
+    publish(done);
   }
+  S.passes_done = done;
   S.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   if (stats) *stats = S;
   return PBRHIP_OK;
 }
 
-extern "C" int pbrhip_render_device(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile int* cancel,
+extern "C" int pbrhip_render_device(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile unsigned char* cancel,
                                     float* d_rgba, uint32_t* d_count, size_t* finish_pass, pbrhip_render_stats* stats) {
-  if (!s || !d || !d_rgba || !d_count) return fail(PBRHIP_EINVAL, "render: NULL argument");
-  return render_impl(s, d, cancel, d_rgba, d_count, finish_pass, stats);
+  return guarded([&]() -> int {
+    if (!s || !d || !d_rgba || !d_count) return fail(PBRHIP_EINVAL, "render: NULL argument");
+    return render_impl(s, d, cancel, d_rgba, d_count, finish_pass, stats);
+  });
 }
 
-extern "C" int pbrhip_render(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile int* cancel, float* rgba,
-                             uint32_t* count, size_t* finish_pass, pbrhip_render_stats* stats) {
-  if (!s || !d || !rgba || !count) return fail(PBRHIP_EINVAL, "render: NULL argument");
-  auto t_begin = std::chrono::steady_clock::now();
-  HIPCHK(hipSetDevice(s->device));
-  size_t npx = (size_t)d->width * d->height;
-  HIPCHK(s->own_rgba.reserve(npx * 4));
-  HIPCHK(s->own_count.reserve(npx));
-  if (d->flags & PBRHIP_RENDER_NO_CLEAR) {
-    HIPCHK(hipMemcpyAsync(s->own_rgba.p, rgba, npx * 4 * sizeof(float), hipMemcpyHostToDevice, s->stream));
-    HIPCHK(hipMemcpyAsync(s->own_count.p, count, npx * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
-  }
-  int rc = render_impl(s, d, cancel, s->own_rgba.p, s->own_count.p, finish_pass, stats);
-  if (rc) return rc;
-  HIPCHK(hipMemcpyAsync(rgba, s->own_rgba.p, npx * 4 * sizeof(float), hipMemcpyDeviceToHost, s->stream));
-  HIPCHK(hipMemcpyAsync(count, s->own_count.p, npx * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
-  HIPCHK(hipStreamSynchronize(s->stream));
-  if (stats) stats->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
-  return PBRHIP_OK;
+extern "C" int pbrhip_render(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile unsigned char* cancel,
+                             float* rgba, uint32_t* count, size_t* finish_pass, pbrhip_render_stats* stats) {
+  return guarded([&]() -> int {
+    if (!s || !d || !rgba || !count) return fail(PBRHIP_EINVAL, "render: NULL argument");
+    auto t_begin = std::chrono::steady_clock::now();
+    HIPCHK(hipSetDevice(s->device));
+    size_t npx = (size_t)d->width * d->height;
+    HIPCHK(s->own_rgba.reserve(npx * 4));
+    HIPCHK(s->own_count.reserve(npx));
+    if (d->flags & PBRHIP_RENDER_NO_CLEAR) {
+      HIPCHK(hipMemcpyAsync(s->own_rgba.p, rgba, npx * 4 * sizeof(float), hipMemcpyHostToDevice, s->stream));
+      HIPCHK(hipMemcpyAsync(s->own_count.p, count, npx * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+    }
+    int rc = render_impl(s, d, cancel, s->own_rgba.p, s->own_count.p, finish_pass, stats);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(rgba, s->own_rgba.p, npx * 4 * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipMemcpyAsync(count, s->own_count.p, npx * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if (stats) stats->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    return PBRHIP_OK;
+  });
 }
 
 // ------------------------------------------------------------------ test hooks
 extern "C" int pbrhip_trace_closest(pbrhip_scene* s, const pbrhip_ray* rays, size_t n, pbrhip_hit* hits) {
+  return guarded([&]() -> int {
   if (!s || (!rays && n) || (!hits && n)) return fail(PBRHIP_EINVAL, "trace_closest: NULL argument");
   if (!s->committed) return fail(PBRHIP_ESTATE, "scene not committed");
   if (n == 0) return PBRHIP_OK;
@@ -1127,8 +1191,10 @@ extern "C" int pbrhip_trace_closest(pbrhip_scene* s, const pbrhip_ray* rays, siz
   HIPCHK(hipStreamSynchronize(s->stream));
   if (s->h_counts[kCntOverflow]) return fail(PBRHIP_EOVERFLOW, "BVH traversal stack overflow");
   return PBRHIP_OK;
+  });
 }
 extern "C" int pbrhip_trace_any(pbrhip_scene* s, const pbrhip_ray* rays, size_t n, uint8_t* occluded) {
+  return guarded([&]() -> int {
   if (!s || (!rays && n) || (!occluded && n)) return fail(PBRHIP_EINVAL, "trace_any: NULL argument");
   if (!s->committed) return fail(PBRHIP_ESTATE, "scene not committed");
   if (n == 0) return PBRHIP_OK;
@@ -1148,4 +1214,5 @@ extern "C" int pbrhip_trace_any(pbrhip_scene* s, const pbrhip_ray* rays, size_t 
   HIPCHK(hipStreamSynchronize(s->stream));
   if (s->h_counts[kCntOverflow]) return fail(PBRHIP_EOVERFLOW, "BVH traversal stack overflow");
   return PBRHIP_OK;
+  });
 }

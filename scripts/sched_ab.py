@@ -1,0 +1,61 @@
+"""A/B of the path-group schedule (pbrhip.cpp::plan_groups) on one GPU: the whole C2 frame (world 1) and rank 0's share
+of an 8-rank job (16 x 16 blocks), best of REPS renders each.  Configurations = environment overrides the library reads
+per render.  usage: python scripts/sched_ab.py [variant]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import pbrlab_amd as pa
+from pbrlab_amd import scenes, api
+
+variant = sys.argv[1] if len(sys.argv) > 1 else "ggx"
+spp = {"ggx": 64, "sss": 256}.get(variant, 128)
+desc = scenes.hair_scene(seed=1) if variant == "hair" else scenes.cornell_scene(variant, seed=1)
+s = pa.scene_from_desc(desc)
+W, H = 1920, 1080
+rgba = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda"); cnt = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+torch.cuda.synchronize()
+REPS = int(os.environ.get("REPS", "3"))
+KEYS = ("PBRHIP_GROUPS", "PBRHIP_WINDOW", "PBRHIP_BULK_DIV", "PBRHIP_GROUP_MIN_PATHS", "PBRHIP_STREAMS", "PBRHIP_TAIL_PATHS")
+CONFIGS = [
+    {},                                                     # library default
+    {"PBRHIP_STREAMS": "1"},
+    {"PBRHIP_STREAMS": "2"},                                 # round 1's default for big chunks
+    {"PBRHIP_STREAMS": "4"},
+    {"PBRHIP_WINDOW": "1"},
+    {"PBRHIP_WINDOW": "3"},
+    {"PBRHIP_BULK_DIV": "4"},
+    {"PBRHIP_BULK_DIV": "16"},
+    {"PBRHIP_BULK_DIV": "64"},
+    {"PBRHIP_GROUP_MIN_PATHS": "262144"},
+    {"PBRHIP_GROUP_MIN_PATHS": "4194304"},
+    {"PBRHIP_GROUPS": "16,16,16,8,4,2,1,1"},
+    {"PBRHIP_GROUPS": "24,16,8,8,4,2,1,1"},
+    {"PBRHIP_GROUPS": "16,16,16,16"},
+    {"PBRHIP_GROUPS": "8,8,8,8,8,8,8,4,2,1,1", "PBRHIP_WINDOW": "2"},
+    {"PBRHIP_GROUPS": "8,8,8,8,8,8,8,4,2,1,1", "PBRHIP_WINDOW": "3"},
+]
+
+
+def best(world, rank=0, **kw):
+    t_best, st_best = 1e9, None
+    for _ in range(REPS):
+        t = time.perf_counter()
+        _, st = api.Render(s, W, H, spp, tile_rank=rank, tile_world=world, device_out=(rgba.data_ptr(), cnt.data_ptr()),
+                           shard_block=16 if world > 1 else 0, **kw)
+        dt = (time.perf_counter() - t) * 1e3
+        if dt < t_best:
+            t_best, st_best = dt, st
+    return t_best, st_best
+
+
+best(1)
+for cfg in CONFIGS:
+    for k in KEYS:
+        os.environ.pop(k, None)
+    os.environ.update(cfg)
+    t1, st1 = best(1)
+    t8, st8 = best(8)
+    t4, _ = best(4)
+    t2, _ = best(2)
+    print(f"{str(cfg):90s} world1 {t1:6.2f} ms ({st1['iterations']:3d} it)  1/2 {t2:6.2f} ({t1 / t2:.2f}x)  1/4 {t4:6.2f} ({t1 / t4:.2f}x)  "
+          f"1/8 {t8:6.2f} ms ({st8['iterations']:3d} it, {t1 / t8:.2f}x)", flush=True)

@@ -56,6 +56,80 @@ def test_gloo_world2_reduce(tmp_path):
     assert "DIST_OK" in outs[0]
 
 
+WORKER_GATHER = r"""
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np, torch, torch.distributed as dist
+import _oracle as O
+from pbrlab_amd import scenes
+from pbrlab_amd.dist import reduce_layer, gather_layer, shard_pixels
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+d = scenes.cornell_scene("ggx", monkey_subdiv=1, lucy_nu=32, lucy_nv=8)
+so = O.oracle_scene_from_desc(d)
+W, H, SPP = 150, 90, 2
+full, fcnt, _ = so.render(W, H, SPP)
+for block in (16, 64, 100):
+    # this rank's layer: its blocks of the frame, zeros elsewhere (what pbrhip_render writes for tile_rank / shard_block)
+    pix = shard_pixels(W, H, rank, world, block)
+    rgba, cnt = np.zeros_like(full), np.zeros_like(fcnt)
+    rgba.reshape(-1, 4)[pix] = full.reshape(-1, 4)[pix]
+    cnt.reshape(-1)[pix] = fcnt.reshape(-1)[pix]
+    assert len(np.unique(pix)) == len(pix)
+    for how in (gather_layer, reduce_layer):
+        t_rgba, t_cnt = torch.from_numpy(rgba.copy()), torch.from_numpy(cnt.astype(np.int32))
+        if how is gather_layer: how(t_rgba, t_cnt, block=block, dst=0)
+        else: how(t_rgba, t_cnt, dst=0)
+        if rank == 0:
+            assert t_rgba.numpy().tobytes() == full.tobytes(), (block, how.__name__)
+            assert np.array_equal(t_cnt.numpy(), fcnt.astype(np.int32))
+# the ranks' pixel lists partition the frame
+all_pix = np.concatenate([shard_pixels(W, H, r, world, 16) for r in range(world)])
+assert np.array_equal(np.sort(all_pix), np.arange(W * H))
+if rank == 0: print("DIST_OK")
+dist.destroy_process_group()
+"""
+
+
+def run_world(tmp_path, text, world):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "worker.py"
+    script.write_text(text.format(root=ROOT))
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "DIST_OK" in outs[0]
+
+
+def test_gloo_world2_gather_and_reduce(tmp_path):
+    """the two exchanges of the N > 1 path (shard gather = what pbrhip_comm_gather_layer does; full-layer reduce) on the
+    block -> rank map the library uses, for several block sizes: both land the one-rank frame on rank 0, bit for bit"""
+    run_world(tmp_path, WORKER_GATHER, 2)
+
+
+def test_gloo_world3_gather_and_reduce(tmp_path):
+    run_world(tmp_path, WORKER_GATHER, 3)
+
+
+def test_shard_pixels_matches_tiles():
+    """block 64 = CreateTiles' tiles in CreateTiles' order (render-tile.cc:29-41)"""
+    from pbrlab_amd.dist import shard_pixels, tiles_of_rank
+    W, H = 200, 136
+    for world in (1, 3):
+        for r in range(world):
+            want = np.concatenate([(np.arange(sy, ty)[:, None] * W + np.arange(sx, tx)[None, :]).reshape(-1)
+                                   for sx, tx, sy, ty in tiles_of_rank(W, H, r, world).astype(np.int64)])
+            assert np.array_equal(shard_pixels(W, H, r, world, 64), want)
+
+
 def test_tile_rank_map():
     from pbrlab_amd.dist import tiles_of_rank
     import pbrlab_amd as pa

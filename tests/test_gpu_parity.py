@@ -255,12 +255,119 @@ def test_texture_errors(pa):
 
 def test_cancel_and_finish_pass(pa, pairs):
     desc, sg, so = pairs["lambert"]
-    fin, cancel, lay = C.c_size_t(99), C.c_int(1), pa.RenderLayer()
+    fin, cancel, lay = C.c_size_t(99), C.c_ubyte(1), pa.RenderLayer()
     pa.Render(sg, 32, 32, 4, cancel_render_flag=cancel, layer=lay, finish_pass=fin)
     assert fin.value == 0 and not lay.count.any()
     cancel.value = 0
     pa.Render(sg, 32, 32, 4, cancel_render_flag=cancel, layer=lay, finish_pass=fin)
     assert fin.value == 4 and (lay.count == 4).all()
+
+
+def test_cancel_from_another_thread_mid_render(pa):
+    """render.cc:217: the flag is set by another thread while Render() runs.  The library reads it at every host round
+    trip, drains what is in flight and returns the passes that are complete: count is uniform and equals finish_pass,
+    and those passes are the very ones an uncancelled render of that many passes produces."""
+    import threading
+    import time
+    from pbrlab_amd import scenes
+    desc = scenes.cornell_scene("sss", monkey_subdiv=2, lucy_nu=64, lucy_nv=12)
+    sg = pa.scene_from_desc(desc)
+    W, H, SPP = 640, 360, 4096            # ~1 G samples of the random-walk scene: seconds of work
+    warm = pa.RenderLayer()
+    pa.Render(sg, W, H, 8, layer=warm)    # allocate the working set outside the timed part
+    fin, cancel, lay = C.c_size_t(0), C.c_ubyte(0), pa.RenderLayer()
+    seen, t_set = [], [0.0]
+
+    def killer():
+        time.sleep(0.25)
+        seen.append(fin.value)            # progress is visible while the call runs
+        t_set[0] = time.perf_counter()
+        cancel.value = 1
+    th = threading.Thread(target=killer)
+    th.start()
+    ok, st = pa.Render(sg, W, H, SPP, cancel_render_flag=cancel, layer=lay, finish_pass=fin)
+    t_ret = time.perf_counter()
+    th.join()
+    assert ok is True and 0 < fin.value < SPP and st["passes_done"] == fin.value
+    assert seen[0] <= fin.value
+    assert (lay.count == fin.value).all() and np.array_equal(lay.rgba[..., 3], np.full((H, W), fin.value, np.float32))
+    assert t_ret - t_set[0] < 0.25, t_ret - t_set[0]        # a wavefront iteration, not the rest of the frame
+    ref = pa.RenderLayer()
+    pa.Render(sg, W, H, int(fin.value), layer=ref)
+    assert ref.rgba.tobytes() == lay.rgba.tobytes()
+    print(f"cancelled after {fin.value} of {SPP} passes, returned {1e3 * (t_ret - t_set[0]):.1f} ms after the flag")
+
+
+@pytest.mark.parametrize("name", ["ggx", "sss", "hair"])
+def test_group_schedules_are_exact(pa, pairs, name, monkeypatch):
+    """pbrhip.cpp::plan_groups: however the passes of a chunk are split into path groups and however many of them are in
+    their bulk phase at once, the image is the same, bit for bit"""
+    desc, sg, so = pairs[name]
+    ref = pa.RenderLayer()
+    pa.Render(sg, 96, 80, 11, layer=ref, num_streams=1)
+    for plan, window, minp in (("6,3,1,1", "2", None), ("1,1,1,1,1,1,1,1,1,1,1", "3", None), ("5,6", "1", None),
+                               ("8", "2", None), (None, "2", "4096"), (None, "1", "1")):
+        if plan is None:
+            monkeypatch.delenv("PBRHIP_GROUPS", raising=False)
+        else:
+            monkeypatch.setenv("PBRHIP_GROUPS", plan)
+        monkeypatch.setenv("PBRHIP_WINDOW", window)
+        if minp is not None:
+            monkeypatch.setenv("PBRHIP_GROUP_MIN_PATHS", minp)
+        for tail in (0, 0xFFFFFFFF, 500):
+            lay = pa.RenderLayer()
+            fin = C.c_size_t(0)
+            pa.Render(sg, 96, 80, 11, layer=lay, tail_paths=tail, finish_pass=fin)
+            assert fin.value == 11 and lay.rgba.tobytes() == ref.rgba.tobytes(), (plan, window, minp, tail)
+
+
+@pytest.mark.parametrize("name", ["sss", "hair"])
+def test_render_multi_matches_single(pa, pairs, name):
+    """pbrhip_render_multi: ranks of one process, rank g on device g % ndev, shards gathered device-to-device inside the
+    library; equals the one-rank frame bit for bit (src/render.cc:203-238: the image does not depend on the workers)"""
+    desc, sg, so = pairs[name]
+    full = pa.RenderLayer()
+    pa.Render(sg, 200, 136, 3, layer=full)
+    ndev = pa.device_count()
+    for n in (2, 3, 8):
+        reps = [sg] + [pa.replicate(sg, g % ndev) for g in range(1, n)]
+        lay = pa.RenderLayer()
+        fin = C.c_size_t(0)
+        ok, sts = pa.RenderMulti(reps, 200, 136, 3, layer=lay, finish_pass=fin)
+        assert ok is True and fin.value == 3 and len(sts) == n
+        assert lay.rgba.tobytes() == full.rgba.tobytes() and np.array_equal(lay.count, full.count), n
+        assert sum(s["samples"] for s in sts) == 200 * 136 * 3
+        lay2 = pa.RenderLayer()
+        pa.RenderMulti(reps, 200, 136, 3, layer=lay2, shard_block=64)      # the reference's tiles as the dealing unit
+        assert lay2.rgba.tobytes() == full.rgba.tobytes()
+        for r in reps[1:]:
+            r.close()
+    # a replica is a full scene: it renders and traces on its own
+    rep = pa.replicate(sg, 0)
+    lay = pa.RenderLayer()
+    pa.Render(rep, 200, 136, 3, layer=lay)
+    assert lay.rgba.tobytes() == full.rgba.tobytes()
+    assert np.array_equal(rep.FetchSceneAABB()[0], sg.FetchSceneAABB()[0])
+
+
+def test_library_communicator_world1(pa, pairs):
+    """pbrhip_comm_* (RCCL inside the library): with one rank the reduce is the identity and the gather a no-op; this
+    checks that librccl loads, a communicator initialises and a collective runs on this box (the multi-rank exchange is
+    covered by the in-process path above and by the gloo tests of the same pixel lists)"""
+    import torch
+    desc, sg, so = pairs["ggx"]
+    W, H = 96, 80
+    rgba = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    cnt = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+    pa.Render(sg, W, H, 2, device_out=(rgba.data_ptr(), cnt.data_ptr()))
+    torch.cuda.synchronize()
+    before = rgba.clone()
+    comm = pa.Comm(pa.Comm.unique_id(), 0, 1)
+    comm.reduce_layer(rgba.data_ptr(), cnt.data_ptr(), W * H, root=0)
+    comm.gather_layer(sg, W, H, rgba.data_ptr(), cnt.data_ptr(), shard_block=16, root=0)
+    torch.cuda.synchronize()
+    assert torch.equal(rgba, before) and int(cnt.min()) == 2
+    comm.close()
 
 
 @pytest.mark.parametrize("config", ["c2", "c3", "c4"])
