@@ -23,6 +23,8 @@ struct TravStats {
   uint32_t anodes, atris, acurves;  // any-hit (shadow) rays
   // phase-voting traversal, lane 0 of each wave: iterations and participating lanes per phase
   uint32_t it_node, it_tri, it_curve, it_refill, ln_node, ln_tri, ln_curve;
+  // per ray: steps (node visits + primitive tests) in power-of-two buckets (<= 16, 32, ... 1024, more) and the maximum
+  uint32_t hist[8], max_steps;
 };
 
 __device__ __forceinline__ V3 ld3(const float4& a) { return V3(a.x, a.y, a.z); }
@@ -122,10 +124,12 @@ __device__ __forceinline__ void box_test2(const float4& n0, const float4& n1, co
   h1 = a1 <= b1 && b1 >= tmin && a1 <= tmax;
 }
 
-// Leaf processing.  ANY: returns true on the first accepted hit.
-template <bool ANY, bool STATS, bool CURVES>
+// Leaf processing.  any: returns true on the first accepted hit.
+// MODE: 0 = closest hit, 1 = any hit, 2 = per lane (`any_rt`), as in trace_pv.
+template <int MODE, bool STATS, bool CURVES>
 __device__ __forceinline__ bool leaf_test(const DScene& sc, uint32_t leaf, V3 o, V3 d, float tmin, float& best_t,
-                                          Hit& hit, TravStats& st) {
+                                          Hit& hit, TravStats& st, bool any_rt) {
+  const bool ANY = MODE == 2 ? any_rt : (MODE == 1);
   uint32_t first = (leaf & 0x3FFFFFFFu) >> 3, count = (leaf & 7u) + 1u;
   bool is_curve = (leaf & kCurveBit) != 0;
   for (uint32_t s = first; s < first + count; s++) {
@@ -153,9 +157,9 @@ __device__ __forceinline__ bool leaf_test(const DScene& sc, uint32_t leaf, V3 o,
 }
 
 // BVH2 traversal, near child first, far child on a per-lane stack (stack[i * stride]).
-template <bool ANY, bool STATS, bool CURVES>
-__device__ __forceinline__ bool traverse(const DScene& sc, V3 o, V3 d, float tmin, float tmax, Hit& hit,
-                                         uint32_t* stack, uint32_t stride, TravStats& st, uint32_t* overflow) {
+template <int MODE, bool STATS, bool CURVES>
+__device__ __forceinline__ bool traverse_mode(const DScene& sc, V3 o, V3 d, float tmin, float tmax, Hit& hit,
+                                              uint32_t* stack, uint32_t stride, TravStats& st, uint32_t* overflow, bool any_rt) {
   hit.slot = kNone;
   hit.t = tmax, hit.u = 0.f, hit.v = 0.f;
   if (sc.num_nodes == 0) return false;
@@ -195,11 +199,16 @@ __device__ __forceinline__ bool traverse(const DScene& sc, V3 o, V3 d, float tmi
         next = stack[(uint32_t)sp * stride];
       }
       if (!(next & kLeafBit)) break;
-      if (leaf_test<ANY, STATS, CURVES>(sc, next, o, d, tmin, best_t, hit, st)) return true;
+      if (leaf_test<MODE, STATS, CURVES>(sc, next, o, d, tmin, best_t, hit, st, any_rt)) return true;
       next = kEmptyChild;
     }
     cur = next;
   }
+}
+template <bool ANY, bool STATS, bool CURVES>
+__device__ __forceinline__ bool traverse(const DScene& sc, V3 o, V3 d, float tmin, float tmax, Hit& hit,
+                                         uint32_t* stack, uint32_t stride, TravStats& st, uint32_t* overflow) {
+  return traverse_mode<ANY ? 1 : 0, STATS, CURVES>(sc, o, d, tmin, tmax, hit, stack, stride, st, overflow, ANY);
 }
 
 }  // namespace pb

@@ -18,7 +18,11 @@
 
 namespace pb {
 
-constexpr uint32_t kPvBatch = 512;        // rays grabbed per atomicAdd
+constexpr uint32_t kPvBatch = 512;        // rays grabbed per atomicAdd, at most
+#ifndef PB_GUIDE
+#define PB_GUIDE 2
+#endif
+constexpr uint32_t kPvGuide = PB_GUIDE;   // a grab takes 1 / (kPvGuide x waves) of what is left (>= 64 rays); 0 = fixed batches
 #ifndef PB_LDS_STACK
 #define PB_LDS_STACK 16
 #endif
@@ -59,7 +63,10 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
                                          uint32_t* overflow, float* frame = nullptr) {
   // frame (CURVES): 10 words per lane in LDS (frame[k * stride]), the ray's RayFrame, written when the ray is fetched
   const uint32_t lane = __lane_id();
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  // number of set bits of a wave mask below this lane (v_mbcnt: no per-lane mask has to stay in registers)
+  auto rank_in = [](unsigned long long m) {
+    return (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+  };
   // wave-uniform batch cursor.  Rays are grabbed kPvBatch at a time when there are plenty; when the queue is
   // short the batch shrinks to one ray per lane so that the work spreads over all resident waves instead of
   // being walked serially by a few (a 20 k-ray launch took 1.5 ms with fixed 512-ray batches).
@@ -67,8 +74,8 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
   const uint32_t waves_total = gridDim.x * (blockDim.x >> 6);
   uint32_t batch = n / waves_total;
   if (batch >= 64u) {
-    batch &= ~63u;
-    batch = batch > kPvBatch ? kPvBatch : batch;
+    batch = (kPvGuide ? n / (waves_total * kPvGuide) : batch) & ~63u;
+    batch = batch > kPvBatch ? kPvBatch : (batch < 64u ? 64u : batch);
   } else {
     // fewer rays than resident lanes: spread them thin (a few lanes per wave, every SIMD busy).  A launch like this is
     // bound by the latency of its longest ray, and a ray advances fastest when its wave has no other phase to vote for
@@ -99,21 +106,23 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
 
   // per-lane state
   uint32_t state = kStIdle, tag = 0;
-  bool any_ray = (MODE == 1);
   V3 o(0.f), d(0.f), inv(0.f);
   float tmin = 0.f;  // (the current tmax of the ray is hit.t)
   Hit hit = {0.f, 0.f, 0.f, kNone};
   int sp = 0;
-  uint32_t cur = 0, end = 0;  // index of the current 64-byte item (node; TRI/CURVE: num_nodes + slot) and end of the leaf
+  uint32_t steps = 0;  // STATS: node visits + primitive tests of the lane's current ray
+  uint32_t rem = 0;  // primitives of the current leaf still to test after the current one
+  bool any_ray = (MODE == 1);
+  uint32_t cur = 0;  // index of the current 64-byte item (node; TRI/CURVE: num_nodes + slot)
   float4 D0 = make_float4(0, 0, 0, 0), D1 = D0, D2 = D0;  // prefetched node / primitive slot
   float2 D3 = make_float2(0, 0);                           // a node's two child references
 
   for (;;) {
-    unsigned long long idle_mask = __ballot(state == kStIdle || state >= kStDone);
-    int n_idle = __popcll(idle_mask);
     // `advance`: the lane needs a new item; `next` is its reference when have_next, else it is popped
     bool advance = false, have_next = false, need_load = false;
     uint32_t next = 0;
+    unsigned long long idle_mask = __ballot(state == kStIdle || state >= kStDone);
+    int n_idle = __popcll(idle_mask);
     if (!exhausted && (n_idle >= kPvRefillIdle)) {
       // ---- refill idle lanes from the queue
       if (batch_cur == batch_end) {
@@ -123,6 +132,13 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
         batch_cur = base < n ? base : n;
         batch_end = (base + batch) < n ? (base + batch) : n;
         if (batch_cur >= n) exhausted = true;
+        // guided self-scheduling: the batches shrink as the queue empties (down to one wave-full), so that the waves run
+        // dry at about the same time.  With fixed 512-ray batches the last batch of the unlucky waves was ~0.35 ms of a
+        // 16 M-ray launch during which the rest of the chip idled (one wave traces a ray in ~0.8 us).
+        if (kPvGuide && batch >= 64u) {
+          uint32_t nb = ((n - batch_end) / (waves_total * kPvGuide)) & ~63u;
+          batch = nb > kPvBatch ? kPvBatch : (nb < 64u ? 64u : nb);
+        }
       }
       if (state >= kStDone) {
         sink.done(tag, hit, state == kStDoneOccluded);
@@ -130,7 +146,7 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
       }
       uint32_t avail = batch_end - batch_cur;
       uint32_t take = (uint32_t)n_idle < avail ? (uint32_t)n_idle : avail;
-      uint32_t rank = (uint32_t)__popcll(idle_mask & lt_mask);
+      uint32_t rank = rank_in(idle_mask);
       if (state == kStIdle && rank < take) {
         float tmax;
         bool a = sink.load(batch_cur + rank, tag, o, d, tmin, tmax);
@@ -143,7 +159,7 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
           for (int k = 0; k < 10; k++) frame[(uint32_t)k * stride] = w[k];
         }
         hit.t = tmax, hit.u = 0.f, hit.v = 0.f, hit.slot = kNone;
-        sp = 0;
+        sp = 0, steps = 0;
         advance = true, have_next = true, next = 0u;  // root is always an internal node
       }
       batch_cur += take;
@@ -153,7 +169,7 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
       unsigned long long node_mask = __ballot(state == kStNode);
       unsigned long long tri_mask = __ballot(state == kStTri);
       int n_node = __popcll(node_mask), n_tri = __popcll(tri_mask);
-      int n_curve = CURVES ? (64 - n_idle - n_node - n_tri) : 0;
+      int n_curve = CURVES ? __popcll(__ballot(state == kStCurve)) : 0;
       // vote: the phase that advances the most lanes per instruction issued (a node step is cheaper than a primitive step)
       const int w_node = n_node * PB_W_NODE, w_tri = n_tri * PB_W_TRI, w_curve = n_curve * PB_W_CURVE;
       const int phase = (w_node >= w_tri && w_node >= w_curve) ? 0 : ((!CURVES || w_tri >= w_curve) ? 1 : 2);
@@ -165,7 +181,7 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
       if (phase == 0) {
         // ---- NODE phase
         if (state == kStNode) {
-          if (STATS) (any_ray ? st.anodes : st.nodes)++;
+          if (STATS) (any_ray ? st.anodes : st.nodes)++, steps++;
           uint32_t c0 = __float_as_uint(D3.x), c1 = __float_as_uint(D3.y);
           float t0, t1;
           bool h0, h1;
@@ -189,11 +205,13 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
         }
       } else {
         // ---- TRI / CURVE phase: one primitive per lane
-        const bool mine = (phase == 1) ? (state == kStTri) : (CURVES && state == kStCurve);
+        const bool is_tri = state == kStTri, is_curve = CURVES && state == kStCurve;
+        const bool mine = (phase == 1) ? is_tri : is_curve;
         if (mine) {
+          if (STATS) steps++;
           float t, u, v;
           bool ok;
-          if (!CURVES || phase == 1) {
+          if (!CURVES || is_tri) {
             if (STATS) (any_ray ? st.atris : st.tris)++;
             ok = tri_test(ld3(D0), ld3(D1), ld3(D2), o, d, tmin, t, u, v) && (t <= hit.t);
           } else {
@@ -209,10 +227,12 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
           }
           if (any_ray && ok) {
             state = kStDoneOccluded;
+            if (STATS) st.hist[steps <= 16u ? 0 : (28 - __clz(steps - 1u) > 7 ? 7 : 28 - __clz(steps - 1u))]++, st.max_steps = steps > st.max_steps ? steps : st.max_steps;
+          } else if (rem != 0u) {  // next primitive of the same leaf
+            rem--, cur++;
+            need_load = true;
           } else {
-            cur++;
-            if (cur < end) need_load = true;  // next primitive of the same leaf
-            else advance = true;              // leaf done: pop
+            advance = true;  // leaf done: pop
           }
         }
       }
@@ -223,6 +243,7 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
         if (sp == 0) {
           state = kStDone;
           advance = false;
+          if (STATS) st.hist[steps <= 16u ? 0 : (28 - __clz(steps - 1u) > 7 ? 7 : 28 - __clz(steps - 1u))]++, st.max_steps = steps > st.max_steps ? steps : st.max_steps;
         } else {
           sp--;
           // the LDS read is unconditional (a clamped index), the spill read the rare exception: one ds_read instead of a
@@ -235,7 +256,7 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
         need_load = true;
         if (next & kLeafBit) {
           cur = ((next & 0x3FFFFFFFu) >> 3) + sc.num_nodes;  // slots follow the nodes in one array of 64-byte items
-          end = cur + (next & 7u) + 1u;
+          rem = next & 7u;
           state = (CURVES && (next & kCurveBit)) ? kStCurve : kStTri;
         } else {
           cur = next;

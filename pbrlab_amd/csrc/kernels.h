@@ -27,6 +27,8 @@ struct PathState {
   uint32_t* spill;               // traversal-stack spill area: (kStackDepth - LDS part) x resident threads
   uint32_t* counts;              // kCnt*
   unsigned long long* stats;     // kStat*; null unless the render collects statistics
+  unsigned long long* wave_log;  // debugging (PBRHIP_WAVE_LOG): per k_trace launch and wave: start, end (100 MHz clock), rays, loop turns
+  uint32_t wave_log_launch;      // index of this launch in wave_log
   // First bounce of a chunk: every path still has the camera position as its origin (tmin 0), throughput (1,1,1) and pdf 0,
   // so k_generate does not store ray_o / thr and the first trace and shading do not load them; the only per-path flag
   // ("not the first bounce", MIS weight of emission) is the same bit.
@@ -49,7 +51,8 @@ enum : uint32_t {
   kStatClosestRays = 0, kStatClosestNodes, kStatClosestTris, kStatClosestCurves,
   kStatShadowRays, kStatShadowNodes, kStatShadowTris, kStatShadowCurves,
   kStatPvItNode, kStatPvItTri, kStatPvItCurve, kStatPvItRefill, kStatPvLnNode, kStatPvLnTri, kStatPvLnCurve,
-  kStatTailClosestRays, kStatTailShadowRays, kStatPrunedRays, kStatNum
+  kStatTailClosestRays, kStatTailShadowRays, kStatPrunedRays,
+  kStatStepHist0, kStatStepHistLast = kStatStepHist0 + 7, kStatMaxSteps, kStatMaxWaveIters, kStatNum
 };
 
 // Resident 256-thread blocks per CU of the persistent traversal kernel = waves per SIMD (VGPR budget 512 / waves).
@@ -64,7 +67,8 @@ enum : uint32_t {
 constexpr uint32_t kTraceBlocksPerCU = PB_TRACE_BLOCKS, kTraceBlocksPerCUCurves = PB_TRACE_BLOCKS_CURVES;
 constexpr uint32_t kTraceGridCap = 256 * (kTraceBlocksPerCU > kTraceBlocksPerCUCurves ? kTraceBlocksPerCU : kTraceBlocksPerCUCurves);  // persistent traversal: at most the resident blocks (sizes the spill area)
 constexpr uint32_t kShadeGridCap = 256 * 8;
-constexpr int kMaxGroups = 8;  // concurrent path groups (one HIP stream each)
+constexpr int kMaxGroups = 8;
+constexpr uint32_t kWaveLogWaves = 8192, kWaveLogLaunches = 64;  // PBRHIP_WAVE_LOG buffer: launches x waves x 4 words  // concurrent path groups (one HIP stream each)
 
 struct HookHit {  // == pbrhip_hit == TraceResult (raytracer.h:9-17)
   float ng[3];

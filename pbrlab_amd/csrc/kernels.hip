@@ -108,10 +108,18 @@ __global__ __launch_bounds__(kBlock, (CURVES ? kTraceBlocksPerCUCurves : kTraceB
   TravStats st = {};
   uint32_t overflow = 0u;
   TraceSink sink = {P, n_closest};
+  const unsigned long long t_start = P.wave_log ? wall_clock64() : 0ull;
   trace_pv<2, STATS, CURVES>(sc, n_closest + n_shadow, &P.counts[kCntHead], sink, stk + threadIdx.x, kBlock,
                              P.spill + blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, st, &overflow,
                              CURVES ? frm + threadIdx.x : nullptr);
   if (overflow) P.counts[kCntOverflow] = 1u;
+  if (P.wave_log && __lane_id() == 0 && P.wave_log_launch < kWaveLogLaunches) {
+    const uint32_t w = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+    if (w < kWaveLogWaves) {
+      unsigned long long* o = P.wave_log + ((size_t)P.wave_log_launch * kWaveLogWaves + w) * 4;
+      o[0] = t_start, o[1] = wall_clock64(), o[2] = st.it_refill, o[3] = st.it_node + st.it_tri + st.it_curve;
+    }
+  }
   if (STATS) {
     uint32_t v[13] = {st.nodes, st.tris, st.curves, st.anodes, st.atris, st.acurves, st.it_node, st.it_tri, st.it_curve,
                       st.it_refill, st.ln_node, st.ln_tri, st.ln_curve};
@@ -122,6 +130,12 @@ __global__ __launch_bounds__(kBlock, (CURVES ? kTraceBlocksPerCUCurves : kTraceB
       uint32_t s = wave_sum(v[i]);
       if (__lane_id() == 0 && s) atomicAdd(&P.stats[idx[i]], (unsigned long long)s);
     }
+    for (int i = 0; i < 8; i++) {
+      uint32_t s = wave_sum(st.hist[i]);
+      if (__lane_id() == 0 && s) atomicAdd(&P.stats[kStatStepHist0 + i], (unsigned long long)s);
+    }
+    atomicMax(&P.stats[kStatMaxSteps], (unsigned long long)st.max_steps);
+    if (__lane_id() == 0) atomicMax(&P.stats[kStatMaxWaveIters], (unsigned long long)(st.it_node + st.it_tri + st.it_curve + st.it_refill));
     if (threadIdx.x == 0 && blockIdx.x == 0) {
       atomicAdd(&P.stats[kStatClosestRays], (unsigned long long)n_closest);
       atomicAdd(&P.stats[kStatShadowRays], (unsigned long long)n_shadow);
@@ -783,8 +797,15 @@ __global__ __launch_bounds__(kBlock) void k_sss_step(PathState P, DScene sc, uin
 // path (the shadow ray of bounce k is resolved before anything of bounce k+1 touches L), so results are unchanged.
 // Input: q_in = the paths just traced by k_trace (their hit records are in P.hit).  Traversal is the plain per-lane
 // one (dtrace.h::traverse): with a handful of lanes per wave there is nothing to vote on.
+// Lanes: a wave starts with one path per lane (up to 64).  Once at most 32 of them are alive they are moved to the even
+// lanes and every odd lane becomes its neighbour's helper: it traverses the path's shadow ray while the even lane
+// traverses the continuation ray -- the two dependent-load chains of a bounce run side by side instead of one after the
+// other (what bounds k_tail is the chain of the longest path, not throughput).
+#ifndef PB_TAIL_WAVES
+#define PB_TAIL_WAVES 2  // min waves per SIMD of k_tail (VGPR budget 512 / waves)
+#endif
 template <bool CURVES, bool STATS>
-__global__ __launch_bounds__(kBlock) void k_tail(PathState P, DScene sc, uint64_t rng_inc) {
+__global__ __launch_bounds__(kBlock, PB_TAIL_WAVES) void k_tail(PathState P, DScene sc, uint64_t rng_inc) {
   __shared__ uint32_t stk[kStackDepth * kBlock];
   const uint32_t n = P.counts[kCntIn];
   const uint32_t lane = threadIdx.x & 63u;
@@ -795,37 +816,86 @@ __global__ __launch_bounds__(kBlock) void k_tail(PathState P, DScene sc, uint64_
   uint32_t overflow = 0u, n_closest = 0u, n_shadow = 0u;  // rays traced here (STATS)
   const TraceSink sink = {P, 0u};
   uint32_t* const stack = stk + threadIdx.x;
-  for (uint32_t base = wave * per_wave; base < n; base += nwaves * per_wave) {
-    const uint32_t i = base + lane;
-    if (lane >= per_wave || i >= n) continue;
-    const uint32_t e = P.q_in[i];
-    const uint32_t p = e & kQPathMask;
-    bool in_medium = (e & kQSssBit) != 0u;
-    bool first = P.first != 0u;  // the tail starts at the very first bounce of tiny renders
+  constexpr uint32_t kHave = 0x80000000u, kMedium = 0x40000000u, kFirst = 0x20000000u;  // lane state = path slot | flags
+  for (uint32_t base = wave * per_wave; base < n; base += nwaves * per_wave) {  // (wave-uniform loop)
+    uint32_t state = 0u;
+    if (lane < per_wave && base + lane < n) {
+      const uint32_t e = P.q_in[base + lane];
+      state = (e & kQPathMask) | kHave | ((e & kQSssBit) ? kMedium : 0u) | (P.first ? kFirst : 0u);  // the tail starts at the very first bounce of tiny renders
+    }
+    bool paired = false;
     for (;;) {
-      uint32_t r;
-      if (in_medium) {
-        r = sss_step_path(P, sc, p, rng_inc);
+      const unsigned long long act = __ballot((state & kHave) != 0u);
+      if (act == 0ull) break;
+      if (!paired && __popcll(act) <= 32) {
+        // move the k-th live path to lane 2k (its state is this one word; everything else lives in the path's slot)
+        uint32_t src = lane;
+        bool mine = false;
+        uint32_t k = 0;
+        for (unsigned long long m = act; m; m &= m - 1ull, k++)
+          if (lane == 2u * k) src = (uint32_t)__builtin_ctzll(m), mine = true;
+        const uint32_t moved = (uint32_t)__shfl((int)state, (int)src);
+        state = mine ? moved : 0u;
+        paired = true;
+      }
+      const uint32_t p = state & kQPathMask;
+      uint32_t r = 0u;
+      if (state & kHave) {
+        if (state & kMedium) {
+          r = sss_step_path(P, sc, p, rng_inc);
+        } else {
+          const uint32_t slot = __float_as_uint(P.hit[p].w);
+          if (slot != kNone)  // a miss ends the path (render.cc:34)
+            r = (slot & kHitHair) ? shade_hair_path(P, sc, p, rng_inc, (state & kFirst) != 0u)
+                                  : shade_principled_path(P, sc, p, rng_inc, (state & kFirst) != 0u);
+        }
+        state &= ~kFirst;
+      }
+      const bool want_shadow = (r & kRShadow) != 0u, want_closest = (r & kRAlive) != 0u;
+      if (!paired) {
+        if (want_shadow) {
+          const float4 o4 = P.ray_o[p], d4 = P.sh_d[p];
+          Hit h;
+          const bool occluded = traverse<true, false, CURVES>(sc, ld3(o4), ld3(d4), o4.w, d4.w, h, stack, kBlock, st, &overflow);
+          sink.done(p | 0x80000000u, h, occluded);
+          n_shadow++;
+        }
+        if (want_closest) {
+          const float4 o4 = P.ray_o[p], d4 = P.ray_d[p];
+          Hit h;
+          traverse<false, false, CURVES>(sc, ld3(o4), ld3(d4), o4.w, d4.w, h, stack, kBlock, st, &overflow);
+          P.hit[p] = make_float4(h.t, h.u, h.v, __uint_as_float(h.slot));
+          n_closest++;
+        }
       } else {
-        const uint32_t slot = __float_as_uint(P.hit[p].w);
-        if (slot == kNone) break;  // miss: the path ends (render.cc:34)
-        r = (slot & kHitHair) ? shade_hair_path(P, sc, p, rng_inc, first) : shade_principled_path(P, sc, p, rng_inc, first);
+        // even lane: the path and its continuation ray; odd lane: the shadow ray of the even lane to its left
+        const bool odd = (lane & 1u) != 0u;
+        float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f), d4 = o4, s4 = o4;
+        if (want_shadow || want_closest) o4 = P.ray_o[p];
+        if (want_closest) d4 = P.ray_d[p];
+        if (want_shadow) s4 = P.sh_d[p];
+        const int left = (int)(lane & ~1u);
+        const float sx = __shfl(s4.x, left), sy = __shfl(s4.y, left), sz = __shfl(s4.z, left), sw = __shfl(s4.w, left);
+        const float ox = __shfl(o4.x, left), oy = __shfl(o4.y, left), oz = __shfl(o4.z, left), ow = __shfl(o4.w, left);
+        const bool left_shadow = __shfl((int)want_shadow, left) != 0;
+        bool go = want_closest;
+        if (odd) o4 = make_float4(ox, oy, oz, ow), d4 = make_float4(sx, sy, sz, sw), go = left_shadow;
+        Hit h = {0.f, 0.f, 0.f, kNone};
+        bool occluded = false;
+        if (go) occluded = traverse_mode<2, false, CURVES>(sc, ld3(o4), ld3(d4), o4.w, d4.w, h, stack, kBlock, st, &overflow, odd);
+        const bool occ_right = __shfl((int)occluded, (int)(lane | 1u)) != 0;
+        if (want_shadow) {
+          Hit none = {0.f, 0.f, 0.f, kNone};
+          sink.done(p | 0x80000000u, none, occ_right);  // (a shadow ray's result is the one bit)
+          n_shadow++;
+        }
+        if (want_closest) {
+          P.hit[p] = make_float4(h.t, h.u, h.v, __uint_as_float(h.slot));
+          n_closest++;
+        }
       }
-      first = false;
-      if (r & kRShadow) {
-        const float4 o4 = P.ray_o[p], d4 = P.sh_d[p];
-        Hit h;
-        const bool occluded = traverse<true, false, CURVES>(sc, ld3(o4), ld3(d4), o4.w, d4.w, h, stack, kBlock, st, &overflow);
-        sink.done(p | 0x80000000u, h, occluded);
-        n_shadow++;
-      }
-      if (!(r & kRAlive)) break;
-      in_medium = (r & kQSssBit) != 0u;
-      const float4 o4 = P.ray_o[p], d4 = P.ray_d[p];
-      Hit h;
-      traverse<false, false, CURVES>(sc, ld3(o4), ld3(d4), o4.w, d4.w, h, stack, kBlock, st, &overflow);
-      P.hit[p] = make_float4(h.t, h.u, h.v, __uint_as_float(h.slot));
-      n_closest++;
+      if (!want_closest) state = 0u;
+      else state = (state & ~kMedium) | ((r & kQSssBit) ? kMedium : 0u);
     }
   }
   if (overflow) P.counts[kCntOverflow] = 1u;
@@ -976,8 +1046,13 @@ void launch_generate(hipStream_t s, const PathState& P, const Camera& cam, const
                      width, first_pass, seed_seq);
 }
 void launch_trace(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, bool stats) {
-  // persistent kernel: the resident set, unless there are so few rays that 4 per wave need fewer blocks
-  uint32_t blocks = (n_upper + 15u) / 16u;
+  // Persistent kernel: at most the resident set.  A launch with fewer rays than that would fill gets fewer waves, so that
+  // every wave still has a queue to refill its lanes from (kRaysPerWave rays each): a wave that starts with one ray per
+  // lane and nothing to refill from runs until its longest ray ends with most lanes idle, and with seven such waves per
+  // SIMD the launch is bound by the instructions those mostly empty waves issue.
+  const char* e = getenv("PBRHIP_RAYS_PER_WAVE");  // (tuning knob; read per launch)
+  const uint32_t rays_per_wave = e ? (uint32_t)strtoul(e, nullptr, 10) : 4u;
+  uint32_t blocks = (n_upper + 4u * rays_per_wave - 1u) / (4u * rays_per_wave);
   const bool curves = sc.num_curves != 0;
   const uint32_t cap = 256u * (curves ? kTraceBlocksPerCUCurves : kTraceBlocksPerCU);
   dim3 g(blocks < 1u ? 1u : (blocks < cap ? blocks : cap));

@@ -832,13 +832,12 @@ static uint32_t env_u32(const char* name, uint32_t dflt) {
   return e ? (uint32_t)strtoul(e, nullptr, 10) : dflt;
 }
 
-// How the passes of a chunk are split into path groups (each group = its own queues, counters and HIP stream).
-// The end of every group is latency-bound: a few launch-bound wavefront iterations, then k_tail, whose duration is the
-// dependent chain of the group's longest path (tens of bounces).  Groups therefore run as a pipeline: the first, largest
-// one starts alone; the next one starts as soon as fewer than `window` groups are still in their bulk phase, so one
-// group's tail hides behind the next one's bulk work; sizes shrink geometrically so that the last group -- the only
-// one whose tail nothing can hide -- is small (short bulk, shorter longest path).  Path slots stay global and passes are
-// accumulated in ascending order, so the image does not depend on the split (GPU test).
+// How the passes of a chunk are split into path groups (each group = its own queues, counters and HIP stream; path
+// slots stay global and passes are accumulated in ascending order, so the image does not depend on the split: GPU test).
+// The scheduler in render_impl starts groups in order while fewer than `window` of them are in their bulk phase (default:
+// all at once).  PBRHIP_GROUPS="56,8" (passes per group, started one after the other: PBRHIP_WINDOW defaults to 1 then)
+// and pbrhip_render_desc.num_streams = n (n equal groups at once) override the default plan; the pipelined plans that
+// were tried (geometric sizes, big-then-small pairs) all lost to it, see profiles/README.md.
 static std::vector<uint32_t> plan_groups(uint32_t np, uint32_t npix, uint32_t want_groups) {
   std::vector<uint32_t> g;
   if (const char* e = getenv("PBRHIP_GROUPS")) {  // explicit passes per group, e.g. "32,16,8,4,2,1,1" (the rest joins the last)
@@ -860,15 +859,12 @@ static std::vector<uint32_t> plan_groups(uint32_t np, uint32_t npix, uint32_t wa
     for (uint32_t k = 0; k < ng; k++) g.push_back((uint32_t)((uint64_t)np * (k + 1) / ng) - (uint32_t)((uint64_t)np * k / ng));
     return g;
   }
-  // default: halve until a group would hold fewer than min_paths paths
-  const uint64_t min_paths = env_u32("PBRHIP_GROUP_MIN_PATHS", 1u << 20);
-  uint32_t left = np;
-  while (left) {
-    uint32_t v = (left + 1) / 2;
-    if ((uint64_t)v * npix < min_paths || g.size() + 1 >= (size_t)kMaxGroups * 2) v = left;
-    else if ((uint64_t)(left - v) * npix < min_paths) v = left;
-    g.push_back(v), left -= v;
-  }
+  // default (A/B on C2, scripts/sched_ab.py, profiles/README.md): two equal groups, both started at once, when the chunk
+  // holds at least 96 Mi paths (the whole 132.7 M-path frame: 60.4 -> 58.9 ms; one group's launch-bound drains and its
+  // k_tail overlap the other's bulk work); one group below that (a half / quarter / eighth of the frame: 32.6 / 19.7 /
+  // 12.1 ms with one group against 32.2 / 19.9 / 12.8 with two -- every extra group adds its own latency-bound launches)
+  if ((uint64_t)np * npix >= (96ull << 20) && np >= 2) g.push_back(np / 2), g.push_back(np - np / 2);
+  else g.push_back(np);
   return g;
 }
 
@@ -934,6 +930,17 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
     P.sh_d = s->sh[0].p, P.sh_c = s->sh[1].p, P.sh_e = s->sh[2].p;
     P.counts = s->counts.p, P.stats = want_stats ? s->stats.p : nullptr, P.spill = s->spill.p;
     P.first = 0u, P.cam_org[0] = P.cam_org[1] = P.cam_org[2] = 0.f;
+    P.wave_log = nullptr, P.wave_log_launch = 0;
+    // debugging aid: PBRHIP_WAVE_LOG=<file> with PBRHIP_RENDER_STATS dumps start / end / turns of every wave of every
+    // k_trace launch (scripts/wave_log.py reads it)
+    DevBuf<unsigned long long> wave_log;
+    const char* wave_log_path = getenv("PBRHIP_WAVE_LOG");
+    uint32_t wave_log_launches = 0;
+    if (wave_log_path) {
+      HIPCHK(wave_log.reserve((size_t)kWaveLogLaunches * kWaveLogWaves * 4));
+      HIPCHK(hipMemsetAsync(wave_log.p, 0, sizeof(unsigned long long) * kWaveLogLaunches * kWaveLogWaves * 4, st));
+      P.wave_log = wave_log.p;
+    }
     HIPCHK(hipMemsetAsync(s->stats.p, 0, sizeof(unsigned long long) * kStatNum, st));
     const Camera cam = make_camera(s, d->width, d->height);
     const uint64_t rng_inc = (d->seed_seq << 1u) | 1u;  // pcg32_srandom (rng.h:30-36)
@@ -943,9 +950,11 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
     if (const char* e = getenv("PBRHIP_TAIL_PATHS")) tail_paths = (uint32_t)strtoul(e, nullptr, 10);  // 0 = never
     uint32_t want_groups = d->num_streams;
     if (const char* e = getenv("PBRHIP_STREAMS")) want_groups = (uint32_t)atoi(e);
-    // at most `window` groups in their bulk phase (more live paths than bulk_frac of what they started with) at a time
-    const uint32_t window = std::max(1u, env_u32("PBRHIP_WINDOW", want_groups ? kMaxGroups : 2u));
-    const double bulk_frac = 1.0 / std::max(1u, env_u32("PBRHIP_BULK_DIV", 8u));
+    // at most `window` groups in their bulk phase at a time; a group is in its bulk phase until it has handed its
+    // remaining paths to k_tail (or, with PBRHIP_BULK_DIV = k, until fewer than 1/k of its paths are alive)
+    const uint32_t window = std::max(1u, env_u32("PBRHIP_WINDOW", getenv("PBRHIP_GROUPS") ? 1u : (uint32_t)kMaxGroups));
+    const uint32_t bulk_div = env_u32("PBRHIP_BULK_DIV", 0u);
+    const bool trace_sched = getenv("PBRHIP_TRACE_SCHED") != nullptr;
     if (int rc = ensure_groups(s, kMaxGroups)) return rc;
     struct Group {
       PathState P;
@@ -985,6 +994,7 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
           // few live paths: trace this bounce (and the pending shadow rays), then finish every path in one launch
           gr.P.first = gr.iters++ == 0 ? 1u : 0u;
           HIPCHK(gr.tm.begin(&S.ms_trace_closest));
+          gr.P.wave_log_launch = wave_log_launches++;
           launch_trace(gst, gr.P, sc, 2 * n, want_stats);
           HIPCHK(gr.tm.end());
           HIPCHK(gr.tm.begin(&S.ms_tail));
@@ -998,6 +1008,7 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
         for (int it = 0; it < burst; it++) {
           gr.P.first = gr.iters++ == 0 ? 1u : 0u;
           HIPCHK(gr.tm.begin(&S.ms_trace_closest));
+          gr.P.wave_log_launch = wave_log_launches++;
           launch_trace(gst, gr.P, sc, 2 * n, want_stats);  // this bounce's closest rays + last bounce's shadow rays
           HIPCHK(gr.tm.end());
           HIPCHK(gr.tm.begin(&S.ms_surface));
@@ -1055,7 +1066,7 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
         while (!stop && next_start < ng) {
           uint32_t bulk = 0;
           for (const Group& gr : G)
-            if (gr.started && !gr.finished && (double)gr.n > bulk_frac * (double)gr.n0) bulk++;
+            if (gr.started && !gr.finished && gr.n > std::max<uint64_t>(tail_paths, bulk_div ? gr.n0 / bulk_div : 0u)) bulk++;
           int lane = -1;
           for (int l = 0; l < kMaxGroups; l++)
             if (!lane_busy[l]) {
@@ -1078,6 +1089,10 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
           const uint32_t* hc = lane_hcounts(gr.lane);
           if (hc[kCntOverflow]) return fail(PBRHIP_EOVERFLOW, "BVH traversal stack overflow");
           gr.n = std::max(hc[kCntIn], hc[kCntShadowIn]);  // pending shadow rays need one more trace
+          if (trace_sched)
+            fprintf(stderr, "sched %8.3f ms  group %d (passes %u)  iter %u  live %u\n",
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(),
+                    (int)(&gr - G.data()), gr.npass, gr.iters, gr.n);
           if (gr.n == 0 || stop) {  // complete -- or abandoned: a cancelled render drops what is in flight
             gr.finished = gr.n == 0;
             if (!gr.finished) gr.started = false;
@@ -1111,6 +1126,14 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
       S.chunks++;
     }
     HIPCHK(hipStreamSynchronize(st));
+    if (wave_log_path) {
+      std::vector<unsigned long long> h((size_t)kWaveLogLaunches * kWaveLogWaves * 4);
+      HIPCHK(hipMemcpy(h.data(), wave_log.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+      if (FILE* f = fopen(wave_log_path, "wb")) {
+        fwrite(h.data(), sizeof(unsigned long long), h.size(), f);
+        fclose(f);
+      }
+    }
     if (want_stats) {
       unsigned long long hs[kStatNum];
       HIPCHK(hipMemcpy(hs, s->stats.p, sizeof(hs), hipMemcpyDeviceToHost));
@@ -1126,6 +1149,11 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
                 hs[kStatPvLnNode] / (double)std::max<unsigned long long>(1, hs[kStatPvItNode]),
                 hs[kStatPvLnTri] / (double)std::max<unsigned long long>(1, hs[kStatPvItTri]),
                 hs[kStatPvLnCurve] / (double)std::max<unsigned long long>(1, hs[kStatPvItCurve]));
+      if (getenv("PBRHIP_PV_STATS")) {
+        fprintf(stderr, "pv steps per ray (<=16, 32, 64, 128, 256, 512, 1024, more):");
+        for (int i = 0; i < 8; i++) fprintf(stderr, " %llu", hs[kStatStepHist0 + i]);
+        fprintf(stderr, " | max %llu | most loop turns of one wave (whole render) %llu\n", hs[kStatMaxSteps], hs[kStatMaxWaveIters]);
+      }
     }
   } else {
     HIPCHK(hipStreamSynchronize(st));

@@ -15,25 +15,28 @@ W, H = 1920, 1080
 rgba = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda"); cnt = torch.zeros((H, W), dtype=torch.int32, device="cuda")
 torch.cuda.synchronize()
 REPS = int(os.environ.get("REPS", "3"))
-KEYS = ("PBRHIP_GROUPS", "PBRHIP_WINDOW", "PBRHIP_BULK_DIV", "PBRHIP_GROUP_MIN_PATHS", "PBRHIP_STREAMS", "PBRHIP_TAIL_PATHS")
+KEYS = ("PBRHIP_RAYS_PER_WAVE", "PBRHIP_GROUPS", "PBRHIP_WINDOW", "PBRHIP_BULK_DIV", "PBRHIP_GROUP_MIN_PATHS", "PBRHIP_STREAMS", "PBRHIP_TAIL_PATHS")
 CONFIGS = [
-    {},                                                     # library default
     {"PBRHIP_STREAMS": "1"},
     {"PBRHIP_STREAMS": "2"},                                 # round 1's default for big chunks
-    {"PBRHIP_STREAMS": "4"},
-    {"PBRHIP_WINDOW": "1"},
-    {"PBRHIP_WINDOW": "3"},
-    {"PBRHIP_BULK_DIV": "4"},
-    {"PBRHIP_BULK_DIV": "16"},
-    {"PBRHIP_BULK_DIV": "64"},
-    {"PBRHIP_GROUP_MIN_PATHS": "262144"},
-    {"PBRHIP_GROUP_MIN_PATHS": "4194304"},
-    {"PBRHIP_GROUPS": "16,16,16,8,4,2,1,1"},
-    {"PBRHIP_GROUPS": "24,16,8,8,4,2,1,1"},
-    {"PBRHIP_GROUPS": "16,16,16,16"},
-    {"PBRHIP_GROUPS": "8,8,8,8,8,8,8,4,2,1,1", "PBRHIP_WINDOW": "2"},
-    {"PBRHIP_GROUPS": "8,8,8,8,8,8,8,4,2,1,1", "PBRHIP_WINDOW": "3"},
+    {"PBRHIP_GROUPS": "62,2"},
+    {"PBRHIP_GROUPS": "60,4"},
+    {"PBRHIP_GROUPS": "56,8"},
+    {"PBRHIP_GROUPS": "48,16"},
+    {"PBRHIP_GROUPS": "32,32"},
+    {"PBRHIP_GROUPS": "48,12,4"},
+    {"PBRHIP_GROUPS": "56,6,2"},
+    {"PBRHIP_GROUPS": "60,3,1"},
+    {"PBRHIP_GROUPS": "56,8", "PBRHIP_BULK_DIV": "8"},
+    {"PBRHIP_GROUPS": "56,8", "PBRHIP_BULK_DIV": "3"},
+    {"PBRHIP_GROUPS": "56,8", "PBRHIP_TAIL_PATHS": "1048576"},
+    {"PBRHIP_GROUPS": "56,8", "PBRHIP_TAIL_PATHS": "65536"},
+    {"PBRHIP_STREAMS": "1", "PBRHIP_TAIL_PATHS": "1048576"},
+    {"PBRHIP_STREAMS": "1", "PBRHIP_TAIL_PATHS": "65536"},
 ]
+if os.environ.get("SCHED_CONFIGS"):
+    import json
+    CONFIGS = json.loads(os.environ["SCHED_CONFIGS"])
 
 
 def best(world, rank=0, **kw):
@@ -59,3 +62,15 @@ for cfg in CONFIGS:
     t2, _ = best(2)
     print(f"{str(cfg):90s} world1 {t1:6.2f} ms ({st1['iterations']:3d} it)  1/2 {t2:6.2f} ({t1 / t2:.2f}x)  1/4 {t4:6.2f} ({t1 / t4:.2f}x)  "
           f"1/8 {t8:6.2f} ms ({st8['iterations']:3d} it, {t1 / t8:.2f}x)", flush=True)
+
+# where the time of rank 0's eighth goes (one group), and its timeline
+for k in KEYS:
+    os.environ.pop(k, None)
+os.environ["PBRHIP_STREAMS"] = "1"
+_, st = api.Render(s, W, H, spp, tile_rank=0, tile_world=8, device_out=(rgba.data_ptr(), cnt.data_ptr()), shard_block=16, flags=api.RENDER_TIMING)
+print("1/8, one group, per-kernel ms:", {k: round(v, 2) for k, v in st.items() if k.startswith("ms_")})
+os.environ["PBRHIP_TRACE_SCHED"] = "1"
+api.Render(s, W, H, spp, tile_rank=0, tile_world=8, device_out=(rgba.data_ptr(), cnt.data_ptr()), shard_block=16)
+os.environ["PBRHIP_GROUPS"] = "56,8"
+os.environ.pop("PBRHIP_STREAMS")
+api.Render(s, W, H, spp, tile_rank=0, tile_world=8, device_out=(rgba.data_ptr(), cnt.data_ptr()), shard_block=16)

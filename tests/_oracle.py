@@ -9,7 +9,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-ORACLE_SO = os.path.join(ORACLE_DIR, "libpbr_oracle.so")
+ORACLE_SO = os.environ.get("PBR_ORACLE_SO") or os.path.join(ORACLE_DIR, "libpbr_oracle.so")  # PBR_ORACLE_SO: another build (bench.py)
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libref_leaf.so")
 
 MATH_LIBM, MATH_F64R = 0, 1

@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:  # torch carries its own HIP runtime: it must be in the process before libpbrhip.so pulls in /opt/rocm's
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
