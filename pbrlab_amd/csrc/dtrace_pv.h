@@ -52,6 +52,10 @@ enum : uint32_t { kStIdle = 0, kStNode = 1, kStTri = 2, kStCurve = 3, kStDone = 
 // Sink: what to do with a finished ray.  closest: store the hit record; shadow: resolve the contribution.
 //   bool load(uint32_t idx, uint32_t& tag, V3& o, V3& d, float& tmin, float& tmax)   returns "any-hit ray"
 //   void done(uint32_t tag, const Hit& h, bool occluded)
+// A WALKING sink (Sink::kWalk, the random walk of subsurface scattering: k_sss_walk) chains rays: its queue entries arrive
+// with a hit that is already known, and every finished ray is followed by the next one of the same walk:
+//   void start(uint32_t idx, uint32_t& tag, Hit& h, V3& o, V3& d)                     the entry's ray and its known hit
+//   bool next(uint32_t tag, const Hit& h, V3& o, V3& d, float& tmin, float& tmax)     one step; true = trace this ray next
 // MODE: 0 = every ray wants its closest hit, 1 = every ray is an any-hit (shadow) ray, 2 = per ray (load()'s
 // return value): closest-hit rays of bounce k+1 and shadow rays of bounce k share one launch and one drain.
 // Traversal stack: the first kPvLdsStack entries of each lane live in LDS (stk_base[i * stride]), deeper ones
@@ -103,6 +107,7 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
     }
     return;
   }
+  if (Sink::kWalk && sc.num_nodes == 0) return;  // (nothing can be inside a medium of an empty scene)
 
   // per-lane state
   uint32_t state = kStIdle, tag = 0;
@@ -123,9 +128,10 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
     uint32_t next = 0;
     unsigned long long idle_mask = __ballot(state == kStIdle || state >= kStDone);
     int n_idle = __popcll(idle_mask);
-    if (!exhausted && (n_idle >= kPvRefillIdle)) {
+    // (a walking sink has work for its finished lanes even when the queue is empty: their walks go on)
+    if (n_idle >= kPvRefillIdle && (!exhausted || (Sink::kWalk && __ballot(state >= kStDone) != 0ull))) {
       // ---- refill idle lanes from the queue
-      if (batch_cur == batch_end) {
+      if (!exhausted && batch_cur == batch_end) {
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(head, batch);
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)base, 0));
@@ -140,17 +146,38 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
           batch = nb > kPvBatch ? kPvBatch : (nb < 64u ? 64u : nb);
         }
       }
+      bool fresh = false;  // the lane has a new ray in (o, d, tmin, hit.t)
       if (state >= kStDone) {
-        sink.done(tag, hit, state == kStDoneOccluded);
-        state = kStIdle;
+        if constexpr (Sink::kWalk) {
+          float tmax = 0.f;
+          fresh = sink.next(tag, hit, o, d, tmin, tmax);
+          hit.t = tmax;
+          if (!fresh) state = kStIdle;
+        } else {
+          sink.done(tag, hit, state == kStDoneOccluded);
+          state = kStIdle;
+        }
+      }
+      if constexpr (Sink::kWalk) {
+        idle_mask = __ballot(state == kStIdle);  // (lanes whose walk goes on take no new entry)
+        n_idle = __popcll(idle_mask);
       }
       uint32_t avail = batch_end - batch_cur;
       uint32_t take = (uint32_t)n_idle < avail ? (uint32_t)n_idle : avail;
       uint32_t rank = rank_in(idle_mask);
       if (state == kStIdle && rank < take) {
-        float tmax;
-        bool a = sink.load(batch_cur + rank, tag, o, d, tmin, tmax);
-        any_ray = (MODE == 1) || (MODE == 2 && a);
+        if constexpr (Sink::kWalk) {
+          sink.start(batch_cur + rank, tag, hit, o, d);
+          state = kStDone;  // its first step runs at the next refill, together with the other lanes'
+        } else {
+          float tmax;
+          bool a = sink.load(batch_cur + rank, tag, o, d, tmin, tmax);
+          any_ray = (MODE == 1) || (MODE == 2 && a);
+          hit.t = tmax;
+          fresh = true;
+        }
+      }
+      if (fresh) {
         inv = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
         if (CURVES) {
           const RayFrame f = ray_frame(d);
@@ -158,7 +185,7 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
 #pragma unroll
           for (int k = 0; k < 10; k++) frame[(uint32_t)k * stride] = w[k];
         }
-        hit.t = tmax, hit.u = 0.f, hit.v = 0.f, hit.slot = kNone;
+        hit.u = 0.f, hit.v = 0.f, hit.slot = kNone;
         sp = 0, steps = 0;
         advance = true, have_next = true, next = 0u;  // root is always an internal node
       }
@@ -270,7 +297,9 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
       if (state == kStNode) D3 = *reinterpret_cast<const float2*>(g + 3);
     }
   }
-  if (state >= kStDone) sink.done(tag, hit, state == kStDoneOccluded);  // rays that finished after the queue ran dry
+  if constexpr (!Sink::kWalk) {
+    if (state >= kStDone) sink.done(tag, hit, state == kStDoneOccluded);  // rays that finished after the queue ran dry
+  }
 }
 
 }  // namespace pb

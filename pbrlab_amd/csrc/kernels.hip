@@ -65,6 +65,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(PathState P, Camera cam, co
 //                kShSssEntry A  = 0 + c_vis when unoccluded (first NEE of a path that entered the medium)
 //                kShSssExit  L += unoccluded ? c_vis : c_occ
 struct TraceSink {
+  static constexpr bool kWalk = false;
   const PathState& P;
   uint32_t n_closest;
   __device__ __forceinline__ bool load(uint32_t idx, uint32_t& tag, V3& o, V3& d, float& tmin, float& tmax) const {
@@ -645,7 +646,47 @@ __global__ __launch_bounds__(kBlock) void k_shade_hair(PathState P, DScene sc, u
 // One iteration of RandomWalkSubsurface's loop after its TraceFirstHit1 (random-walk-sss.h:314-405),
 // then either the next step's direction/distance sampling (:287-311) or the exit: second NEE + diffuse
 // re-sample (cycles-principled-shader.cc:197-216) and the tail of CyclesPrincipledShader (:467-483).
-__device__ __forceinline__ uint32_t sss_step_path(const PathState& P, const DScene& sc, uint32_t p, uint64_t rng_inc) {
+// State of a random walk between two events (random-walk-sss.h:287-311): the bounded ray (org, dir, t_scatter), the
+// medium (sigma_t, sigma_s), the walk's throughput, the step index and the path's generator.
+struct WalkState {
+  V3 org, dir, sigt, sigs, wthr;
+  float t_scatter;
+  uint32_t bounce;
+  uint64_t rng_state;
+};
+// The event after a bounded ray that hit nothing: scatter at its end (random-walk-sss.h:333-366, :287-311): throughput
+// update, Russian roulette, the step bound, then the next isotropic direction and scatter distance.  Returns false when
+// the walk FAILS here (roulette, or more than 8192 steps); then `w` is left untouched.  Shared by the wavefront's step
+// (sss_step_path) and by the fast-forward kernel (k_sss_walk), so both compute the very same values.
+__device__ __forceinline__ bool sss_scatter(WalkState& w, uint64_t rng_inc) {
+  const V3 chpdf = scatter_channel_pdf(w.wthr, w.sigs, w.sigt);  // what sample_scatter_distance computed when it drew this step's distance
+  const V3 trans = attenuate_transmission(w.sigt, w.t_scatter);
+  float pdf = dot(chpdf, w.sigt * trans);
+  V3 wthr = w.wthr * (w.sigs * trans) / pdf;
+  float pr = saturate(spectrum_norm(wthr));
+  Rng rng = {w.rng_state, rng_inc};
+  float q = draw(rng);
+  if (q >= pr) return false;
+  wthr = wthr / pr;
+  const V3 org = w.org + w.t_scatter * w.dir;
+  const uint32_t bounce = w.bounce + 1u;
+  if (bounce > 8192u) return false;  // loop bound :287
+  // next step: isotropic direction; g++ evaluates UniformSampleSphere(Draw(), Draw()) right-to-left,
+  // so the FIRST draw is u2 (:296)
+  float first = draw(rng);
+  float second = draw(rng);
+  V3 wi = vnormalize(uniform_sample_sphere(second, first));
+  float e0 = draw(rng);
+  float e1 = draw(rng);
+  V3 chpdf_next;
+  float t_scatter = sample_scatter_distance(wthr, w.sigs, w.sigt, e0, e1, chpdf_next);
+  w.org = org, w.dir = wi, w.wthr = wthr, w.t_scatter = t_scatter, w.bounce = bounce, w.rng_state = rng.state;
+  return true;
+}
+
+// hreg: the hit of the path's bounded ray when the caller holds it in registers, else it is read from P.hit.
+__device__ __forceinline__ uint32_t sss_step_path(const PathState& P, const DScene& sc, uint32_t p, uint64_t rng_inc,
+                                                  const Hit* hreg = nullptr) {
   {
     const bool active = true;
     bool alive = false, shadow = false;
@@ -654,52 +695,43 @@ __device__ __forceinline__ uint32_t sss_step_path(const PathState& P, const DSce
     Nee nee;
     nee.dir = V3(0.f), nee.emission = V3(0.f), nee.dist = 0.f, nee.pdf_sigma = 0.f;
     if (active) {
-      float4 h4 = P.hit[p], o4 = P.ray_o[p], d4 = P.ray_d[p];
+      float4 o4 = P.ray_o[p], d4 = P.ray_d[p];
       float4 st4 = P.sss_sigt[p], ss4 = P.sss_sigs[p], wt4 = P.sss_thr[p];
-      Hit h = {h4.x, h4.y, h4.z, __float_as_uint(h4.w)};
+      Hit h;
+      if (hreg) {
+        h = *hreg;
+      } else {
+        const float4 h4 = P.hit[p];
+        h.t = h4.x, h.u = h4.y, h.v = h4.z, h.slot = __float_as_uint(h4.w);
+      }
       V3 org = ld3(o4), dir = ld3(d4), sigt = ld3(st4), sigs = ld3(ss4), wthr = ld3(wt4);
-      V3 chpdf = scatter_channel_pdf(wthr, sigs, sigt);  // what sample_scatter_distance computed when it drew this step's distance
       uint32_t bounce = __float_as_uint(wt4.w), entry_inst = __float_as_uint(ss4.w);
       Rng rng = {P.rng[p], rng_inc};
       bool hit = (h.slot != kNone);
-      float t = hit ? h.t : d4.w;  // d4.w = t_scatter
-      V3 trans = attenuate_transmission(sigt, t);
       bool fail = false, exited = false;
       if (hit) {
+        V3 chpdf = scatter_channel_pdf(wthr, sigs, sigt);  // what sample_scatter_distance computed when it drew this step's distance
+        V3 trans = attenuate_transmission(sigt, h.t);
         float pdf = dot(chpdf, trans);
         wthr = wthr * trans / pdf;
         exited = true;
       } else {
-        float pdf = dot(chpdf, sigt * trans);
-        wthr = wthr * (sigs * trans) / pdf;
-        float pr = saturate(spectrum_norm(wthr));
-        float q = draw(rng);
-        if (q >= pr) {
+        WalkState w = {org, dir, sigt, sigs, wthr, d4.w /* = t_scatter */, bounce, rng.state};
+        if (!sss_scatter(w, rng_inc)) {
           fail = true;
         } else {
-          wthr = wthr / pr;
-          org = org + t * dir;
-          bounce++;
-          if (bounce > 8192u) fail = true;  // loop bound :287
+          P.ray_o[p] = mk4(w.org, 0.f);
+          P.ray_d[p] = mk4(w.dir, w.t_scatter);
+          P.sss_thr[p] = mk4(w.wthr, __uint_as_float(w.bounce));
+          P.rng[p] = w.rng_state;
+          alive = true;
+          qbit = kQSssBit;
         }
       }
       V3 thr = ld3(P.thr[p]);
       V3 A = ld3(P.sss_A[p]);
-      if (!fail && !exited) {
-        // next step: isotropic direction; g++ evaluates UniformSampleSphere(Draw(), Draw()) right-to-left,
-        // so the FIRST draw is u2 (:296)
-        float first = draw(rng);
-        float second = draw(rng);
-        V3 wi = vnormalize(uniform_sample_sphere(second, first));
-        float e0 = draw(rng);
-        float e1 = draw(rng);
-        float t_scatter = sample_scatter_distance(wthr, sigs, sigt, e0, e1, chpdf);
-        P.ray_o[p] = mk4(org, 0.f);
-        P.ray_d[p] = mk4(wi, t_scatter);
-        P.sss_thr[p] = mk4(wthr, __uint_as_float(bounce));
-        P.rng[p] = rng.state;
-        alive = true;
-        qbit = kQSssBit;
+      if (alive) {
+        // (the walk goes on: nothing else to do)
       } else if (exited) {
         uint32_t exit_inst;
         Surface s = make_surface(sc, org, dir, h, &exit_inst);  // :369
@@ -785,6 +817,93 @@ __global__ __launch_bounds__(kBlock) void k_sss_step(PathState P, DScene sc, uin
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
     const uint32_t p = P.q_sss[i];
     P.q_sss[i] = p | sss_step_path(P, sc, p, rng_inc);
+  }
+}
+
+// ------------------------------------------------------------------ k_sss_walk
+// Fast-forward of the random walks (RandomWalkSubsurface's loop, random-walk-sss.h:287-405).  A walk alternates a bounded
+// closest-hit ray with an event: most events are plain scatterings (the ray hit nothing: new direction, new distance),
+// the last one is the exit (the ray hit the boundary) or the walk's failure.  One wavefront iteration per event cost a C3
+// frame ~470 iterations of trace / classify / step / compact over mostly in-medium paths.  This kernel runs between
+// k_classify and k_sss_step: a lane takes an in-medium path whose pending event is a scattering, keeps the walk's state in
+// registers, applies the event (sss_scatter: the code the step kernel itself runs), traces the next bounded ray with the
+// persistent phase-voting traversal (dtrace_pv.h), and repeats until the pending event is no plain scattering any more --
+// a hit, or a scattering that fails (which is NOT applied).  It then leaves the path exactly as the wavefront would have
+// left it before that event (ray, throughput, step index, generator state, hit record), and k_sss_step handles the event
+// as it always did.  A path therefore spends one or two wavefront iterations inside a medium instead of one per step; the
+// values computed are the same, in the same order.
+struct WalkSink {
+  static constexpr bool kWalk = true;
+  const PathState& P;
+  uint64_t rng_inc;
+  // What a walk carries besides its ray (which the traversal holds in registers anyway) lives in LDS, 9 words per lane
+  // (wl[k * kBlock]): throughput, scatter distance, step index, generator state, scatterings applied, path slot.  sigma_t /
+  // sigma_s are re-read from the path state each step.  This keeps the kernel's registers at the traversal's.
+  float* wl;
+  uint32_t n_rays;  // rays traced by this lane (STATS)
+  __device__ __forceinline__ void start(uint32_t idx, uint32_t& tag, Hit& h, V3& o, V3& d) {
+    tag = idx;
+    const uint32_t p = P.q_sss[idx] & kQPathMask;
+    const float4 h4 = P.hit[p];
+    h.t = h4.x, h.u = h4.y, h.v = h4.z, h.slot = __float_as_uint(h4.w);
+    wl[7 * kBlock] = __uint_as_float(0u), wl[8 * kBlock] = __uint_as_float(p);
+    if (h.slot == kNone) {  // a scattering is pending: fetch the walk
+      const float4 o4 = P.ray_o[p], d4 = P.ray_d[p], wt4 = P.sss_thr[p];
+      const uint64_t r = P.rng[p];
+      o = ld3(o4), d = ld3(d4);
+      wl[0] = wt4.x, wl[kBlock] = wt4.y, wl[2 * kBlock] = wt4.z, wl[3 * kBlock] = d4.w, wl[4 * kBlock] = wt4.w;
+      wl[5 * kBlock] = __uint_as_float((uint32_t)r), wl[6 * kBlock] = __uint_as_float((uint32_t)(r >> 32));
+    }
+  }
+  __device__ __forceinline__ bool next(uint32_t tag, const Hit& h, V3& o, V3& d, float& tmin, float& tmax) {
+    const uint32_t p = __float_as_uint(wl[8 * kBlock]);
+    if (h.slot == kNone) {
+      WalkState w;
+      w.org = o, w.dir = d, w.sigt = ld3(P.sss_sigt[p]), w.sigs = ld3(P.sss_sigs[p]);
+      w.wthr = V3(wl[0], wl[kBlock], wl[2 * kBlock]), w.t_scatter = wl[3 * kBlock], w.bounce = __float_as_uint(wl[4 * kBlock]);
+      w.rng_state = (uint64_t)__float_as_uint(wl[5 * kBlock]) | ((uint64_t)__float_as_uint(wl[6 * kBlock]) << 32);
+      if (sss_scatter(w, rng_inc)) {
+        o = w.org, d = w.dir, tmin = 0.f, tmax = w.t_scatter;
+        wl[0] = w.wthr.x, wl[kBlock] = w.wthr.y, wl[2 * kBlock] = w.wthr.z, wl[3 * kBlock] = w.t_scatter;
+        wl[4 * kBlock] = __uint_as_float(w.bounce);
+        wl[5 * kBlock] = __uint_as_float((uint32_t)w.rng_state), wl[6 * kBlock] = __uint_as_float((uint32_t)(w.rng_state >> 32));
+        wl[7 * kBlock] = __uint_as_float(1u);
+        n_rays++;
+        return true;
+      }
+    }
+    if (__float_as_uint(wl[7 * kBlock])) {  // hand the path back as the wavefront would have left it before the pending event
+      P.ray_o[p] = mk4(o, 0.f);
+      P.ray_d[p] = mk4(d, wl[3 * kBlock]);
+      P.sss_thr[p] = make_float4(wl[0], wl[kBlock], wl[2 * kBlock], wl[4 * kBlock]);
+      P.rng[p] = (uint64_t)__float_as_uint(wl[5 * kBlock]) | ((uint64_t)__float_as_uint(wl[6 * kBlock]) << 32);
+      P.hit[p] = make_float4(h.t, h.u, h.v, __uint_as_float(h.slot));
+    }
+    return false;
+  }
+  // (trace_pv only calls these for sinks that do not walk)
+  __device__ __forceinline__ bool load(uint32_t, uint32_t&, V3&, V3&, float&, float&) const { return false; }
+  __device__ __forceinline__ void done(uint32_t, const Hit&, bool) const {}
+};
+#ifndef PB_WALK_WAVES
+#define PB_WALK_WAVES 4  // waves per SIMD of k_sss_walk
+#endif
+template <bool STATS, bool CURVES>
+__global__ __launch_bounds__(kBlock, PB_WALK_WAVES) void k_sss_walk(PathState P, DScene sc, uint64_t rng_inc) {
+  __shared__ uint32_t stk[kPvLdsStack * kBlock];
+  __shared__ float frm[CURVES ? 10 * kBlock : 1];
+  __shared__ float walk[9 * kBlock];
+  const uint32_t n = P.counts[kCntSss];
+  TravStats st = {};
+  uint32_t overflow = 0u;
+  WalkSink sink = {P, rng_inc, walk + threadIdx.x, 0u};
+  trace_pv<0, STATS, CURVES>(sc, n, &P.counts[kCntWalkHead], sink, stk + threadIdx.x, kBlock,
+                             P.spill + blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, st, &overflow,
+                             CURVES ? frm + threadIdx.x : nullptr);
+  if (overflow) P.counts[kCntOverflow] = 1u;
+  if (STATS) {
+    const uint32_t a = wave_sum(sink.n_rays);
+    if (__lane_id() == 0 && a) atomicAdd(&P.stats[kStatTailClosestRays], (unsigned long long)a);
   }
 }
 
@@ -965,6 +1084,7 @@ __device__ __forceinline__ HookHit hook_result(const DScene& sc, V3 o, V3 d, con
   return r;
 }
 struct HookSink {
+  static constexpr bool kWalk = false;
   const DScene& sc;
   const float4* rays;
   HookHit* hits;
@@ -1029,7 +1149,7 @@ __global__ void k_advance(uint32_t* counts) {
     counts[kCntIn] = counts[kCntOut];
     counts[kCntShadowIn] = counts[kCntShadow];
     counts[kCntOut] = 0, counts[kCntPrincipled] = 0, counts[kCntHair] = 0, counts[kCntSss] = 0, counts[kCntShadow] = 0;
-    counts[kCntHead] = 0;
+    counts[kCntHead] = 0, counts[kCntWalkHead] = 0;
   }
 }
 
@@ -1081,6 +1201,16 @@ void launch_shade_hair(hipStream_t s, const PathState& P, const DScene& sc, uint
 }
 void launch_sss_step(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc) {
   hipLaunchKernelGGL(k_sss_step, dim3(grid_for(n_upper, kShadeGridCap)), dim3(kBlock), 0, s, P, sc, rng_inc);
+}
+void launch_sss_walk(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc, bool stats) {
+  const uint32_t cap = 256u * PB_WALK_WAVES;  // persistent: the resident blocks (<= kTraceGridCap: the walk shares k_trace's spill area)
+  const uint32_t blocks = (n_upper + 15u) / 16u;
+  dim3 g(blocks < 1u ? 1u : (blocks < cap ? blocks : cap));
+  const bool curves = sc.num_curves != 0;
+  if (stats && curves) hipLaunchKernelGGL((k_sss_walk<true, true>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
+  else if (stats) hipLaunchKernelGGL((k_sss_walk<true, false>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
+  else if (curves) hipLaunchKernelGGL((k_sss_walk<false, true>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
+  else hipLaunchKernelGGL((k_sss_walk<false, false>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
 }
 void launch_accumulate(hipStream_t s, const PathState& P, const uint32_t* pix_index, uint32_t npix, uint32_t npass,
                        float* rgba, uint32_t* count) {

@@ -955,6 +955,7 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
     const uint32_t window = std::max(1u, env_u32("PBRHIP_WINDOW", getenv("PBRHIP_GROUPS") ? 1u : (uint32_t)kMaxGroups));
     const uint32_t bulk_div = env_u32("PBRHIP_BULK_DIV", 0u);
     const bool trace_sched = getenv("PBRHIP_TRACE_SCHED") != nullptr;
+    const bool sss_walk = env_u32("PBRHIP_SSS_WALK", 1u) != 0u;  // 0: one wavefront iteration per step of a random walk (A/B)
     if (int rc = ensure_groups(s, kMaxGroups)) return rc;
     struct Group {
       PathState P;
@@ -1025,7 +1026,8 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
           }
           if (s->has_sss) {
             HIPCHK(gr.tm.begin(&S.ms_sss_step));
-            launch_sss_step(gst, gr.P, sc, n, rng_inc);
+            if (sss_walk) launch_sss_walk(gst, gr.P, sc, n, rng_inc, want_stats);  // every walk forward to its last event ...
+            launch_sss_step(gst, gr.P, sc, n, rng_inc);                            // ... which the step kernel handles
             HIPCHK(gr.tm.end());
             S.n_sss_step++;
           }

@@ -285,7 +285,7 @@ def test_cancel_from_another_thread_mid_render(pa):
         cancel.value = 1
     th = threading.Thread(target=killer)
     th.start()
-    ok, st = pa.Render(sg, W, H, SPP, cancel_render_flag=cancel, layer=lay, finish_pass=fin)
+    ok, st = pa.Render(sg, W, H, SPP, cancel_render_flag=cancel, layer=lay, finish_pass=fin, max_paths_in_flight=W * H * 16)
     t_ret = time.perf_counter()
     th.join()
     assert ok is True and 0 < fin.value < SPP and st["passes_done"] == fin.value
@@ -293,7 +293,7 @@ def test_cancel_from_another_thread_mid_render(pa):
     assert (lay.count == fin.value).all() and np.array_equal(lay.rgba[..., 3], np.full((H, W), fin.value, np.float32))
     assert t_ret - t_set[0] < 0.25, t_ret - t_set[0]        # a wavefront iteration, not the rest of the frame
     ref = pa.RenderLayer()
-    pa.Render(sg, W, H, int(fin.value), layer=ref)
+    pa.Render(sg, W, H, int(fin.value), layer=ref)                      # (one chunk: the image does not depend on the chunking)
     assert ref.rgba.tobytes() == lay.rgba.tobytes()
     print(f"cancelled after {fin.value} of {SPP} passes, returned {1e3 * (t_ret - t_set[0]):.1f} ms after the flag")
 
