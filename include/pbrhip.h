@@ -144,7 +144,11 @@ int pbrhip_scene_add_texture(pbrhip_scene*, const float* pixels, uint32_t width,
 /* Scene::AddLightParam (scene.h:34-37) with AreaLightParameter (light-param.h:20-23) */
 int pbrhip_scene_add_area_light(pbrhip_scene*, const float emission[3], uint32_t* light_id);
 /* Scene::CreateLocalScene (scene.cc:157-164), AddMeshToLocalScene (scene.cc:14-62), CreateInstance (scene.cc:106-155;
- * transform = float[4][4], row-vector convention v' = v*M; only the identity is supported so far) */
+ * transform = float[4][4], row-vector convention v' = v*M with the translation in the last row, NULL = identity.  As in the
+ * reference the transform only reaches the raytracer (raytracer_impl.cc:61-81 hands it to Embree): rays see the transformed
+ * geometry -- triangles and curve control points transformed, curve radii as they are -- while geometric / shading normals,
+ * texcoords and light sampling stay in the instance's local space (scene.cc:217,237 and light-manager.h:128-136 "TODO
+ * transform").  A singular or non-finite matrix is refused (PBRHIP_EINVAL). */
 int pbrhip_scene_create_local_scene(pbrhip_scene*, uint32_t* local_scene_id);
 int pbrhip_scene_add_mesh_to_local_scene(pbrhip_scene*, uint32_t local_scene_id, uint32_t mesh_id, uint32_t* geom_id);
 int pbrhip_scene_create_instance(pbrhip_scene*, uint32_t local_scene_id, const float* transform4x4,

@@ -847,14 +847,18 @@ static int better_hit(float t, uint32_t gid, float best_t, uint32_t best_gid) {
   return (t < best_t) || (t == best_t && gid < best_gid);
 }
 
+/* Ng as Embree reports it for an instanced geometry: in the instance's LOCAL space (the ray is intersected in object
+ * space; raytracer_impl.cc:221-233 normalises it and never transforms it).  prim_geo holds what the raytracer sees (the
+ * transformed primitive), so the normal is taken from the mesh itself. */
 static void fill_ng(const orc_scene* s, f3 d, orc_isect* is) {
   (void)d;
-  const float* geo = s->prim_geo + (size_t)is->gid * ORC_GEO_STRIDE;
-  if (s->prims[is->gid].kind == 0) {
-    f3 v0 = f3_make(geo[0], geo[1], geo[2]), v1 = f3_make(geo[3], geo[4], geo[5]), v2 = f3_make(geo[6], geo[7], geo[8]);
+  const orc_primref* pr = &s->prims[is->gid];
+  const orc_mesh* m = inst_mesh(s, pr->instance_id, pr->geom_id);
+  if (pr->kind == 0) {
+    f3 v0 = mesh_vertex(m, pr->prim_id, 0), v1 = mesh_vertex(m, pr->prim_id, 1), v2 = mesh_vertex(m, pr->prim_id, 2);
     is->ng = f3_cross(f3_sub(v1, v0), f3_sub(v2, v0));
   } else {
-    is->ng = bezier_tangent(geo, is->u);
+    is->ng = bezier_tangent(m->cverts + (size_t)m->cidx[pr->prim_id] * 4, is->u);
   }
 }
 

@@ -56,7 +56,7 @@ constexpr uint32_t kSlotMatNone = 8u;   // touching the material table (shader.c
 constexpr uint32_t kSlotHasUV = 16u;
 
 struct alignas(128) ShadeRec {
-  float v[9];   // triangle corners xyz (world).  Curve piece: words 0..15 of the record (v[0..8], n[0..6]) hold the cubic's
+  float v[9];   // triangle corners xyz (the mesh's own, local space: only the geometric normal is taken from them).  Curve piece: words 0..15 of the record (v[0..8], n[0..6]) hold the cubic's
   float n[9];   // four control points xyzr instead.  Triangle: corner shading normals xyz (kSlotHasNormals)
   uint32_t gid, material, lightrec, flags;
   uint32_t instance_id, geom_id, prim_id;
@@ -156,6 +156,7 @@ struct DScene {
   const float* tex_pixels;
   const TexDesc* textures;
   uint32_t num_nodes, num_slots, num_lights, num_materials, num_curves, num_textures, num_lrecs;
+  uint32_t lights_transformed;  // an emissive instance has a transform: lrecs / light_boxes are not what the raytracer sees
 };
 
 // camera of RenderingTile (render.cc:132-158), derived on the host from the scene AABB

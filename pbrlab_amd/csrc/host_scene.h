@@ -34,6 +34,7 @@ struct HostAreaLight {  // LightManager::AreaLight (light-manager.h:174-182)
 struct HostInstance {  // MeshInstance (mesh-instance.h:22-36)
   uint32_t local_scene = 0;
   float xf[16];
+  bool identity = true;  // xf is bit-for-bit the identity: the raytracer sees the meshes as they are
   std::vector<std::vector<uint32_t>> material_ids, light_ids;
   std::vector<int> has_area_light;  // per geom
   std::vector<HostAreaLight> area_lights;

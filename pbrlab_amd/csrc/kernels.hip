@@ -373,6 +373,7 @@ __device__ __forceinline__ uint32_t doomed_bit(V3 thr, uint64_t state, uint64_t 
 // Beyond that the ray is kept (a linear scan would not pay).
 constexpr uint32_t kLightPretest = 8;
 __device__ __forceinline__ bool misses_all_lights(const DScene& sc, V3 o, V3 d, float tmin) {
+  if (sc.lights_transformed) return false;  // the light records hold local positions, the raytracer tests transformed ones
   if (sc.num_lrecs <= kLightPretest) {
     for (uint32_t i = 0; i < sc.num_lrecs; i++) {
       const float4* lr = reinterpret_cast<const float4*>(sc.lrecs + i);

@@ -236,8 +236,18 @@ extern "C" int pbrhip_scene_create_instance(pbrhip_scene* s, uint32_t local_scen
   HostInstance in;
   in.local_scene = local_scene_id;
   memcpy(in.xf, transform ? transform : ident, sizeof(ident));
-  if (memcmp(in.xf, ident, sizeof(ident)) != 0)
-    return fail(PBRHIP_EUNSUPPORTED, "instance transforms other than the identity are not supported yet");
+  in.identity = memcmp(in.xf, ident, sizeof(ident)) == 0;
+  if (!in.identity) {
+    // raytracer_impl.cc:49-84 hands the matrix to Embree (row-vector convention, v' = v * M, translation in the last
+    // row); everything above the raytracer keeps working in the instance's local space (scene.cc:217,237 "TODO
+    // transform").  A matrix that is not invertible has no such instance.
+    const float* m = in.xf;
+    for (int k = 0; k < 16; k++)
+      if (!std::isfinite(m[k])) return fail(PBRHIP_EINVAL, "create_instance: the transform has a non-finite entry");
+    const double det = (double)m[0] * ((double)m[5] * m[10] - (double)m[6] * m[9]) - (double)m[1] * ((double)m[4] * m[10] - (double)m[6] * m[8]) +
+                       (double)m[2] * ((double)m[4] * m[9] - (double)m[5] * m[8]);
+    if (!(det != 0.0)) return fail(PBRHIP_EINVAL, "create_instance: the transform is singular");
+  }
   // scene.cc:119-143: material ids are copied from the meshes when the instance is created
   for (uint32_t mid : s->locals[local_scene_id]) {
     const HostMesh& m = s->meshes[mid];
@@ -282,6 +292,25 @@ extern "C" int pbrhip_scene_attach_material_ids(pbrhip_scene* s, uint32_t instan
 static V3 mesh_vertex(const HostMesh& m, uint32_t prim, int k) {
   const float* p = m.vertices.data() + (size_t)m.vid[prim * 3 + k] * 4;
   return V3(p[0], p[1], p[2]);
+}
+// What the raytracer sees of an instance (raytracer_impl.cc:61-81: the transform goes to Embree and nowhere else):
+// v' = v * M with the translation row, in this order of operations (the checker uses the same expression).
+static V3 xf_point(const float* m, V3 v) {
+  return V3(m[0] * v.x + m[4] * v.y + m[8] * v.z + m[12], m[1] * v.x + m[5] * v.y + m[9] * v.z + m[13],
+            m[2] * v.x + m[6] * v.y + m[10] * v.z + m[14]);
+}
+static V3 world_vertex(const HostInstance& in, const HostMesh& m, uint32_t prim, int k) {
+  const V3 v = mesh_vertex(m, prim, k);
+  return in.identity ? v : xf_point(in.xf, v);
+}
+// control points xyzr of curve `prim` as the raytracer sees them (the radius is not scaled)
+static void world_curve(const HostInstance& in, const HostMesh& m, uint32_t prim, float out[16]) {
+  const float* cps = m.cverts.data() + (size_t)m.cidx[prim] * 4;
+  for (int c = 0; c < 4; c++) {
+    V3 v(cps[4 * c], cps[4 * c + 1], cps[4 * c + 2]);
+    if (!in.identity) v = xf_point(in.xf, v);
+    out[4 * c] = v.x, out[4 * c + 1] = v.y, out[4 * c + 2] = v.z, out[4 * c + 3] = cps[4 * c + 3];
+  }
 }
 // TriangleMesh::FetchFaceArea (mesh/triangle-mesh.cc:113-124)
 static float face_area(const HostMesh& m, uint32_t prim) {
@@ -399,18 +428,20 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
   for (uint32_t g = 0; g < np; g++) {
     const PrimRef& pr = prims[g];
     const HostMesh& m = *inst_mesh(s, pr.instance_id, pr.geom_id);
+    const HostInstance& inst = s->instances[pr.instance_id];
     float l[3] = {inf, inf, inf}, h[3] = {-inf, -inf, -inf};
     kinds[g] = (uint8_t)pr.kind;
     if (pr.kind == 0) {
       for (int c = 0; c < 3; c++) {
-        V3 v = mesh_vertex(m, pr.prim_id, c);
+        V3 v = world_vertex(inst, m, pr.prim_id, c);
         float a[3] = {v.x, v.y, v.z};
         for (int k = 0; k < 3; k++) l[k] = std::min(l[k], a[k]), h[k] = std::max(h[k], a[k]);
       }
     } else {
       // scene bounds (they place the camera): convex hull of the control points widened by the largest control radius,
       // per whole curve -- the intersection contract shared with the checker
-      const float* cps = m.cverts.data() + (size_t)m.cidx[pr.prim_id] * 4;
+      float cps[16];
+      world_curve(inst, m, pr.prim_id, cps);
       if (pr.sub == 0) {
         float r = 0.f, cl[3] = {inf, inf, inf}, ch[3] = {-inf, -inf, -inf};
         for (int c = 0; c < 4; c++) {
@@ -512,8 +543,10 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
     for (int c = 0; c < 4; c++) sl[c] = make_float4(0, 0, 0, 0);
     if (pr.kind == 0) {
       for (int c = 0; c < 3; c++) {
-        V3 v = mesh_vertex(m, pr.prim_id, c);
-        sl[c] = make_float4(v.x, v.y, v.z, 0.f);
+        // traversal: what Embree sees (the transformed triangle); shading: the mesh's own corners -- the geometric normal
+        // Embree reports for an instance is in the instance's local space and pbrlab uses it as it is
+        const V3 w = world_vertex(in, m, pr.prim_id, c), v = mesh_vertex(m, pr.prim_id, c);
+        sl[c] = make_float4(w.x, w.y, w.z, 0.f);
         sr.v[3 * c + 0] = v.x, sr.v[3 * c + 1] = v.y, sr.v[3 * c + 2] = v.z;
       }
       uint32_t a = m.nid[pr.prim_id * 3 + 0], b = m.nid[pr.prim_id * 3 + 1], c = m.nid[pr.prim_id * 3 + 2];
@@ -540,9 +573,11 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
       }
     } else {
       flags |= kSlotIsCurve;
-      const float* cps = m.cverts.data() + (size_t)m.cidx[pr.prim_id] * 4;
+      const float* cps = m.cverts.data() + (size_t)m.cidx[pr.prim_id] * 4;  // local: the tangent (= Ng) shading uses
+      float wcps[16];
+      world_curve(in, m, pr.prim_id, wcps);
       float a[4], b[4];
-      curve_piece(cps, pr.sub, a, b);
+      curve_piece(wcps, pr.sub, a, b);
       sl[0] = make_float4(a[0], a[1], a[2], a[3]);
       sl[1] = make_float4(b[0], b[1], b[2], b[3]);
       sl[2] = make_float4(__builtin_bit_cast(float, pr.sub), 0.f, 0.f, 0.f);
@@ -608,6 +643,11 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
   d.tex_pixels = s->d_tex_pixels.p, d.textures = s->d_tex_descs.p, d.num_textures = (uint32_t)s->tex_descs.size();
   d.num_curves = 0;
   for (uint8_t kd : kinds) d.num_curves += kd ? 1u : 0u;
+  // light sampling works on the meshes' local positions (light-manager.h:128-136 "TODO transform"), the raytracer on the
+  // transformed ones: the doomed-path pretest against the light primitives (kernels.hip::misses_all_lights) is only the
+  // traversal's own test when the two coincide
+  d.lights_transformed = 0;
+  for (const HostLight& L : s->lights) d.lights_transformed |= s->instances[L.instance_id].identity ? 0u : 1u;
   s->committed = true;
   return PBRHIP_OK;
   });

@@ -71,6 +71,7 @@ class Shape:
     normal_ids: Optional[np.ndarray]  # (F,3) u32 or None
     material_ids: np.ndarray          # (F,) u32 (scene-global material ids)
     texcoord_ids: Optional[np.ndarray] = None  # (F,3) u32 into SceneDesc.texcoords or None
+    transform: Optional[np.ndarray] = None     # (4,4) instance transform, row-vector convention v' = v M (None = identity)
 
 
 @dataclass
@@ -79,6 +80,7 @@ class CurveShape:
     vertices: np.ndarray   # (4*S, 4) xyz + radius, 4 control points per segment (not shared)
     indices: np.ndarray    # (S,) u32 first control point
     material: dict = field(default_factory=lambda: dict(HAIR_DEFAULTS, kind="hair", name="hair"))
+    transform: Optional[np.ndarray] = None     # (4,4) instance transform (None = identity)
 
 
 @dataclass
@@ -457,7 +459,7 @@ def build_scene(scene, desc: SceneDesc, make_principled, make_hair):
                                      sh.texcoord_ids, mat_ids[sh.material_ids])
         ls = scene.CreateLocalScene()
         scene.AddMeshToLocalScene(ls, mesh)
-        inst = scene.CreateInstance(ls, None)
+        inst = scene.CreateInstance(ls, sh.transform)
         instances.append(inst)
         if sh.name[:5] == "light":
             lid = scene.AddLightParam(desc.light_emission)
@@ -467,9 +469,24 @@ def build_scene(scene, desc: SceneDesc, make_principled, make_hair):
         mesh = scene.AddCubicBezierCurveMesh(cs.vertices, cs.indices, np.full(len(cs.indices), mid, np.uint32))
         ls = scene.CreateLocalScene()
         scene.AddMeshToLocalScene(ls, mesh)
-        instances.append(scene.CreateInstance(ls, None))
+        instances.append(scene.CreateInstance(ls, cs.transform))
     scene.CommitScene()
     return instances
+
+
+def instance_matrix(rotate_deg=(0.0, 0.0, 0.0), scale=(1.0, 1.0, 1.0), translate=(0.0, 0.0, 0.0)):
+    """4x4 for Scene::CreateInstance in pbrlab's row-vector convention (v' = v M, translation in the last row):
+    scale, then rotate about x, y, z, then translate."""
+    rx, ry, rz = [np.deg2rad(a) for a in rotate_deg]
+    S = np.diag([scale[0], scale[1], scale[2]])
+    cx, sx, cy, sy, cz, sz = np.cos(rx), np.sin(rx), np.cos(ry), np.sin(ry), np.cos(rz), np.sin(rz)
+    Rx = np.array([[1, 0, 0], [0, cx, sx], [0, -sx, cx]])
+    Ry = np.array([[cy, 0, -sy], [0, 1, 0], [sy, 0, cy]])
+    Rz = np.array([[cz, sz, 0], [-sz, cz, 0], [0, 0, 1]])
+    M = np.eye(4)
+    M[:3, :3] = S @ Rx @ Ry @ Rz
+    M[3, :3] = translate
+    return M.astype(np.float32)
 
 
 def random_rays(desc_aabb, n, seed=0):

@@ -209,7 +209,7 @@ def test_material_update_and_errors(pa, pairs):
         sg.AttachMaterialParamIdsToInstance(0, [np.zeros(5, np.uint32)])
     assert e.value.code == -2                       # "material param error" (scene.cc:86-88)
     with pytest.raises(pa.PbrHipError):
-        sg.CreateInstance(0, np.diag([2.0, 1, 1, 1]).astype(np.float32))
+        sg.CreateInstance(0, np.diag([0.0, 1, 1, 1]).astype(np.float32))   # singular (any invertible transform is accepted)
     s3 = pa.Scene()
     with pytest.raises(pa.PbrHipError):
         pa.Render(s3, 8, 8, 1, layer=pa.RenderLayer())   # not committed
@@ -710,6 +710,84 @@ def test_doomed_path_pruning_around_the_light_limits(pa, nlight, nshapes):
         assert st["shadow_rays"] + st["tail_shadow_rays"] == ost["shadow_rays"]
         assert (st["pruned_rays"] > 0) == (nlight <= 8 or nshapes <= 8), (nlight, nshapes, st["pruned_rays"])
     assert rgba[..., :3].max() > 0
+
+
+def transformed_scene(kind):
+    from pbrlab_amd import scenes
+    if kind == "hair":
+        d = scenes.hair_scene(n_strands=400, n_segments=6, head_subdiv=2)
+        for s in d.shapes:
+            if s.name == "head":
+                s.transform = scenes.instance_matrix((10, -25, 5), (1.0, 1.0, 1.0), (0.05, 0.02, -0.1))
+        d.curves[0].transform = scenes.instance_matrix((10, -25, 5), (1.0, 1.0, 1.0), (0.05, 0.02, -0.1))
+        return d
+    d = scenes.cornell_scene(kind, monkey_subdiv=2, lucy_nu=64, lucy_nv=12)
+    xf = {"monkey": scenes.instance_matrix((20, 35, -10), (1.2, 0.8, 1.1), (0.1, -0.05, 0.2)),
+          "lucy": scenes.instance_matrix((0, 90, 0), (0.9, 0.9, 0.9), (-0.15, 0.0, 0.1)),
+          "box": scenes.instance_matrix((0, 0, 45), (1.0, 2.0, 1.0), (0.0, 0.1, 0.0)),
+          "light": scenes.instance_matrix((0, 15, 0), (1.0, 1.0, 1.0), (0.05, 0.0, 0.1))}
+    for s in d.shapes:
+        if s.name in xf:
+            s.transform = xf[s.name]
+    return d
+
+
+@pytest.mark.parametrize("kind", ["ggx", "sss", "hair"])
+def test_instance_transforms(pa, kind):
+    """Scene::CreateInstance with a transform (scene.cc:106-155, raytracer_impl.cc:49-84): rotated / scaled / translated
+    instances, also of the emissive mesh.  The raytracer sees the transformed geometry; normals, texcoords and light
+    sampling stay local as in the reference ("TODO transform").  Hits and images equal the oracle's, bit for bit, for
+    both BVH builders; a transform that is the identity changes nothing; singular matrices are refused."""
+    from pbrlab_amd import scenes
+    desc = transformed_scene(kind)
+    so = O.oracle_scene_from_desc(desc)
+    lo, hi = so.FetchSceneAABB()
+    rays = scenes.random_rays((lo, hi), 30000, seed=4)
+    ho = so.trace_closest(rays)
+    assert_hits_equal(ho[:1200], so.trace_closest(rays[:1200], brute_force=True))
+    rgba, cnt, ost = so.render(72, 56, 3, threads=4, math_mode=O.MATH_F64R)
+    for builder in (pa.api.BVH_HOST_SAH, pa.api.BVH_GPU_LBVH):
+        sg = pa.scene_from_desc(desc, bvh_builder=builder)
+        glo, ghi = sg.FetchSceneAABB()
+        assert np.array_equal(lo, glo) and np.array_equal(hi, ghi)
+        assert_hits_equal(sg.trace_closest(rays), ho)
+        sr = rays.copy()
+        sr["tmax"] = 0.7
+        assert np.array_equal(sg.trace_any(sr), so.trace_any(sr))
+        for tail in (0, 0xFFFFFFFF):
+            lay = pa.RenderLayer()
+            ok, st = pa.Render(sg, 72, 56, 3, layer=lay, flags=pa.api.RENDER_STATS, tail_paths=tail)
+            assert lay.rgba.tobytes() == rgba.tobytes(), (builder, tail)
+            assert (st["closest_rays"] + st["tail_closest_rays"] + st["pruned_rays"], st["shadow_rays"] + st["tail_shadow_rays"]) == (ost["closest_rays"], ost["shadow_rays"])
+    # the image really depends on the transforms ...
+    plain = transformed_scene(kind)
+    for s in plain.shapes:
+        s.transform = None
+    for c in plain.curves:
+        c.transform = None
+    a, b = pa.RenderLayer(), pa.RenderLayer()
+    pa.Render(pa.scene_from_desc(plain), 72, 56, 3, layer=a)
+    assert a.rgba.tobytes() != rgba.tobytes()
+    # ... and an explicit identity is the same scene as no transform
+    for s in plain.shapes:
+        s.transform = np.eye(4, dtype=np.float32)
+    pa.Render(pa.scene_from_desc(plain), 72, 56, 3, layer=b)
+    assert a.rgba.tobytes() == b.rgba.tobytes()
+
+
+def test_instance_transform_errors(pa):
+    s = pa.Scene()
+    v = np.array([[0, 0, 0, 1], [1, 0, 0, 1], [0, 1, 0, 1]], np.float32)
+    m = s.AddTriangleMesh(v, None, None, np.array([[0, 1, 2]], np.uint32))
+    ls = s.CreateLocalScene()
+    s.AddMeshToLocalScene(ls, m)
+    sing = np.eye(4, dtype=np.float32)
+    sing[1, 1] = 0.0
+    for bad in (sing, np.full((4, 4), np.nan, np.float32), np.zeros((4, 4), np.float32)):
+        with pytest.raises(pa.PbrHipError) as e:
+            s.CreateInstance(ls, bad)
+        assert e.value.code == -1
+    assert s.CreateInstance(ls, np.diag([2, 2, 2, 1]).astype(np.float32)) == 0      # the failed calls created nothing
 
 
 def test_multi_geometry_instances_and_duplicate_instances(pa):
