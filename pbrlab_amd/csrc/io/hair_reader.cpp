@@ -43,8 +43,19 @@ void end_piece(float q[4], float p0, float p1, float p2) {  // :7-30
   q[3] = p2;
 }
 
+// bytes between the read position and the end of the file
+size_t bytes_left(FILE* fp) {
+  const long here = ftell(fp);
+  if (here < 0 || fseek(fp, 0, SEEK_END) != 0) return 0;
+  const long end = ftell(fp);
+  fseek(fp, here, SEEK_SET);
+  return end > here ? size_t(end - here) : 0;
+}
 template <typename T>
 bool read_block(FILE* fp, std::vector<T>* dst, size_t count) {
+  // the counts come from the file's header: a block the file cannot hold is a failed read (as it is in the reference,
+  // whose fread comes up short), not an allocation of up to 2^32 * 3 floats
+  if (count > bytes_left(fp) / sizeof(T)) return false;
   dst->resize(count);
   if (count == 0) return false;  // fread(ptr, 0, 1, fp) returns 0 in the reference too
   return fread(dst->data(), sizeof(T) * count, 1, fp) == 1;

@@ -169,6 +169,21 @@ bool LoadTriangleMeshFromObj(const std::string& filename, ObjScene* out) {
   return true;
 }
 
+// The elements of `src` (stride floats each) that `ids` references, in order of first use; `ids` is rewritten to index
+// them.  uint32(-1) ("none") stays as it is.
+static void compact_attribute(const std::vector<float>& src, size_t stride, std::vector<uint32_t>* ids, std::vector<float>* out) {
+  std::vector<uint32_t> remap(src.size() / stride, 0xFFFFFFFFu);
+  out->clear();
+  for (uint32_t& id : *ids) {
+    if (id == 0xFFFFFFFFu || id >= remap.size()) continue;  // (out-of-range ids are left for the library to report)
+    if (remap[id] == 0xFFFFFFFFu) {
+      remap[id] = uint32_t(out->size() / stride);
+      out->insert(out->end(), src.begin() + size_t(id) * stride, src.begin() + size_t(id + 1) * stride);
+    }
+    id = remap[id];
+  }
+}
+
 bool AddObjToScene(pbrhip_scene* scene, const std::string& obj_filename, std::string* err) {
   ObjScene o;
   if (!LoadTriangleMeshFromObj(obj_filename, &o)) {
@@ -210,11 +225,18 @@ bool AddObjToScene(pbrhip_scene* scene, const std::string& obj_filename, std::st
       std::cerr << "    (no faces: skipped)" << std::endl;
       continue;
     }
+    // The reference's meshes share one Attribute through a shared_ptr (triangle-mesh-io.cc:246-262); the library copies
+    // what it is given, so every shape hands over only the vertices / normals / texcoords it references (ids remapped):
+    // memory stays linear in the file size however many shapes there are.
+    std::vector<float> sv, sn, st;
+    std::vector<uint32_t> vid = m.vertex_ids, nid = m.normal_ids, tid = m.texcoord_ids;
+    compact_attribute(o.vertices_xyzw, 4, &vid, &sv);
+    compact_attribute(o.normals_xyzw, 4, &nid, &sn);
+    compact_attribute(o.texcoords_uv, 2, &tid, &st);
     uint32_t mesh, local_scene, geom, instance;
-    if (!check(pbrhip_scene_add_triangle_mesh(scene, o.vertices_xyzw.data(), uint32_t(o.vertices_xyzw.size() / 4),
-                                              o.normals_xyzw.data(), uint32_t(o.normals_xyzw.size() / 4),
-                                              o.texcoords_uv.data(), uint32_t(o.texcoords_uv.size() / 2), m.vertex_ids.data(),
-                                              m.normal_ids.data(), m.texcoord_ids.data(), m.material_ids.data(), nf, &mesh), err) ||
+    if (!check(pbrhip_scene_add_triangle_mesh(scene, sv.data(), uint32_t(sv.size() / 4), sn.data(), uint32_t(sn.size() / 4),
+                                              st.data(), uint32_t(st.size() / 2), vid.data(), nid.data(), tid.data(),
+                                              m.material_ids.data(), nf, &mesh), err) ||
         !check(pbrhip_scene_create_local_scene(scene, &local_scene), err) ||
         !check(pbrhip_scene_add_mesh_to_local_scene(scene, local_scene, mesh, &geom), err) ||
         !check(pbrhip_scene_create_instance(scene, local_scene, kIdentity, &instance), err))
