@@ -922,7 +922,8 @@ __global__ __launch_bounds__(kBlock, PB_WALK_WAVES) void k_sss_walk(PathState P,
 // traverses the continuation ray -- the two dependent-load chains of a bounce run side by side instead of one after the
 // other (what bounds k_tail is the chain of the longest path, not throughput).
 #ifndef PB_TAIL_WAVES
-#define PB_TAIL_WAVES 2  // min waves per SIMD of k_tail (VGPR budget 512 / waves)
+#define PB_TAIL_WAVES 3  // min waves per SIMD of k_tail (<= 168 VGPRs: three blocks per CU hold 196 k lanes, so every path of a 256 Ki tail starts at once;
+                         // A/B on C2: 2 -> 59.1 ms per frame / 12.1 ms for an eighth, 3 -> 58.6 / 11.8)
 #endif
 template <bool CURVES, bool STATS>
 __global__ __launch_bounds__(kBlock, PB_TAIL_WAVES) void k_tail(PathState P, DScene sc, uint64_t rng_inc) {
