@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <deque>
 #include <future>
 #include <limits>
 #include <thread>
@@ -179,7 +180,7 @@ void build_bvh(const std::vector<float>& lo, const std::vector<float>& hi, const
   pool.nodes.reserve(2 * (size_t)n / 2 + 16);
   int32_t root = b.build(pool, 0, n, 1);
 
-  // flatten: internal nodes get consecutive indices in DFS order; node 0 is always internal
+  // flatten: internal nodes get consecutive indices; node 0 is always internal
   const std::vector<TNode>& T = pool.nodes;
   const float kNaN3[3] = {std::numeric_limits<float>::quiet_NaN(), std::numeric_limits<float>::quiet_NaN(),
                           std::numeric_limits<float>::quiet_NaN()};
@@ -199,12 +200,15 @@ void build_bvh(const std::vector<float>& lo, const std::vector<float>& hi, const
       int32_t t;
       uint32_t out;
     };
-    std::vector<Item> stack;
+    // Numbering: breadth first for the first kTopNodes nodes (the top of the tree is one contiguous block that the
+    // traversal kernel copies into LDS: dscene.h), depth first below
+    std::deque<Item> work;
     N.emplace_back();
-    stack.push_back({root, 0});
-    while (!stack.empty()) {
-      Item it = stack.back();
-      stack.pop_back();
+    work.push_back({root, 0});
+    while (!work.empty()) {
+      Item it;
+      if (N.size() < (size_t)kTopNodes) it = work.front(), work.pop_front();
+      else it = work.back(), work.pop_back();
       const TNode& t = T[it.t];
       depth = std::max(depth, t.depth);
       BvhNode nd;
@@ -217,14 +221,14 @@ void build_bvh(const std::vector<float>& lo, const std::vector<float>& hi, const
       } else {
         nd.c0 = (uint32_t)N.size();
         N.emplace_back();
-        stack.push_back({t.left, nd.c0});
+        work.push_back({t.left, nd.c0});
       }
       if (r.left < 0) {
         nd.c1 = leaf_ref(r);
       } else {
         nd.c1 = (uint32_t)N.size();
         N.emplace_back();
-        stack.push_back({t.right, nd.c1});
+        work.push_back({t.right, nd.c1});
       }
       N[it.out] = nd;
     }

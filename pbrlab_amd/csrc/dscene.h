@@ -29,6 +29,12 @@ constexpr int kMaxLeaf = PB_MAX_LEAF;
 #define PB_STACK_DEPTH 40
 #endif
 constexpr int kStackDepth = PB_STACK_DEPTH;
+// The host builder numbers the first kTopNodes nodes breadth first (levels 0..5 of a full tree): DScene::top_nodes of
+// them form the top of the tree and are staged in LDS by k_trace (4 KB per block).  0 for trees without that numbering.
+#ifndef PB_TOP_NODES
+#define PB_TOP_NODES 64
+#endif
+constexpr int kTopNodes = PB_TOP_NODES;
 
 // Both children's boxes, interleaved [axis][child] so that the two children's values of one bound sit in an aligned
 // register pair after the 16-byte loads: the slab test runs on v_pk_add_f32 / v_pk_mul_f32 (two children per instruction).
@@ -156,6 +162,7 @@ struct DScene {
   const float* tex_pixels;
   const TexDesc* textures;
   uint32_t num_nodes, num_slots, num_lights, num_materials, num_curves, num_textures, num_lrecs;
+  uint32_t top_nodes;           // nodes 0 .. top_nodes-1 are the breadth-first top of the tree (<= kTopNodes; 0: not numbered that way)
   uint32_t lights_transformed;  // an emissive instance has a transform: lrecs / light_boxes are not what the raytracer sees
 };
 

@@ -64,7 +64,9 @@ enum : uint32_t { kStIdle = 0, kStNode = 1, kStTri = 2, kStCurve = 3, kStDone = 
 template <int MODE, bool STATS, bool CURVES, typename Sink>
 __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t* head, Sink& sink, uint32_t* stk_base,
                                          uint32_t stride, uint32_t* spill, uint32_t spill_stride, TravStats& st,
-                                         uint32_t* overflow, float* frame = nullptr) {
+                                         uint32_t* overflow, float* frame = nullptr, const float4* top = nullptr,
+                                         uint32_t ntop = 0) {
+  // top / ntop: LDS copy of nodes 0 .. ntop-1 (the breadth-first top of the tree, 64 bytes each), or none
   // frame (CURVES): 10 words per lane in LDS (frame[k * stride]), the ray's RayFrame, written when the ray is fetched
   const uint32_t lane = __lane_id();
   // number of set bits of a wave mask below this lane (v_mbcnt: no per-lane mask has to stay in registers)
@@ -292,9 +294,15 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
       }
     }
     if (need_load) {
-      const float4* g = reinterpret_cast<const float4*>(sc.nodes + cur);  // node, or slot cur - num_nodes
-      D0 = g[0], D1 = g[1], D2 = g[2];
-      if (state == kStNode) D3 = *reinterpret_cast<const float2*>(g + 3);
+      if (kTopNodes > 0 && cur < ntop) {  // the top of the tree: every ray passes through it
+        const float4* g = top + cur * 4u;
+        D0 = g[0], D1 = g[1], D2 = g[2];
+        D3 = *reinterpret_cast<const float2*>(g + 3);
+      } else {
+        const float4* g = reinterpret_cast<const float4*>(sc.nodes + cur);  // node, or slot cur - num_nodes
+        D0 = g[0], D1 = g[1], D2 = g[2];
+        if (state == kStNode) D3 = *reinterpret_cast<const float2*>(g + 3);
+      }
     }
   }
   if constexpr (!Sink::kWalk) {

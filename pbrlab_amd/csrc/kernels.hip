@@ -105,6 +105,15 @@ template <bool STATS, bool CURVES>
 __global__ __launch_bounds__(kBlock, (CURVES ? kTraceBlocksPerCUCurves : kTraceBlocksPerCU)) void k_trace(PathState P, DScene sc) {
   __shared__ uint32_t stk[kPvLdsStack * kBlock];
   __shared__ float frm[CURVES ? 10 * kBlock : 1];
+  // the top of the tree in LDS (triangle-only scenes: with the ribbon frames of curve scenes it would cost a block per CU)
+  constexpr bool kStageTop = !CURVES && kTopNodes > 0;
+  __shared__ float4 top[kStageTop ? kTopNodes * 4 : 1];
+  const uint32_t ntop = kStageTop ? sc.top_nodes : 0u;
+  if (kStageTop) {
+    const float4* src = reinterpret_cast<const float4*>(sc.nodes);
+    for (uint32_t i = threadIdx.x; i < ntop * 4u; i += kBlock) top[i] = src[i];
+    __syncthreads();
+  }
   const uint32_t n_closest = P.counts[kCntIn], n_shadow = P.counts[kCntShadowIn];
   TravStats st = {};
   uint32_t overflow = 0u;
@@ -112,7 +121,7 @@ __global__ __launch_bounds__(kBlock, (CURVES ? kTraceBlocksPerCUCurves : kTraceB
   const unsigned long long t_start = P.wave_log ? wall_clock64() : 0ull;
   trace_pv<2, STATS, CURVES>(sc, n_closest + n_shadow, &P.counts[kCntHead], sink, stk + threadIdx.x, kBlock,
                              P.spill + blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, st, &overflow,
-                             CURVES ? frm + threadIdx.x : nullptr);
+                             CURVES ? frm + threadIdx.x : nullptr, top, ntop);
   if (overflow) P.counts[kCntOverflow] = 1u;
   if (P.wave_log && __lane_id() == 0 && P.wave_log_launch < kWaveLogLaunches) {
     const uint32_t w = (blockIdx.x * kBlock + threadIdx.x) >> 6;

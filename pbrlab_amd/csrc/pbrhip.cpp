@@ -643,6 +643,7 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
   d.tex_pixels = s->d_tex_pixels.p, d.textures = s->d_tex_descs.p, d.num_textures = (uint32_t)s->tex_descs.size();
   d.num_curves = 0;
   for (uint8_t kd : kinds) d.num_curves += kd ? 1u : 0u;
+  d.top_nodes = gpu_built ? 0u : std::min<uint32_t>(num_nodes, (uint32_t)kTopNodes);
   // light sampling works on the meshes' local positions (light-manager.h:128-136 "TODO transform"), the raytracer on the
   // transformed ones: the doomed-path pretest against the light primitives (kernels.hip::misses_all_lights) is only the
   // traversal's own test when the two coincide
