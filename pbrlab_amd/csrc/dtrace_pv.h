@@ -34,6 +34,9 @@ constexpr int kPvRefillIdle = PB_REFILL;         // refill when at least this ma
 // Weights of one lane in the phase vote.  Measured on C2 (A/B, k_trace ms per frame): node:tri = 2:1 64.1, 1:1 60.9,
 // 3:4 59.0, 1:2 57.9, 1:3 58.0 -- primitives first: a lane parked at a leaf holds a shorter tmax for its own later box
 // tests and returns to the (much more frequent) node phase, so the node phase runs with more lanes.
+#ifndef PB_WALK_REFILL
+#define PB_WALK_REFILL 64
+#endif
 #ifndef PB_W_NODE
 #define PB_W_NODE 1
 #endif
@@ -131,7 +134,10 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
     unsigned long long idle_mask = __ballot(state == kStIdle || state >= kStDone);
     int n_idle = __popcll(idle_mask);
     // (a walking sink has work for its finished lanes even when the queue is empty: their walks go on)
-    if (n_idle >= kPvRefillIdle && (!exhausted || (Sink::kWalk && __ballot(state >= kStDone) != 0ull))) {
+    // (a walking sink's step is ~3x the work of tracing a ray: it waits for more lanes to be ready for theirs)
+    constexpr int kRefillAt = Sink::kWalk ? PB_WALK_REFILL : kPvRefillIdle;
+    const int n_busy_now = 64 - n_idle;
+    if ((n_idle >= kRefillAt || (Sink::kWalk && n_busy_now == 0)) && (!exhausted || (Sink::kWalk && __ballot(state >= kStDone) != 0ull))) {
       // ---- refill idle lanes from the queue
       if (!exhausted && batch_cur == batch_end) {
         uint32_t base = 0;

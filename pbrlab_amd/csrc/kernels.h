@@ -52,7 +52,8 @@ enum : uint32_t {
   kStatShadowRays, kStatShadowNodes, kStatShadowTris, kStatShadowCurves,
   kStatPvItNode, kStatPvItTri, kStatPvItCurve, kStatPvItRefill, kStatPvLnNode, kStatPvLnTri, kStatPvLnCurve,
   kStatTailClosestRays, kStatTailShadowRays, kStatPrunedRays,
-  kStatStepHist0, kStatStepHistLast = kStatStepHist0 + 7, kStatMaxSteps, kStatMaxWaveIters, kStatNum
+  kStatStepHist0, kStatStepHistLast = kStatStepHist0 + 7, kStatMaxSteps, kStatMaxWaveIters,
+  kStatWalkNodes, kStatWalkTris, kStatWalkTurns, kStatWalkSteps, kStatNum
 };
 
 // Resident 256-thread blocks per CU of the persistent traversal kernel = waves per SIMD (VGPR budget 512 / waves).

@@ -912,8 +912,13 @@ __global__ __launch_bounds__(kBlock, PB_WALK_WAVES) void k_sss_walk(PathState P,
                              CURVES ? frm + threadIdx.x : nullptr);
   if (overflow) P.counts[kCntOverflow] = 1u;
   if (STATS) {
-    const uint32_t a = wave_sum(sink.n_rays);
+    const uint32_t a = wave_sum(sink.n_rays), nn = wave_sum(st.nodes), nt = wave_sum(st.tris + st.curves);
     if (__lane_id() == 0 && a) atomicAdd(&P.stats[kStatTailClosestRays], (unsigned long long)a);
+    if (__lane_id() == 0) {
+      atomicAdd(&P.stats[kStatWalkNodes], (unsigned long long)nn), atomicAdd(&P.stats[kStatWalkTris], (unsigned long long)nt);
+      atomicAdd(&P.stats[kStatWalkTurns], (unsigned long long)(st.it_node + st.it_tri + st.it_curve));
+      atomicAdd(&P.stats[kStatWalkSteps], (unsigned long long)st.it_refill);
+    }
   }
 }
 
