@@ -35,7 +35,7 @@ constexpr int kPvRefillIdle = PB_REFILL;         // refill when at least this ma
 // 3:4 59.0, 1:2 57.9, 1:3 58.0 -- primitives first: a lane parked at a leaf holds a shorter tmax for its own later box
 // tests and returns to the (much more frequent) node phase, so the node phase runs with more lanes.
 #ifndef PB_WALK_REFILL
-#define PB_WALK_REFILL 64
+#define PB_WALK_REFILL 56
 #endif
 #ifndef PB_W_NODE
 #define PB_W_NODE 1

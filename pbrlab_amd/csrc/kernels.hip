@@ -842,6 +842,10 @@ __global__ __launch_bounds__(kBlock) void k_sss_step(PathState P, DScene sc, uin
 // left it before that event (ray, throughput, step index, generator state, hit record), and k_sss_step handles the event
 // as it always did.  A path therefore spends one or two wavefront iterations inside a medium instead of one per step; the
 // values computed are the same, in the same order.
+#ifndef PB_WALK_CAP
+#define PB_WALK_CAP 24u  // A/B on C3 (walk + step kernels, ms per frame): no cap 230, 128: 183, 64: 164, 32: 149, 24: 140, 16: 139, 12: 134 (but more iterations), 8: 138
+#endif
+constexpr uint32_t kWalkCap = PB_WALK_CAP;
 struct WalkSink {
   static constexpr bool kWalk = true;
   const PathState& P;
@@ -867,7 +871,9 @@ struct WalkSink {
   }
   __device__ __forceinline__ bool next(uint32_t tag, const Hit& h, V3& o, V3& d, float& tmin, float& tmax) {
     const uint32_t p = __float_as_uint(wl[8 * kBlock]);
-    if (h.slot == kNone) {
+    // A launch ends with its longest walk, so a walk is fast-forwarded by at most kWalkCap scatterings per launch; a longer
+    // one is handed back (k_sss_step applies its pending scattering) and goes on in the next iteration's launch.
+    if (h.slot == kNone && __float_as_uint(wl[7 * kBlock]) < kWalkCap) {
       WalkState w;
       w.org = o, w.dir = d, w.sigt = ld3(P.sss_sigt[p]), w.sigs = ld3(P.sss_sigs[p]);
       w.wthr = V3(wl[0], wl[kBlock], wl[2 * kBlock]), w.t_scatter = wl[3 * kBlock], w.bounce = __float_as_uint(wl[4 * kBlock]);
@@ -877,7 +883,7 @@ struct WalkSink {
         wl[0] = w.wthr.x, wl[kBlock] = w.wthr.y, wl[2 * kBlock] = w.wthr.z, wl[3 * kBlock] = w.t_scatter;
         wl[4 * kBlock] = __uint_as_float(w.bounce);
         wl[5 * kBlock] = __uint_as_float((uint32_t)w.rng_state), wl[6 * kBlock] = __uint_as_float((uint32_t)(w.rng_state >> 32));
-        wl[7 * kBlock] = __uint_as_float(1u);
+        wl[7 * kBlock] = __uint_as_float(__float_as_uint(wl[7 * kBlock]) + 1u);
         n_rays++;
         return true;
       }

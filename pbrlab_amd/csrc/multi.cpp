@@ -191,6 +191,7 @@ extern "C" int pbrhip_comm_gather_layer(pbrhip_comm* c, pbrhip_scene* s, const p
       if (int rc = ensure_pixels(s, d->width, d->height, d->tile_rank, world, d->shard_block)) return rc;
       const uint32_t npix = s->pk_npix;
       HIPCHK(s->xchg_send.reserve(shard_words(npix)));
+      if (npix == 0) return PBRHIP_OK;  // (the root posts no receive for a rank without pixels either)
       launch_layer_pack(st, s->pix_index.p, npix, d_rgba, d_count, s->xchg_send.p);
       HIPCHK(hipGetLastError());
       NCCLCHK(R, R->Send(s->xchg_send.p, 5 * (size_t)npix, ncclFloat32, root, c->comm, st));
