@@ -25,6 +25,7 @@ struct TravStats {
   uint32_t it_node, it_tri, it_curve, it_refill, ln_node, ln_tri, ln_curve;
   // per ray: steps (node visits + primitive tests) in power-of-two buckets (<= 16, 32, ... 1024, more) and the maximum
   uint32_t hist[8], max_steps;
+  uint32_t ahist[8], amax_steps;  // the same for any-hit (shadow) rays
 };
 
 __device__ __forceinline__ V3 ld3(const float4& a) { return V3(a.x, a.y, a.z); }

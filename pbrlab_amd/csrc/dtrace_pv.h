@@ -262,7 +262,7 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
           }
           if (any_ray && ok) {
             state = kStDoneOccluded;
-            if (STATS) st.hist[steps <= 16u ? 0 : (28 - __clz(steps - 1u) > 7 ? 7 : 28 - __clz(steps - 1u))]++, st.max_steps = steps > st.max_steps ? steps : st.max_steps;
+            if (STATS) st.ahist[steps <= 16u ? 0 : (28 - __clz(steps - 1u) > 7 ? 7 : 28 - __clz(steps - 1u))]++, st.amax_steps = steps > st.amax_steps ? steps : st.amax_steps;
           } else if (rem != 0u) {  // next primitive of the same leaf
             rem--, cur++;
             need_load = true;
@@ -278,7 +278,11 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
         if (sp == 0) {
           state = kStDone;
           advance = false;
-          if (STATS) st.hist[steps <= 16u ? 0 : (28 - __clz(steps - 1u) > 7 ? 7 : 28 - __clz(steps - 1u))]++, st.max_steps = steps > st.max_steps ? steps : st.max_steps;
+          if (STATS) {
+            const int b = steps <= 16u ? 0 : (28 - __clz(steps - 1u) > 7 ? 7 : 28 - __clz(steps - 1u));
+            if (any_ray) st.ahist[b]++, st.amax_steps = steps > st.amax_steps ? steps : st.amax_steps;
+            else st.hist[b]++, st.max_steps = steps > st.max_steps ? steps : st.max_steps;
+          }
         } else {
           sp--;
           // the LDS read is unconditional (a clamped index), the spill read the rare exception: one ds_read instead of a

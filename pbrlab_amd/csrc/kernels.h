@@ -53,7 +53,8 @@ enum : uint32_t {
   kStatPvItNode, kStatPvItTri, kStatPvItCurve, kStatPvItRefill, kStatPvLnNode, kStatPvLnTri, kStatPvLnCurve,
   kStatTailClosestRays, kStatTailShadowRays, kStatPrunedRays,
   kStatStepHist0, kStatStepHistLast = kStatStepHist0 + 7, kStatMaxSteps, kStatMaxWaveIters,
-  kStatWalkNodes, kStatWalkTris, kStatWalkTurns, kStatWalkSteps, kStatNum
+  kStatWalkNodes, kStatWalkTris, kStatWalkTurns, kStatWalkSteps,
+  kStatAnyHist0, kStatAnyHistLast = kStatAnyHist0 + 7, kStatAnyMaxSteps, kStatNum
 };
 
 // Resident 256-thread blocks per CU of the persistent traversal kernel = waves per SIMD (VGPR budget 512 / waves).

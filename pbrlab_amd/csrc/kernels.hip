@@ -144,6 +144,11 @@ __global__ __launch_bounds__(kBlock, (CURVES ? kTraceBlocksPerCUCurves : kTraceB
       uint32_t s = wave_sum(st.hist[i]);
       if (__lane_id() == 0 && s) atomicAdd(&P.stats[kStatStepHist0 + i], (unsigned long long)s);
     }
+    for (int i = 0; i < 8; i++) {
+      uint32_t s = wave_sum(st.ahist[i]);
+      if (__lane_id() == 0 && s) atomicAdd(&P.stats[kStatAnyHist0 + i], (unsigned long long)s);
+    }
+    atomicMax(&P.stats[kStatAnyMaxSteps], (unsigned long long)st.amax_steps);
     atomicMax(&P.stats[kStatMaxSteps], (unsigned long long)st.max_steps);
     if (__lane_id() == 0) atomicMax(&P.stats[kStatMaxWaveIters], (unsigned long long)(st.it_node + st.it_tri + st.it_curve + st.it_refill));
     if (threadIdx.x == 0 && blockIdx.x == 0) {

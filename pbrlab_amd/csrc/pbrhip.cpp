@@ -1193,9 +1193,12 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
                 hs[kStatPvLnTri] / (double)std::max<unsigned long long>(1, hs[kStatPvItTri]),
                 hs[kStatPvLnCurve] / (double)std::max<unsigned long long>(1, hs[kStatPvItCurve]));
       if (getenv("PBRHIP_PV_STATS")) {
-        fprintf(stderr, "pv steps per ray (<=16, 32, 64, 128, 256, 512, 1024, more):");
+        fprintf(stderr, "pv steps per closest-hit ray (<=16, 32, 64, 128, 256, 512, 1024, more):");
         for (int i = 0; i < 8; i++) fprintf(stderr, " %llu", hs[kStatStepHist0 + i]);
         fprintf(stderr, " | max %llu | most loop turns of one wave (whole render) %llu\n", hs[kStatMaxSteps], hs[kStatMaxWaveIters]);
+        fprintf(stderr, "pv steps per shadow ray:");
+        for (int i = 0; i < 8; i++) fprintf(stderr, " %llu", hs[kStatAnyHist0 + i]);
+        fprintf(stderr, " | max %llu\n", hs[kStatAnyMaxSteps]);
         fprintf(stderr, "walk: nodes %llu prims %llu | wave turns: traversal %llu, step / refill %llu\n", hs[kStatWalkNodes], hs[kStatWalkTris],
                 hs[kStatWalkTurns], hs[kStatWalkSteps]);
       }
