@@ -237,4 +237,72 @@ void build_bvh(const std::vector<float>& lo, const std::vector<float>& hi, const
   out->depth = depth;
 }
 
+uint32_t collapse_bvh4(const std::vector<BvhNode>& N2, std::vector<Bvh4Node>* out) {
+  out->clear();
+  if (N2.empty()) return 0;
+  struct Child {
+    uint32_t ref;
+    float lo[3], hi[3];
+  };
+  auto children_of = [&](uint32_t node, Child* c) {
+    int n = 0;
+    const BvhNode& b = N2[node];
+    for (int k = 0; k < 2; k++) {
+      const uint32_t ref = k ? b.c1 : b.c0;
+      if (ref == kEmptyChild) continue;
+      c[n].ref = ref;
+      for (int a = 0; a < 3; a++) c[n].lo[a] = b.lo[a][k], c[n].hi[a] = b.hi[a][k];
+      n++;
+    }
+    return n;
+  };
+  auto area = [](const Child& c) {
+    const float dx = c.hi[0] - c.lo[0], dy = c.hi[1] - c.lo[1], dz = c.hi[2] - c.lo[2];
+    return dx * dy + dy * dz + dz * dx;
+  };
+  struct Item {
+    uint32_t node2, out, level;
+  };
+  std::vector<Item> work;
+  out->emplace_back();
+  work.push_back({0u, 0u, 1u});
+  uint32_t levels = 0;
+  while (!work.empty()) {
+    const Item it = work.back();
+    work.pop_back();
+    levels = std::max(levels, it.level);
+    Child c[4];
+    int n = children_of(it.node2, c);
+    while (n < 4) {
+      int best = -1;
+      for (int i = 0; i < n; i++)
+        if (!(c[i].ref & kLeafBit) && (best < 0 || area(c[i]) > area(c[best]))) best = i;
+      if (best < 0) break;
+      Child g[2];
+      const int m = children_of(c[best].ref, g);
+      c[best] = g[0];
+      if (m > 1) c[n++] = g[1];
+    }
+    Bvh4Node nd;
+    memset(&nd, 0, sizeof(nd));
+    for (int i = 0; i < 4; i++) {
+      nd.c[i] = kEmptyChild;
+      for (int a = 0; a < 3; a++) nd.lo[a][i] = nd.hi[a][i] = std::numeric_limits<float>::quiet_NaN();
+    }
+    for (int i = 0; i < n; i++) {
+      for (int a = 0; a < 3; a++) nd.lo[a][i] = c[i].lo[a], nd.hi[a][i] = c[i].hi[a];
+      if (c[i].ref & kLeafBit) {
+        nd.c[i] = c[i].ref;
+      } else {
+        const uint32_t id = (uint32_t)out->size();
+        out->emplace_back();
+        nd.c[i] = 2u * id;  // item index: a wide node is two 64-byte items
+        work.push_back({c[i].ref, id, it.level + 1u});
+      }
+    }
+    (*out)[it.out] = nd;
+  }
+  return 3u * levels;
+}
+
 }  // namespace pb

@@ -55,6 +55,18 @@ struct alignas(16) BvhNode {
 };
 static_assert(sizeof(BvhNode) == 64, "node must be 64 B");
 
+// The same tree with four children per node (bvh_build.cpp::collapse_bvh4: every node of the binary tree absorbs the
+// children of its largest children): 128 B = two 64-byte items; [bound][axis][child] so that one 16-byte load holds the four
+// children's values of one bound.  Child references as above, an inner child's reference being its ITEM index (2 x node).
+// Boxes are the binary tree's (already widened).  An unused child has NaN bounds (never hit) and reference kEmptyChild.
+struct alignas(16) Bvh4Node {
+  float lo[3][4];
+  float hi[3][4];
+  uint32_t c[4];
+  uint32_t pad[4];
+};
+static_assert(sizeof(Bvh4Node) == 128, "wide node must be 128 B");
+
 constexpr uint32_t kSlotHasNormals = 1u;
 constexpr uint32_t kSlotIsCurve = 2u;
 constexpr uint32_t kSlotMatHair = 4u;   // material kind, denormalised here so a hit can be routed without
@@ -162,6 +174,8 @@ struct DScene {
   const float* tex_pixels;
   const TexDesc* textures;
   uint32_t num_nodes, num_slots, num_lights, num_materials, num_curves, num_textures, num_lrecs;
+  const float4* wide;           // 4-wide tree: wide_nodes x Bvh4Node followed by a copy of the slots (one array of 64-byte items), or null
+  uint32_t wide_nodes;
   uint32_t top_nodes;           // nodes 0 .. top_nodes-1 are the breadth-first top of the tree (<= kTopNodes; 0: not numbered that way)
   uint32_t lights_transformed;  // an emissive instance has a transform: lrecs / light_boxes are not what the raytracer sees
 };

@@ -26,6 +26,7 @@ struct TravStats {
   // per ray: steps (node visits + primitive tests) in power-of-two buckets (<= 16, 32, ... 1024, more) and the maximum
   uint32_t hist[8], max_steps;
   uint32_t ahist[8], amax_steps;  // the same for any-hit (shadow) rays
+  uint32_t refill_ticks;          // 100 MHz ticks the wave spent in refills (lane 0)
 };
 
 __device__ __forceinline__ V3 ld3(const float4& a) { return V3(a.x, a.y, a.z); }
@@ -125,6 +126,53 @@ __device__ __forceinline__ void box_test2(const float4& n0, const float4& n1, co
   h1 = a1 <= b1 && b1 >= tmin && a1 <= tmax;
 }
 
+// The same slab test on the four boxes of a wide node (Bvh4Node): lx .. hz hold one bound of the four children each.
+// ta / tb: entry / exit distance of each box (widened like box_test2's); the caller compares them with the ray's interval.
+__device__ __forceinline__ void box_test4(const float4& lx, const float4& ly, const float4& lz, const float4& hx, const float4& hy,
+                                          const float4& hz, V3 o, V3 inv, float ta[4], float tb[4]) {
+  const float e = 1.52587890625e-05f;
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const f2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
+    const f2 ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
+    const f2 ax = h ? f2{lx.z, lx.w} : f2{lx.x, lx.y}, bx = h ? f2{hx.z, hx.w} : f2{hx.x, hx.y};
+    const f2 ay = h ? f2{ly.z, ly.w} : f2{ly.x, ly.y}, by = h ? f2{hy.z, hy.w} : f2{hy.x, hy.y};
+    const f2 az = h ? f2{lz.z, lz.w} : f2{lz.x, lz.y}, bz = h ? f2{hz.z, hz.w} : f2{hz.x, hz.y};
+    f2 p = (ax - ox) * ix, q = (bx - ox) * ix;
+    f2 a = __builtin_elementwise_min(p, q), b = __builtin_elementwise_max(p, q);
+    p = (ay - oy) * iy, q = (by - oy) * iy;
+    a = __builtin_elementwise_max(a, __builtin_elementwise_min(p, q)), b = __builtin_elementwise_min(b, __builtin_elementwise_max(p, q));
+    p = (az - oz) * iz, q = (bz - oz) * iz;
+    a = __builtin_elementwise_max(a, __builtin_elementwise_min(p, q)), b = __builtin_elementwise_min(b, __builtin_elementwise_max(p, q));
+    ta[2 * h] = __builtin_fmaf(-fabsf(a.x), e, a.x), ta[2 * h + 1] = __builtin_fmaf(-fabsf(a.y), e, a.y);
+    tb[2 * h] = __builtin_fmaf(fabsf(b.x), e, b.x), tb[2 * h + 1] = __builtin_fmaf(fabsf(b.y), e, b.y);
+  }
+}
+
+// One step at a wide node: the children the ray's interval [tmin, tmax] hits, nearest first.  k[0..3] ascending; a key is the
+// child's entry distance (>= 0 as an integer; its two low bits hold the child index, wide_ref), 0xFFFFFFFF = not hit.
+constexpr uint32_t kWideMiss = 0xFFFFFFFFu;
+__device__ __forceinline__ void wide_node_keys(const float4& lx, const float4& ly, const float4& lz, const float4& hx, const float4& hy,
+                                               const float4& hz, V3 o, V3 inv, float tmin, float tmax, uint32_t k[4]) {
+  float ta[4], tb[4];
+  box_test4(lx, ly, lz, hx, hy, hz, o, inv, ta, tb);
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const bool h = ta[i] <= tb[i] && tb[i] >= tmin && ta[i] <= tmax;
+    const int bits = (int)__float_as_uint(ta[i]);
+    k[i] = h ? ((uint32_t)(bits < 0 ? 0 : bits) & ~3u) | (uint32_t)i : kWideMiss;
+  }
+  auto cex = [](uint32_t& a, uint32_t& b) {
+    const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+    a = lo, b = hi;
+  };
+  cex(k[0], k[1]), cex(k[2], k[3]), cex(k[0], k[2]), cex(k[1], k[3]), cex(k[1], k[2]);
+}
+__device__ __forceinline__ uint32_t wide_ref(const float4& refs, uint32_t key) {
+  const uint32_t a = __float_as_uint((key & 1u) ? refs.y : refs.x), b = __float_as_uint((key & 1u) ? refs.w : refs.z);
+  return (key & 2u) ? b : a;
+}
+
 // Leaf processing.  any: returns true on the first accepted hit.
 // MODE: 0 = closest hit, 1 = any hit, 2 = per lane (`any_rt`), as in trace_pv.
 template <int MODE, bool STATS, bool CURVES>
@@ -158,7 +206,8 @@ __device__ __forceinline__ bool leaf_test(const DScene& sc, uint32_t leaf, V3 o,
 }
 
 // BVH2 traversal, near child first, far child on a per-lane stack (stack[i * stride]).
-template <int MODE, bool STATS, bool CURVES>
+// WIDE: the 4-wide tree (sc.wide must not be null): nearest hit child next, the others pushed farthest first.
+template <int MODE, bool STATS, bool CURVES, bool WIDE = false>
 __device__ __forceinline__ bool traverse_mode(const DScene& sc, V3 o, V3 d, float tmin, float tmax, Hit& hit,
                                               uint32_t* stack, uint32_t stride, TravStats& st, uint32_t* overflow, bool any_rt) {
   hit.slot = kNone;
@@ -170,6 +219,36 @@ __device__ __forceinline__ bool traverse_mode(const DScene& sc, V3 o, V3 d, floa
   uint32_t cur = 0;
   for (;;) {
     // cur is an internal node
+    if (WIDE) {
+      const float4* np = sc.wide + (size_t)cur * 4u;  // (a wide node's reference is its 64-byte item index)
+      const float4 lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5], refs = np[6];
+      if (STATS) st.nodes++;
+      uint32_t k[4];
+      wide_node_keys(lx, ly, lz, hx, hy, hz, o, inv, tmin, best_t, k);
+#pragma unroll
+      for (int j = 3; j >= 1; j--) {
+        if (k[j] == kWideMiss) continue;
+        if (sp < kStackDepth) {
+          stack[(uint32_t)sp * stride] = wide_ref(refs, k[j]);
+          sp++;
+        } else {
+          *overflow = 1u;
+        }
+      }
+      uint32_t next = k[0] == kWideMiss ? kEmptyChild : wide_ref(refs, k[0]);
+      for (;;) {
+        if (next == kEmptyChild) {
+          if (sp == 0) return hit.slot != kNone;
+          sp--;
+          next = stack[(uint32_t)sp * stride];
+        }
+        if (!(next & kLeafBit)) break;
+        if (leaf_test<MODE, STATS, CURVES>(sc, next, o, d, tmin, best_t, hit, st, any_rt)) return true;
+        next = kEmptyChild;
+      }
+      cur = next;
+      continue;
+    }
     const float4* np = reinterpret_cast<const float4*>(sc.nodes + cur);
     float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
     if (STATS) st.nodes++;
@@ -206,10 +285,10 @@ __device__ __forceinline__ bool traverse_mode(const DScene& sc, V3 o, V3 d, floa
     cur = next;
   }
 }
-template <bool ANY, bool STATS, bool CURVES>
+template <bool ANY, bool STATS, bool CURVES, bool WIDE = false>
 __device__ __forceinline__ bool traverse(const DScene& sc, V3 o, V3 d, float tmin, float tmax, Hit& hit,
                                          uint32_t* stack, uint32_t stride, TravStats& st, uint32_t* overflow) {
-  return traverse_mode<ANY ? 1 : 0, STATS, CURVES>(sc, o, d, tmin, tmax, hit, stack, stride, st, overflow, ANY);
+  return traverse_mode<ANY ? 1 : 0, STATS, CURVES, WIDE>(sc, o, d, tmin, tmax, hit, stack, stride, st, overflow, ANY);
 }
 
 }  // namespace pb

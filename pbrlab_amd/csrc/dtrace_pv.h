@@ -64,7 +64,9 @@ enum : uint32_t { kStIdle = 0, kStNode = 1, kStTri = 2, kStCurve = 3, kStDone = 
 // Traversal stack: the first kPvLdsStack entries of each lane live in LDS (stk_base[i * stride]), deeper ones
 // spill to a per-thread global area (spill[(i - kPvLdsStack) * spill_stride]); keeping the LDS part small is
 // what lets 6 blocks (24 waves) share a CU.
-template <int MODE, bool STATS, bool CURVES, typename Sink>
+// WIDE: the 4-wide tree (sc.wide: Bvh4Node, dscene.h) instead of the binary one -- half the dependent fetches per ray, twice
+// the box arithmetic per fetch; hit children are visited nearest first (sorted by entry distance), like the binary tree's.
+template <int MODE, bool STATS, bool CURVES, bool WIDE, typename Sink>
 __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t* head, Sink& sink, uint32_t* stk_base,
                                          uint32_t stride, uint32_t* spill, uint32_t spill_stride, TravStats& st,
                                          uint32_t* overflow, float* frame = nullptr, const float4* top = nullptr,
@@ -126,6 +128,10 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
   uint32_t cur = 0;  // index of the current 64-byte item (node; TRI/CURVE: num_nodes + slot)
   float4 D0 = make_float4(0, 0, 0, 0), D1 = D0, D2 = D0;  // prefetched node / primitive slot
   float2 D3 = make_float2(0, 0);                           // a node's two child references
+  float4 D4 = D0, D5 = D0, D6 = D0, D7 = D0;              // WIDE: D0..D2 / D4..D6 = lower / upper bounds x, y, z of the four children, D7 = their references
+  // items (64 B) of the array the traversal walks: the binary tree's nodes then the slots, or the wide nodes (two items each) then the slots
+  const float4* const items = WIDE ? sc.wide : reinterpret_cast<const float4*>(sc.nodes);
+  const uint32_t slot0 = WIDE ? 2u * sc.wide_nodes : sc.num_nodes;  // item index of slot 0
 
   for (;;) {
     // `advance`: the lane needs a new item; `next` is its reference when have_next, else it is popped
@@ -139,6 +145,7 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
     const int n_busy_now = 64 - n_idle;
     if ((n_idle >= kRefillAt || (Sink::kWalk && n_busy_now == 0)) && (!exhausted || (Sink::kWalk && __ballot(state >= kStDone) != 0ull))) {
       // ---- refill idle lanes from the queue
+      const unsigned long long t_refill = STATS ? wall_clock64() : 0ull;
       if (!exhausted && batch_cur == batch_end) {
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(head, batch);
@@ -198,7 +205,11 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
         advance = true, have_next = true, next = 0u;  // root is always an internal node
       }
       batch_cur += take;
-      if (STATS && lane == 0) st.it_refill++;
+      if (STATS) {
+        // (the tick count is taken after the new rays' loads have landed: the wave waits for them before it goes on)
+        __builtin_amdgcn_s_waitcnt(0x0070);
+        if (lane == 0) st.it_refill++, st.refill_ticks += (uint32_t)(wall_clock64() - t_refill);
+      }
     } else {
       if (n_idle == 64) break;  // queue exhausted and every lane done
       unsigned long long node_mask = __ballot(state == kStNode);
@@ -215,7 +226,42 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
       }
       if (phase == 0) {
         // ---- NODE phase
-        if (state == kStNode) {
+        if (WIDE && state == kStNode) {
+          if (STATS) (any_ray ? st.anodes : st.nodes)++, steps++;
+          uint32_t k[4];
+          wide_node_keys(D0, D1, D2, D4, D5, D6, o, inv, tmin, hit.t, k);
+          auto ref_of = [&](uint32_t key) { return wide_ref(D7, key); };
+          advance = true;
+          have_next = k[0] != kWideMiss;
+          next = ref_of(k[0]);
+          if (k[1] != kWideMiss) {  // the other hit children go on the stack, farthest first
+            if (sp + 3 <= kPvLdsStack) {
+              // (an entry written for a child that was not hit lies above the new top or is overwritten by the next one)
+              uint32_t p = (uint32_t)sp;
+              stk_base[p * stride] = ref_of(k[3]);
+              p += (k[3] != kWideMiss) ? 1u : 0u;
+              stk_base[p * stride] = ref_of(k[2]);
+              p += (k[2] != kWideMiss) ? 1u : 0u;
+              stk_base[p * stride] = ref_of(k[1]);
+              sp = (int)p + 1;
+            } else {
+#pragma unroll
+              for (int j = 3; j >= 1; j--) {
+                if (k[j] == kWideMiss) continue;
+                const uint32_t farc = ref_of(k[j]);
+                if (sp < kPvLdsStack) {
+                  stk_base[(uint32_t)sp * stride] = farc;
+                  sp++;
+                } else if (sp < kStackDepth) {
+                  spill[(uint32_t)(sp - kPvLdsStack) * spill_stride] = farc;
+                  sp++;
+                } else {
+                  *overflow = 1u;
+                }
+              }
+            }
+          }
+        } else if (state == kStNode) {
           if (STATS) (any_ray ? st.anodes : st.nodes)++, steps++;
           uint32_t c0 = __float_as_uint(D3.x), c1 = __float_as_uint(D3.y);
           float t0, t1;
@@ -256,9 +302,9 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
             f.by = V3(frame[6 * stride], frame[7 * stride], frame[8 * stride]), f.inv_len = frame[9 * stride];
             ok = segment_test(D0, D1, __float_as_uint(D2.x), o, f, tmin, hit.t, t, u, v);
           }
-          if (ok && !any_ray && t == hit.t && hit.slot != kNone) ok = sc.shade[cur - sc.num_nodes].gid < sc.shade[hit.slot & kHitSlotMask].gid;
+          if (ok && !any_ray && t == hit.t && hit.slot != kNone) ok = sc.shade[cur - slot0].gid < sc.shade[hit.slot & kHitSlotMask].gid;
           if (ok) {
-            hit.t = t, hit.u = u, hit.v = v, hit.slot = (cur - sc.num_nodes) | __float_as_uint(D2.w);  // + routing bits (dscene.h)
+            hit.t = t, hit.u = u, hit.v = v, hit.slot = (cur - slot0) | __float_as_uint(D2.w);  // + routing bits (dscene.h)
           }
           if (any_ray && ok) {
             state = kStDoneOccluded;
@@ -294,7 +340,7 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
       if (advance) {
         need_load = true;
         if (next & kLeafBit) {
-          cur = ((next & 0x3FFFFFFFu) >> 3) + sc.num_nodes;  // slots follow the nodes in one array of 64-byte items
+          cur = ((next & 0x3FFFFFFFu) >> 3) + slot0;  // slots follow the nodes in one array of 64-byte items
           rem = next & 7u;
           state = (CURVES && (next & kCurveBit)) ? kStCurve : kStTri;
         } else {
@@ -303,7 +349,11 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
         }
       }
     }
-    if (need_load) {
+    if (WIDE && need_load) {
+      const float4* g = items + (size_t)cur * 4u;
+      D0 = g[0], D1 = g[1], D2 = g[2];
+      if (state == kStNode) D4 = g[3], D5 = g[4], D6 = g[5], D7 = g[6];
+    } else if (need_load) {
       if (kTopNodes > 0 && cur < ntop) {  // the top of the tree: every ray passes through it
         const float4* g = top + cur * 4u;
         D0 = g[0], D1 = g[1], D2 = g[2];

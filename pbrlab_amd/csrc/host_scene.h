@@ -71,6 +71,11 @@ struct FlatBvh {
 void build_bvh(const std::vector<float>& lo, const std::vector<float>& hi, const std::vector<uint8_t>& kinds,
                FlatBvh* out);
 
+// The binary tree collapsed to four children per node (dscene.h::Bvh4Node): a node takes its two children and, while it has
+// room, replaces the inner child of largest surface area by that child's two children.  Returns the stack depth a
+// near-first traversal of the wide tree can need (three pushes per level).
+uint32_t collapse_bvh4(const std::vector<BvhNode>& nodes, std::vector<Bvh4Node>* out);
+
 // The same tree format built on the GPU (bvh_gpu.hip: Morton-order linear BVH).  nodes_out: DEVICE array of
 // max(n - 1, 1) nodes; order_out: slot -> primitive index; depth_out: traversal stack depth needed.
 hipError_t build_bvh_gpu(hipStream_t st, const std::vector<float>& lo, const std::vector<float>& hi,

@@ -66,6 +66,10 @@ enum : uint32_t {
 #ifndef PB_TRACE_BLOCKS_CURVES
 #define PB_TRACE_BLOCKS_CURVES 6
 #endif
+#ifndef PB_TRACE_BLOCKS_WIDE
+#define PB_TRACE_BLOCKS_WIDE 5
+#endif
+constexpr uint32_t kTraceBlocksPerCUWide = PB_TRACE_BLOCKS_WIDE;  // the 4-wide tree's kernel holds a 128-byte node in registers
 constexpr uint32_t kTraceBlocksPerCU = PB_TRACE_BLOCKS, kTraceBlocksPerCUCurves = PB_TRACE_BLOCKS_CURVES;
 constexpr uint32_t kTraceGridCap = 256 * (kTraceBlocksPerCU > kTraceBlocksPerCUCurves ? kTraceBlocksPerCU : kTraceBlocksPerCUCurves);  // persistent traversal: at most the resident blocks (sizes the spill area)
 constexpr uint32_t kShadeGridCap = 256 * 8;

@@ -101,12 +101,12 @@ struct TraceSink {
   }
 };
 
-template <bool STATS, bool CURVES>
-__global__ __launch_bounds__(kBlock, (CURVES ? kTraceBlocksPerCUCurves : kTraceBlocksPerCU)) void k_trace(PathState P, DScene sc) {
+template <bool STATS, bool CURVES, bool WIDE = false>
+__global__ __launch_bounds__(kBlock, (WIDE ? kTraceBlocksPerCUWide : (CURVES ? kTraceBlocksPerCUCurves : kTraceBlocksPerCU))) void k_trace(PathState P, DScene sc) {
   __shared__ uint32_t stk[kPvLdsStack * kBlock];
   __shared__ float frm[CURVES ? 10 * kBlock : 1];
   // the top of the tree in LDS (triangle-only scenes: with the ribbon frames of curve scenes it would cost a block per CU)
-  constexpr bool kStageTop = !CURVES && kTopNodes > 0;
+  constexpr bool kStageTop = !CURVES && !WIDE && kTopNodes > 0;
   __shared__ float4 top[kStageTop ? kTopNodes * 4 : 1];
   const uint32_t ntop = kStageTop ? sc.top_nodes : 0u;
   if (kStageTop) {
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(kBlock, (CURVES ? kTraceBlocksPerCUCurves : kTraceB
   uint32_t overflow = 0u;
   TraceSink sink = {P, n_closest};
   const unsigned long long t_start = P.wave_log ? wall_clock64() : 0ull;
-  trace_pv<2, STATS, CURVES>(sc, n_closest + n_shadow, &P.counts[kCntHead], sink, stk + threadIdx.x, kBlock,
+  trace_pv<2, STATS, CURVES, WIDE>(sc, n_closest + n_shadow, &P.counts[kCntHead], sink, stk + threadIdx.x, kBlock,
                              P.spill + blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, st, &overflow,
                              CURVES ? frm + threadIdx.x : nullptr, top, ntop);
   if (overflow) P.counts[kCntOverflow] = 1u;
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(kBlock, (CURVES ? kTraceBlocksPerCUCurves : kTraceB
     const uint32_t w = (blockIdx.x * kBlock + threadIdx.x) >> 6;
     if (w < kWaveLogWaves) {
       unsigned long long* o = P.wave_log + ((size_t)P.wave_log_launch * kWaveLogWaves + w) * 4;
-      o[0] = t_start, o[1] = wall_clock64(), o[2] = st.it_refill, o[3] = st.it_node + st.it_tri + st.it_curve;
+      o[0] = t_start, o[1] = wall_clock64(), o[2] = st.it_refill | ((unsigned long long)st.refill_ticks << 32), o[3] = st.it_node + st.it_tri + st.it_curve;
     }
   }
   if (STATS) {
@@ -918,7 +918,7 @@ __global__ __launch_bounds__(kBlock, PB_WALK_WAVES) void k_sss_walk(PathState P,
   TravStats st = {};
   uint32_t overflow = 0u;
   WalkSink sink = {P, rng_inc, walk + threadIdx.x, 0u};
-  trace_pv<0, STATS, CURVES>(sc, n, &P.counts[kCntWalkHead], sink, stk + threadIdx.x, kBlock,
+  trace_pv<0, STATS, CURVES, false>(sc, n, &P.counts[kCntWalkHead], sink, stk + threadIdx.x, kBlock,
                              P.spill + blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, st, &overflow,
                              CURVES ? frm + threadIdx.x : nullptr);
   if (overflow) P.counts[kCntOverflow] = 1u;
@@ -950,7 +950,7 @@ __global__ __launch_bounds__(kBlock, PB_WALK_WAVES) void k_sss_walk(PathState P,
 #define PB_TAIL_WAVES 3  // min waves per SIMD of k_tail (<= 168 VGPRs: three blocks per CU hold 196 k lanes, so every path of a 256 Ki tail starts at once;
                          // A/B on C2: 2 -> 59.1 ms per frame / 12.1 ms for an eighth, 3 -> 58.6 / 11.8)
 #endif
-template <bool CURVES, bool STATS>
+template <bool CURVES, bool STATS, bool WIDE = false>
 __global__ __launch_bounds__(kBlock, PB_TAIL_WAVES) void k_tail(PathState P, DScene sc, uint64_t rng_inc) {
   __shared__ uint32_t stk[kStackDepth * kBlock];
   const uint32_t n = P.counts[kCntIn];
@@ -1002,14 +1002,14 @@ __global__ __launch_bounds__(kBlock, PB_TAIL_WAVES) void k_tail(PathState P, DSc
         if (want_shadow) {
           const float4 o4 = P.ray_o[p], d4 = P.sh_d[p];
           Hit h;
-          const bool occluded = traverse<true, false, CURVES>(sc, ld3(o4), ld3(d4), o4.w, d4.w, h, stack, kBlock, st, &overflow);
+          const bool occluded = traverse<true, false, CURVES, WIDE>(sc, ld3(o4), ld3(d4), o4.w, d4.w, h, stack, kBlock, st, &overflow);
           sink.done(p | 0x80000000u, h, occluded);
           n_shadow++;
         }
         if (want_closest) {
           const float4 o4 = P.ray_o[p], d4 = P.ray_d[p];
           Hit h;
-          traverse<false, false, CURVES>(sc, ld3(o4), ld3(d4), o4.w, d4.w, h, stack, kBlock, st, &overflow);
+          traverse<false, false, CURVES, WIDE>(sc, ld3(o4), ld3(d4), o4.w, d4.w, h, stack, kBlock, st, &overflow);
           P.hit[p] = make_float4(h.t, h.u, h.v, __uint_as_float(h.slot));
           n_closest++;
         }
@@ -1028,7 +1028,7 @@ __global__ __launch_bounds__(kBlock, PB_TAIL_WAVES) void k_tail(PathState P, DSc
         if (odd) o4 = make_float4(ox, oy, oz, ow), d4 = make_float4(sx, sy, sz, sw), go = left_shadow;
         Hit h = {0.f, 0.f, 0.f, kNone};
         bool occluded = false;
-        if (go) occluded = traverse_mode<2, false, CURVES>(sc, ld3(o4), ld3(d4), o4.w, d4.w, h, stack, kBlock, st, &overflow, odd);
+        if (go) occluded = traverse_mode<2, false, CURVES, WIDE>(sc, ld3(o4), ld3(d4), o4.w, d4.w, h, stack, kBlock, st, &overflow, odd);
         const bool occ_right = __shfl((int)occluded, (int)(lane | 1u)) != 0;
         if (want_shadow) {
           Hit none = {0.f, 0.f, 0.f, kNone};
@@ -1127,20 +1127,21 @@ struct HookSink {
     else hits[i] = hook_result(sc, ld3(rays[2 * i]), ld3(rays[2 * i + 1]), h);
   }
 };
-template <bool ANY>
+template <bool ANY, bool WIDE>  // WIDE: the 4-wide tree (triangle-only scenes), as k_trace uses it
 __global__ __launch_bounds__(kBlock) void k_hook_pv(DScene sc, const float4* __restrict__ rays, uint32_t n, HookHit* hits,
                                                     uint8_t* occ, uint32_t* counts, uint32_t* spill) {
   __shared__ uint32_t stk[kPvLdsStack * kBlock];
-  __shared__ float frm[10 * kBlock];
+  __shared__ float frm[WIDE ? 1 : 10 * kBlock];
   TravStats st = {};
   uint32_t overflow = 0u;
   HookSink sink = {sc, rays, hits, occ};
-  trace_pv<ANY ? 1 : 0, false, true>(sc, n, &counts[kCntHead], sink, stk + threadIdx.x, kBlock,
-                             spill + blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, st, &overflow, frm + threadIdx.x);
+  trace_pv<ANY ? 1 : 0, false, !WIDE, WIDE>(sc, n, &counts[kCntHead], sink, stk + threadIdx.x, kBlock,
+                             spill + blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, st, &overflow, WIDE ? nullptr : frm + threadIdx.x);
   if (overflow) counts[kCntOverflow] = 1u;
 }
 // One ray per thread, plain stack traversal (dtrace.h): an independent second implementation, selected with
 // PBRHIP_SIMPLE_TRAVERSAL=1, that must agree with the production traversal bit for bit.
+template <bool WIDE>
 __global__ __launch_bounds__(kBlock) void k_hook_closest(DScene sc, const float4* __restrict__ rays, uint32_t n,
                                                          HookHit* __restrict__ out, uint32_t* overflow_flag) {
   __shared__ uint32_t stk[kStackDepth * kBlock];
@@ -1149,11 +1150,12 @@ __global__ __launch_bounds__(kBlock) void k_hook_closest(DScene sc, const float4
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
     float4 o4 = rays[2 * i], d4 = rays[2 * i + 1];
     Hit h;
-    traverse<false, false, true>(sc, ld3(o4), ld3(d4), o4.w, fminf(d4.w, INFINITY), h, stk + threadIdx.x, kBlock, st, &overflow);
+    traverse<false, false, !WIDE, WIDE>(sc, ld3(o4), ld3(d4), o4.w, fminf(d4.w, INFINITY), h, stk + threadIdx.x, kBlock, st, &overflow);
     out[i] = hook_result(sc, ld3(o4), ld3(d4), h);
   }
   if (overflow) *overflow_flag = 1u;
 }
+template <bool WIDE>
 __global__ __launch_bounds__(kBlock) void k_hook_any(DScene sc, const float4* __restrict__ rays, uint32_t n,
                                                      uint8_t* __restrict__ out, uint32_t* overflow_flag) {
   __shared__ uint32_t stk[kStackDepth * kBlock];
@@ -1162,8 +1164,8 @@ __global__ __launch_bounds__(kBlock) void k_hook_any(DScene sc, const float4* __
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
     float4 o4 = rays[2 * i], d4 = rays[2 * i + 1];
     Hit h;
-    out[i] = traverse<true, false, true>(sc, ld3(o4), ld3(d4), o4.w, fminf(d4.w, INFINITY), h, stk + threadIdx.x, kBlock, st,
-                                         &overflow)
+    out[i] = traverse<true, false, !WIDE, WIDE>(sc, ld3(o4), ld3(d4), o4.w, fminf(d4.w, INFINITY), h, stk + threadIdx.x, kBlock, st,
+                                                &overflow)
                  ? 1
                  : 0;
   }
@@ -1181,6 +1183,11 @@ __global__ void k_advance(uint32_t* counts) {
 }
 
 // ------------------------------------------------------------------ launchers
+// the 4-wide tree serves triangle-only scenes whose tree was built on the host (PBRHIP_WIDE=0: never; read per launch)
+static inline bool use_wide(const DScene& sc) {
+  const char* e = getenv("PBRHIP_WIDE");
+  return sc.wide != nullptr && sc.num_curves == 0 && !(e && atoi(e) == 0);
+}
 static inline uint32_t grid_for(uint32_t n, uint32_t cap) {
   uint32_t g = (n + kBlock - 1) / kBlock;
   if (g < 1) g = 1;
@@ -1201,9 +1208,12 @@ void launch_trace(hipStream_t s, const PathState& P, const DScene& sc, uint32_t 
   const uint32_t rays_per_wave = e ? (uint32_t)strtoul(e, nullptr, 10) : 4u;
   uint32_t blocks = (n_upper + 4u * rays_per_wave - 1u) / (4u * rays_per_wave);
   const bool curves = sc.num_curves != 0;
-  const uint32_t cap = 256u * (curves ? kTraceBlocksPerCUCurves : kTraceBlocksPerCU);
+  const bool wide = use_wide(sc);
+  const uint32_t cap = 256u * (wide ? kTraceBlocksPerCUWide : (curves ? kTraceBlocksPerCUCurves : kTraceBlocksPerCU));
   dim3 g(blocks < 1u ? 1u : (blocks < cap ? blocks : cap));
-  if (stats && curves) hipLaunchKernelGGL((k_trace<true, true>), g, dim3(kBlock), 0, s, P, sc);
+  if (wide && stats) hipLaunchKernelGGL((k_trace<true, false, true>), g, dim3(kBlock), 0, s, P, sc);
+  else if (wide) hipLaunchKernelGGL((k_trace<false, false, true>), g, dim3(kBlock), 0, s, P, sc);
+  else if (stats && curves) hipLaunchKernelGGL((k_trace<true, true>), g, dim3(kBlock), 0, s, P, sc);
   else if (stats) hipLaunchKernelGGL((k_trace<true, false>), g, dim3(kBlock), 0, s, P, sc);
   else if (curves) hipLaunchKernelGGL((k_trace<false, true>), g, dim3(kBlock), 0, s, P, sc);
   else hipLaunchKernelGGL((k_trace<false, false>), g, dim3(kBlock), 0, s, P, sc);
@@ -1250,7 +1260,9 @@ void launch_tail(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n
   uint32_t blocks = (n_upper + 3u) / 4u;  // one path per wave while that fits, at most 2 blocks per CU
   dim3 g(blocks < 1u ? 1u : (blocks < PB_TAIL_BLOCKS ? blocks : PB_TAIL_BLOCKS));
   const bool curves = sc.num_curves != 0;
-  if (stats && curves) hipLaunchKernelGGL((k_tail<true, true>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
+  if (use_wide(sc) && stats) hipLaunchKernelGGL((k_tail<false, true, true>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
+  else if (use_wide(sc)) hipLaunchKernelGGL((k_tail<false, false, true>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
+  else if (stats && curves) hipLaunchKernelGGL((k_tail<true, true>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
   else if (stats) hipLaunchKernelGGL((k_tail<false, true>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
   else if (curves) hipLaunchKernelGGL((k_tail<true, false>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
   else hipLaunchKernelGGL((k_tail<false, false>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
@@ -1270,18 +1282,30 @@ void launch_advance(hipStream_t s, const PathState& P) { hipLaunchKernelGGL(k_ad
 // counts: kCntNum zeroed words (queue head + overflow flag); spill: traversal-stack spill area
 void launch_hook_closest(hipStream_t s, const DScene& sc, const float4* rays, uint32_t n, HookHit* out, uint32_t* counts,
                          uint32_t* spill, bool simple) {
-  if (simple)
-    hipLaunchKernelGGL(k_hook_closest, dim3(grid_for(n, 4096)), dim3(kBlock), 0, s, sc, rays, n, out, counts + kCntOverflow);
+  const bool wide = use_wide(sc);
+  if (simple && wide)
+    hipLaunchKernelGGL(k_hook_closest<true>, dim3(grid_for(n, 4096)), dim3(kBlock), 0, s, sc, rays, n, out, counts + kCntOverflow);
+  else if (simple)
+    hipLaunchKernelGGL(k_hook_closest<false>, dim3(grid_for(n, 4096)), dim3(kBlock), 0, s, sc, rays, n, out, counts + kCntOverflow);
+  else if (wide)
+    hipLaunchKernelGGL((k_hook_pv<false, true>), dim3(grid_for(n, kTraceGridCap)), dim3(kBlock), 0, s, sc, rays, n, out,
+                       (uint8_t*)nullptr, counts, spill);
   else
-    hipLaunchKernelGGL((k_hook_pv<false>), dim3(grid_for(n, kTraceGridCap)), dim3(kBlock), 0, s, sc, rays, n, out,
+    hipLaunchKernelGGL((k_hook_pv<false, false>), dim3(grid_for(n, kTraceGridCap)), dim3(kBlock), 0, s, sc, rays, n, out,
                        (uint8_t*)nullptr, counts, spill);
 }
 void launch_hook_any(hipStream_t s, const DScene& sc, const float4* rays, uint32_t n, uint8_t* out, uint32_t* counts,
                      uint32_t* spill, bool simple) {
-  if (simple)
-    hipLaunchKernelGGL(k_hook_any, dim3(grid_for(n, 4096)), dim3(kBlock), 0, s, sc, rays, n, out, counts + kCntOverflow);
+  const bool wide = use_wide(sc);
+  if (simple && wide)
+    hipLaunchKernelGGL(k_hook_any<true>, dim3(grid_for(n, 4096)), dim3(kBlock), 0, s, sc, rays, n, out, counts + kCntOverflow);
+  else if (simple)
+    hipLaunchKernelGGL(k_hook_any<false>, dim3(grid_for(n, 4096)), dim3(kBlock), 0, s, sc, rays, n, out, counts + kCntOverflow);
+  else if (wide)
+    hipLaunchKernelGGL((k_hook_pv<true, true>), dim3(grid_for(n, kTraceGridCap)), dim3(kBlock), 0, s, sc, rays, n,
+                       (HookHit*)nullptr, out, counts, spill);
   else
-    hipLaunchKernelGGL((k_hook_pv<true>), dim3(grid_for(n, kTraceGridCap)), dim3(kBlock), 0, s, sc, rays, n,
+    hipLaunchKernelGGL((k_hook_pv<true, false>), dim3(grid_for(n, kTraceGridCap)), dim3(kBlock), 0, s, sc, rays, n,
                        (HookHit*)nullptr, out, counts, spill);
 }
 

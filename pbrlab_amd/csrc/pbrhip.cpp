@@ -613,6 +613,17 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
     if (num_nodes) HIPCHK(hipMemcpyAsync(s->d_nodes.p, bvh.nodes.data(), (size_t)num_nodes * sizeof(BvhNode), hipMemcpyHostToDevice, st));
   }
   if (ns) HIPCHK(hipMemcpyAsync(s->d_nodes.p + num_nodes, slots.data(), (size_t)ns * 64, hipMemcpyHostToDevice, st));
+  // the 4-wide tree of k_trace (host-built trees; PBRHIP_WIDE=0: none), followed by its own copy of the slots
+  std::vector<Bvh4Node> wide;
+  const char* wide_env = getenv("PBRHIP_WIDE");
+  if (!gpu_built && num_nodes && !(wide_env && atoi(wide_env) == 0)) {
+    if (collapse_bvh4(bvh.nodes, &wide) > (uint32_t)kStackDepth) wide.clear();
+  }
+  if (!wide.empty()) {
+    HIPCHK(s->d_wide.reserve(((size_t)wide.size() * 2 + ns) * 4));
+    HIPCHK(hipMemcpyAsync(s->d_wide.p, wide.data(), wide.size() * sizeof(Bvh4Node), hipMemcpyHostToDevice, st));
+    if (ns) HIPCHK(hipMemcpyAsync(s->d_wide.p + wide.size() * 8, slots.data(), (size_t)ns * 64, hipMemcpyHostToDevice, st));
+  }
   HIPCHK(s->d_shade.upload(shade, st));
   HIPCHK(s->d_materials.upload(mats, st));
   HIPCHK(s->d_light_cdf.upload(s->light_cdf, st));
@@ -643,6 +654,7 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
   d.tex_pixels = s->d_tex_pixels.p, d.textures = s->d_tex_descs.p, d.num_textures = (uint32_t)s->tex_descs.size();
   d.num_curves = 0;
   for (uint8_t kd : kinds) d.num_curves += kd ? 1u : 0u;
+  d.wide = wide.empty() ? nullptr : s->d_wide.p, d.wide_nodes = (uint32_t)wide.size();
   d.top_nodes = gpu_built ? 0u : std::min<uint32_t>(num_nodes, (uint32_t)kTopNodes);
   // light sampling works on the meshes' local positions (light-manager.h:128-136 "TODO transform"), the raytracer on the
   // transformed ones: the doomed-path pretest against the light primitives (kernels.hip::misses_all_lights) is only the

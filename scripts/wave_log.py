@@ -25,6 +25,8 @@ for L in range(64):
     start = (w[used, 0] - t0) / 100.0      # us (100 MHz)
     end = (w[used, 1] - t0) / 100.0
     turns = w[used, 3]
+    refills = w[used, 2] & np.uint64(0xFFFFFFFF)
+    rticks = (w[used, 2] >> np.uint64(32)) / 100.0  # us spent in refills (STATS=1)
     q = np.percentile(end, [10, 50, 90, 99, 100])
     print(f"launch {L:2d}: waves {used.sum():5d}  start p50 {np.median(start):6.1f} max {start.max():6.1f} us | end p10 {q[0]:7.1f} p50 {q[1]:7.1f} p90 {q[2]:7.1f} "
-          f"p99 {q[3]:7.1f} max {q[4]:7.1f} us | turns p50 {int(np.median(turns)):5d} max {int(turns.max()):5d} | us/turn p50 {np.median((end - start) / np.maximum(turns, 1)):.2f}")
+          f"p99 {q[3]:7.1f} max {q[4]:7.1f} us | turns p50 {int(np.median(turns)):5d} max {int(turns.max()):5d} | us/turn p50 {np.median((end - start) / np.maximum(turns, 1)):.2f} | refills p50 {int(np.median(refills))} in {np.median(rticks):.1f} us = {100 * rticks.sum() / np.maximum((end - start).sum(), 1e-9):.0f} % of the waves' time")

@@ -472,6 +472,33 @@ def test_gpu_built_bvh_gives_identical_results(pa, pairs, name):
         assert np.array_equal(layer.rgba.view(np.uint32), rgba.view(np.uint32))
 
 
+@pytest.mark.parametrize("name", ["lambert", "ggx", "sss", "textured"])
+def test_wide_and_binary_trees_agree(pa, pairs, name, monkeypatch):
+    """Triangle-only scenes are traversed through the 4-wide tree (k_trace, k_tail, the trace hooks); PBRHIP_WIDE=0 selects the
+    binary tree at every launch.  Hits and images must not depend on the choice (and both equal the oracle)."""
+    from pbrlab_amd import scenes
+    desc, sg, so = pairs[name]
+    lo, hi = so.FetchSceneAABB()
+    rays = scenes.random_rays((lo, hi), 30000, seed=11)
+    want_hits, want_any = so.trace_closest(rays), so.trace_any(rays)
+    rgba, cnt, _ = so.render(96, 64, 4, threads=4, math_mode=O.MATH_F64R)
+    for wide in ("1", "0"):
+        monkeypatch.setenv("PBRHIP_WIDE", wide)
+        for simple in (False, True):
+            if simple:
+                monkeypatch.setenv("PBRHIP_SIMPLE_TRAVERSAL", "1")
+            else:
+                monkeypatch.delenv("PBRHIP_SIMPLE_TRAVERSAL", raising=False)
+            assert_hits_equal(sg.trace_closest(rays), want_hits)
+            assert np.array_equal(sg.trace_any(rays), want_any)
+        monkeypatch.delenv("PBRHIP_SIMPLE_TRAVERSAL", raising=False)
+        for tail in (0, 0xFFFFFFFF, 2000):
+            layer = pa.RenderLayer()
+            pa.Render(sg, 96, 64, 4, layer=layer, tail_paths=tail)
+            assert np.array_equal(layer.count, cnt)
+            assert np.array_equal(layer.rgba.view(np.uint32), rgba.view(np.uint32)), (wide, tail)
+
+
 def test_gpu_bvh_builder_errors_and_tiny_scenes(pa):
     s = pa.Scene()
     with pytest.raises(pa.PbrHipError):
