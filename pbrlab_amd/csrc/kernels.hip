@@ -909,7 +909,7 @@ struct WalkSink {
 #ifndef PB_WALK_WAVES
 #define PB_WALK_WAVES 4  // waves per SIMD of k_sss_walk
 #endif
-template <bool STATS, bool CURVES>
+template <bool STATS, bool CURVES, bool WIDE = false>
 __global__ __launch_bounds__(kBlock, PB_WALK_WAVES) void k_sss_walk(PathState P, DScene sc, uint64_t rng_inc) {
   __shared__ uint32_t stk[kPvLdsStack * kBlock];
   __shared__ float frm[CURVES ? 10 * kBlock : 1];
@@ -918,7 +918,7 @@ __global__ __launch_bounds__(kBlock, PB_WALK_WAVES) void k_sss_walk(PathState P,
   TravStats st = {};
   uint32_t overflow = 0u;
   WalkSink sink = {P, rng_inc, walk + threadIdx.x, 0u};
-  trace_pv<0, STATS, CURVES, false>(sc, n, &P.counts[kCntWalkHead], sink, stk + threadIdx.x, kBlock,
+  trace_pv<0, STATS, CURVES, WIDE>(sc, n, &P.counts[kCntWalkHead], sink, stk + threadIdx.x, kBlock,
                              P.spill + blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, st, &overflow,
                              CURVES ? frm + threadIdx.x : nullptr);
   if (overflow) P.counts[kCntOverflow] = 1u;
@@ -1244,7 +1244,11 @@ void launch_sss_walk(hipStream_t s, const PathState& P, const DScene& sc, uint32
   const uint32_t blocks = (n_upper + 15u) / 16u;
   dim3 g(blocks < 1u ? 1u : (blocks < cap ? blocks : cap));
   const bool curves = sc.num_curves != 0;
-  if (stats && curves) hipLaunchKernelGGL((k_sss_walk<true, true>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
+  const char* ww = getenv("PBRHIP_WIDE_WALK");
+  const bool wide = use_wide(sc) && !(ww && atoi(ww) == 0);
+  if (wide && stats) hipLaunchKernelGGL((k_sss_walk<true, false, true>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
+  else if (wide) hipLaunchKernelGGL((k_sss_walk<false, false, true>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
+  else if (stats && curves) hipLaunchKernelGGL((k_sss_walk<true, true>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
   else if (stats) hipLaunchKernelGGL((k_sss_walk<true, false>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
   else if (curves) hipLaunchKernelGGL((k_sss_walk<false, true>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
   else hipLaunchKernelGGL((k_sss_walk<false, false>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
