@@ -41,7 +41,7 @@ WORKLOADS = {
                scene="cornell_hair", variant="sss", width=3840, height=2160, spp=1024),
 }
 
-# algorithmic bytes of the traversal kernel k_trace: 64 B per BVH node visited, 48 B per
+# algorithmic bytes of the traversal kernel k_trace: 64 B per binary / 128 B per 4-wide BVH node visited, 48 B per
 # triangle tested, 64 B per curve tested; per closest-hit ray 32 B ray + 16 B hit record + 4 B queue entry; per
 # shadow ray 32 B ray (origin shared with the continuation ray) + 4 B queue entry + 16 B pending contribution
 NODE_B, TRI_B, CURVE_B, RAY_B, SHADOW_RAY_B = 64, 48, 64, 52, 52
@@ -305,7 +305,8 @@ def main():
         _, solo = api.Render(scene, W, H, spp, tile_rank=rank, tile_world=world, device_out=ptrs,
                              flags=api.RENDER_TIMING, max_paths_in_flight=args.max_paths, num_streams=1, shard_block=shard_block)
         torch.cuda.synchronize()
-        bytes_step = (NODE_B * (sst["closest_nodes"] + sst["shadow_nodes"]) + TRI_B * (sst["closest_tris"] + sst["shadow_tris"]) +
+        node_b = int(sst.get("node_bytes") or NODE_B)  # 128 when k_trace walks the 4-wide tree (triangle-only scenes)
+        bytes_step = (node_b * (sst["closest_nodes"] + sst["shadow_nodes"]) + TRI_B * (sst["closest_tris"] + sst["shadow_tris"]) +
                       CURVE_B * (sst["closest_curves"] + sst["shadow_curves"]) + RAY_B * sst["closest_rays"] +
                       SHADOW_RAY_B * sst["shadow_rays"])
         launches = agg["n_trace_closest"] / args.steps
@@ -336,7 +337,7 @@ def main():
                         bound = "valu"
             roofline = {"bound": bound, "kernel": "k_trace (closest-hit rays of bounce k + shadow rays of bounce k-1)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                        "note": "achieved / frac = ALGORITHMIC bytes (64 B per node visit, 48 B per triangle test, 52 B per ray: SURVEY 8d) / kernel "
+                        "note": "achieved / frac = ALGORITHMIC bytes (64 B per visit of a binary node, 128 B per visit of a 4-wide node -- node_bytes --, 48 B per triangle test, 52 B per ray: SURVEY 8d) / kernel "
                                 "time (HIP events on the launch's own stream, timed region) -- NOT a ceiling: the scene is served from L2 / "
                                 "Infinity Cache, so it can exceed 1.  The ceilings are frac_hbm_counter (HBM-side bytes from the FETCH_SIZE / "
                                 "WRITE_SIZE PMC passes per launch / solo launch duration / 8 TB/s) and valu.frac (VALU issue); `bound` names "
@@ -347,7 +348,7 @@ def main():
                                  "achieved": bytes_step / (solo_ms * 1e-3) / 1e9,
                                  "frac": bytes_step / (solo_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_frame": solo["ms_total"]},
                         "traffic": traffic, "frac_hbm_counter": frac_hbm_counter, "valu": valu, "pmc_source": pmc_note,
-                        "algorithmic_bytes_per_launch": bytes_step / max(launches, 1),
+                        "algorithmic_bytes_per_launch": bytes_step / max(launches, 1), "node_bytes": node_b,
                         "avg_launch_ms": ms_step / max(launches, 1), "launches_per_step": launches,
                         "rays_per_step": sst["closest_rays"] + sst["shadow_rays"],
                         "kernel_ms_per_step": {{"trace_closest": "trace", "surface": "classify"}.get(k[3:], k[3:]): solo[k]

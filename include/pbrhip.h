@@ -108,6 +108,7 @@ typedef struct {
                            Russian roulette was already known to fail and the ray cannot reach an area light (it misses every
                            light primitive, or the bounding box of every light), so nothing it could find changes the image (closest + tail_closest + pruned = the reference's count) */
   uint64_t passes_done; /* passes every pixel of this rank holds when the call returns (= num_sample unless cancelled) */
+  uint64_t node_bytes;  /* footprint of one node of the tree k_trace walked: 128 (4-wide tree, triangle-only scenes) or 64 (binary) */
 } pbrhip_render_stats;
 
 const char* pbrhip_last_error(void);

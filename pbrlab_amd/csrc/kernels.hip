@@ -1188,6 +1188,7 @@ static inline bool use_wide(const DScene& sc) {
   const char* e = getenv("PBRHIP_WIDE");
   return sc.wide != nullptr && sc.num_curves == 0 && !(e && atoi(e) == 0);
 }
+bool trace_uses_wide(const DScene& sc) { return use_wide(sc); }
 static inline uint32_t grid_for(uint32_t n, uint32_t cap) {
   uint32_t g = (n + kBlock - 1) / kBlock;
   if (g < 1) g = 1;

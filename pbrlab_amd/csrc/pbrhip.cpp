@@ -1221,6 +1221,7 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
     publish(done);
   }
   S.passes_done = done;
+  S.node_bytes = trace_uses_wide(s->dscene) ? sizeof(Bvh4Node) : sizeof(BvhNode);
   S.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   if (stats) *stats = S;
   return PBRHIP_OK;
