@@ -1,4 +1,5 @@
 // host BVH builder under ASan/UBSan: random / degenerate inputs, structural validation of the flattened tree
+#include <algorithm>
 #include <cstdio>
 #include <random>
 #include <vector>
@@ -56,6 +57,48 @@ int main() {
       }
     }
     if (leaves_prims != n) return printf("FAIL: %zu prims in leaves, %u expected\n", leaves_prims, n), 1;
+    // the 4-wide tree collapsed from it: the same leaves once each, every box one of the binary tree's, inner references = item
+    // indices of nodes visited once, unused children NaN + kEmptyChild, the reported stack bound >= 3 per level
+    std::vector<Bvh4Node> w;
+    const uint32_t bound = collapse_bvh4(b.nodes, &w);
+    if (w.empty() || w.size() > b.nodes.size()) return printf("FAIL: wide node count\n"), 1;
+    std::vector<int> visited(w.size(), 0), leaf_seen(n, 0);
+    struct It { uint32_t id, level; };
+    std::vector<It> st2{{0u, 1u}};
+    uint32_t levels = 0;
+    size_t wide_prims = 0;
+    while (!st2.empty()) {
+      It it = st2.back(); st2.pop_back();
+      if (it.id >= w.size() || visited[it.id]++) return printf("FAIL: wide node index / revisit\n"), 1;
+      levels = std::max(levels, it.level);
+      const Bvh4Node& nd = w[it.id];
+      int used = 0;
+      for (int c = 0; c < 4; c++) {
+        if (nd.c[c] == kEmptyChild) {
+          for (int a = 0; a < 3; a++) if (nd.lo[a][c] == nd.lo[a][c] || nd.hi[a][c] == nd.hi[a][c]) return printf("FAIL: unused child without NaN box\n"), 1;
+          continue;
+        }
+        used++;
+        float bl[3] = {nd.lo[0][c], nd.lo[1][c], nd.lo[2][c]}, bh[3] = {nd.hi[0][c], nd.hi[1][c], nd.hi[2][c]};
+        if (nd.c[c] & kLeafBit) {
+          uint32_t first = (nd.c[c] & 0x3FFFFFFFu) >> 3, cnt = (nd.c[c] & 7u) + 1u;
+          if (first + cnt > n) return printf("FAIL: wide leaf range\n"), 1;
+          for (uint32_t s2 = first; s2 < first + cnt; s2++) {
+            if (leaf_seen[s2]++) return printf("FAIL: slot in two wide leaves\n"), 1;
+            uint32_t g = b.slot_gid[s2];
+            if (!inside(bl, bh, &lo[3 * g], &hi[3 * g])) return printf("FAIL: wide leaf box\n"), 1;
+          }
+          wide_prims += cnt;
+        } else {
+          if (nd.c[c] & 1u) return printf("FAIL: inner reference is not an item index\n"), 1;
+          st2.push_back({nd.c[c] / 2u, it.level + 1u});
+        }
+      }
+      if (used == 0) return printf("FAIL: wide node without children\n"), 1;
+    }
+    if (wide_prims != n) return printf("FAIL: %zu prims in wide leaves, %u expected\n", wide_prims, n), 1;
+    for (int v : visited) if (v != 1) return printf("FAIL: unreachable wide node\n"), 1;
+    if (bound != 3u * levels) return printf("FAIL: stack bound %u for %u levels\n", bound, levels), 1;
     cases++;
   }
   printf("bvh builder: %zu cases ok\n", cases);
