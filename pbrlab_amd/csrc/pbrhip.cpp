@@ -613,12 +613,16 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
     if (num_nodes) HIPCHK(hipMemcpyAsync(s->d_nodes.p, bvh.nodes.data(), (size_t)num_nodes * sizeof(BvhNode), hipMemcpyHostToDevice, st));
   }
   if (ns) HIPCHK(hipMemcpyAsync(s->d_nodes.p + num_nodes, slots.data(), (size_t)ns * 64, hipMemcpyHostToDevice, st));
-  // the 4-wide tree of k_trace (host-built trees; PBRHIP_WIDE=0: none), followed by its own copy of the slots
+  // the 4-wide tree of the traversal kernels (triangle-only scenes with a host-built tree; PBRHIP_WIDE=0 at commit: none),
+  // followed by its own copy of the slots
   std::vector<Bvh4Node> wide;
   const char* wide_env = getenv("PBRHIP_WIDE");
-  if (!gpu_built && num_nodes && !(wide_env && atoi(wide_env) == 0)) {
+  bool any_curve = false;
+  for (uint8_t kd : kinds) any_curve = any_curve || kd != 0;
+  if (!gpu_built && num_nodes && !any_curve && !(wide_env && atoi(wide_env) == 0)) {  // (scenes with curves keep the binary tree: DESIGN.md section 3)
     if (collapse_bvh4(bvh.nodes, &wide) > (uint32_t)kStackDepth) wide.clear();
   }
+  if (wide.empty()) s->d_wide.release();
   if (!wide.empty()) {
     HIPCHK(s->d_wide.reserve(((size_t)wide.size() * 2 + ns) * 4));
     HIPCHK(hipMemcpyAsync(s->d_wide.p, wide.data(), wide.size() * sizeof(Bvh4Node), hipMemcpyHostToDevice, st));
