@@ -16,7 +16,8 @@ for r in rows:
         out.append((int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e6)
 print('WIDE=$w k_trace launches (ms):', ' '.join('%.2f'%x for x in out), '| sum %.2f'%sum(out))
 for name in ('k_shade_principled','k_classify','k_compact','k_tail','k_generate'):
-    print('   ', name, '%.2f' % (sum((int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e6 for r in rows if name in r['Kernel_Name'])))
+    v=[(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e6 for r in rows if name in r['Kernel_Name']]
+    print('   ', name, '%.2f' % sum(v), '|', ' '.join('%.2f'%x for x in v))
 "
   rm -rf $d
 done

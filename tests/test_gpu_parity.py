@@ -408,7 +408,7 @@ def test_full_size_properties(pa, config):
 
 
 @pytest.mark.parametrize("config", ["c2", "c3", "c4"])
-def test_whole_frames_on_the_benchmark_scenes(pa, config):
+def test_whole_frames_on_the_benchmark_scenes(pa, config, monkeypatch):
     """The full-geometry benchmark scenes (545 k triangles; Lucy with random-walk SSS; 4.8 M hair pieces) rendered whole at a
     quarter of the resolution, 4 spp: every pixel of the GPU frame equals the oracle's, bit for bit (relative L2 = 0)."""
     from pbrlab_amd import scenes
@@ -424,6 +424,15 @@ def test_whole_frames_on_the_benchmark_scenes(pa, config):
     ndiff, rel = image_check(a.rgba, rgba)
     assert ndiff == 0 and rel == 0.0, (ndiff, rel)
     assert a.rgba[..., :3].max() > 0
+    if config != "c4":  # triangle-only scenes run on the 4-wide tree by default: the binary tree must give the same frame
+        monkeypatch.setenv("PBRHIP_WIDE", "0")
+        b = pa.RenderLayer()
+        _, st = pa.Render(sg, W, H, SPP, layer=b, flags=pa.api.RENDER_STATS)
+        assert st["node_bytes"] == 64
+        monkeypatch.delenv("PBRHIP_WIDE")
+        _, st = pa.Render(sg, W, H, SPP, layer=a, flags=pa.api.RENDER_STATS)
+        assert st["node_bytes"] == 128
+        assert np.array_equal(a.rgba.view(np.uint32), b.rgba.view(np.uint32)) and np.array_equal(a.count, b.count)
 
 
 def test_headline_configuration_spot_parity(pa):
