@@ -623,6 +623,7 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
     if (collapse_bvh4(bvh.nodes, &wide) > (uint32_t)kStackDepth) wide.clear();
   }
   if (wide.empty()) s->d_wide.release();
+  if (getenv("PBRHIP_DEBUG")) fprintf(stderr, "pbrhip: commit: %u binary nodes, %zu wide nodes, %zu slots\n", num_nodes, wide.size(), (size_t)ns);
   if (!wide.empty()) {
     HIPCHK(s->d_wide.reserve(((size_t)wide.size() * 2 + ns) * 4));
     HIPCHK(hipMemcpyAsync(s->d_wide.p, wide.data(), wide.size() * sizeof(Bvh4Node), hipMemcpyHostToDevice, st));
