@@ -1,5 +1,5 @@
 """BASELINE configs[4] (3840x2160 x 1024 spp, S-cornell SSS + S-hair) on ONE GPU: the whole frame vs rank 0's share of an
-8-rank run (tiles i % 8 == 0) -- the single-GPU proxy for strong scaling of the configuration the multi-GPU target names."""
+8-rank run (16 x 16 pixel blocks i % 8 == 0, as bench.py --gpus 8 deals them) -- the single-GPU proxy for strong scaling of the configuration the multi-GPU target names."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,10 +11,12 @@ W, H = 3840, 2160
 SPP = int(os.environ.get("SPP", "1024"))
 rgba = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda"); cnt = torch.zeros((H, W), dtype=torch.int32, device="cuda")
 torch.cuda.synchronize()
+api.Render(s, W, H, 32, tile_rank=0, tile_world=8, device_out=(rgba.data_ptr(), cnt.data_ptr()), shard_block=16)  # (working set allocated, pixel list built)
+api.Render(s, W, H, 32, device_out=(rgba.data_ptr(), cnt.data_ptr()))
 res = {}
 for world in (8, 1):
     t = time.perf_counter()
-    _, st = api.Render(s, W, H, SPP, tile_rank=0, tile_world=world, device_out=(rgba.data_ptr(), cnt.data_ptr()))
+    _, st = api.Render(s, W, H, SPP, tile_rank=0, tile_world=world, device_out=(rgba.data_ptr(), cnt.data_ptr()), shard_block=16 if world > 1 else 0)
     dt = time.perf_counter() - t
     res[world] = dt
     print(f"world {world}: {dt*1e3:.0f} ms, {st['samples']/dt/1e6:.0f} Msamples/s on this GPU, chunks {st['chunks']}, iterations {st['iterations']}", flush=True)
