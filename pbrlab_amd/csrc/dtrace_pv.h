@@ -64,6 +64,14 @@ enum : uint32_t { kStIdle = 0, kStNode = 1, kStTri = 2, kStCurve = 3, kStDone = 
 // Traversal stack: the first kPvLdsStack entries of each lane live in LDS (stk_base[i * stride]), deeper ones
 // spill to a per-thread global area (spill[(i - kPvLdsStack) * spill_stride]); keeping the LDS part small is
 // what lets 6 blocks (24 waves) share a CU.
+// a sink with `static constexpr bool kSplit = true` (and no walk) offers done_issue / done_finish / load_entry / load_ray
+template <typename Sink, typename = void>
+struct SinkSplits { static constexpr bool value = false; };
+template <typename Sink>
+struct SinkSplits<Sink, decltype((void)Sink::kSplit)> { static constexpr bool value = Sink::kSplit && !Sink::kWalk; };
+template <typename Sink>
+__device__ constexpr bool sink_splits() { return SinkSplits<Sink>::value; }
+
 // WIDE: the 4-wide tree (sc.wide: Bvh4Node, dscene.h) instead of the binary one -- half the dependent fetches per ray, twice
 // the box arithmetic per fetch; hit children are visited nearest first (sorted by entry distance), like the binary tree's.
 template <int MODE, bool STATS, bool CURVES, bool WIDE, typename Sink>
@@ -162,6 +170,32 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
         }
       }
       bool fresh = false;  // the lane has a new ray in (o, d, tmin, hit.t)
+      if constexpr (sink_splits<Sink>()) {
+        // A splitting sink hands out its loads first and uses them afterwards: what the delivery of the finished rays needs
+        // (done_issue) and the queue entries of the new rays (load_entry) are in flight together, one memory round trip
+        // instead of three before the new rays' own loads.
+        const bool finishing = state >= kStDone;
+        const uint32_t avail0 = batch_end - batch_cur;
+        const uint32_t take0 = (uint32_t)n_idle < avail0 ? (uint32_t)n_idle : avail0;
+        const uint32_t rank0 = rank_in(idle_mask);
+        const bool taking = (state == kStIdle || finishing) && rank0 < take0;
+        typename Sink::Pending pend = {};
+        if (finishing) pend = sink.done_issue(tag);
+        uint32_t entry = 0u;
+        if (taking) entry = sink.load_entry(batch_cur + rank0);
+        if (finishing) {
+          sink.done_finish(tag, pend, hit, state == kStDoneOccluded);
+          state = kStIdle;
+        }
+        if (taking) {
+          float tmax;
+          const bool a = sink.load_ray(batch_cur + rank0, entry, tag, o, d, tmin, tmax);
+          any_ray = (MODE == 1) || (MODE == 2 && a);
+          hit.t = tmax;
+          fresh = true;
+        }
+        batch_cur += take0;
+      } else {
       if (state >= kStDone) {
         if constexpr (Sink::kWalk) {
           float tmax = 0.f;
@@ -192,6 +226,8 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
           fresh = true;
         }
       }
+      batch_cur += take;
+      }
       if (fresh) {
         inv = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
         if (CURVES) {
@@ -204,7 +240,6 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
         sp = 0, steps = 0;
         advance = true, have_next = true, next = 0u;  // root is always an internal node
       }
-      batch_cur += take;
       if (STATS) {
         // (the tick count is taken after the new rays' loads have landed: the wave waits for them before it goes on)
         __builtin_amdgcn_s_waitcnt(0x0070);

@@ -64,10 +64,57 @@ __global__ __launch_bounds__(kBlock) void k_generate(PathState P, Camera cam, co
 //   shadow ray:  kShNormal   L += c_vis when unoccluded
 //                kShSssEntry A  = 0 + c_vis when unoccluded (first NEE of a path that entered the medium)
 //                kShSssExit  L += unoccluded ? c_vis : c_occ
-struct TraceSink {
+// SPLIT (dtrace_pv.h): the loads of a refill are issued together, then used.  A/B, frame ms: hair scene (C4) 236.2 -> 231.9,
+// triangle-only scenes 57.2 -> 58.5 (C2, the delivery's L load becomes unconditional), 436 -> 436 (C3): curve scenes only.
+template <bool SPLIT>
+struct TraceSinkT {
   static constexpr bool kWalk = false;
+  static constexpr bool kSplit = SPLIT;
   const PathState& P;
   uint32_t n_closest;
+  struct Pending {
+    float4 c, L;  // a shadow ray's pending contribution (+ mode) and its path's radiance
+  };
+  __device__ __forceinline__ Pending done_issue(uint32_t tag) const {
+    Pending q = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    if (tag & 0x80000000u) {
+      const uint32_t p = tag & 0x7FFFFFFFu;
+      q.c = P.sh_c[p], q.L = P.L[p];
+    }
+    return q;
+  }
+  __device__ __forceinline__ void done_finish(uint32_t tag, const Pending& q, const Hit& h, bool occluded) const {
+    const uint32_t p = tag & 0x7FFFFFFFu;
+    if (!(tag & 0x80000000u)) {
+      P.hit[p] = make_float4(h.t, h.u, h.v, __uint_as_float(h.slot));
+      return;
+    }
+    const uint32_t mode = __float_as_uint(q.c.w);
+    if (mode == kShSssEntry) {
+      if (!occluded) P.sss_A[p] = make_float4(0.0f + q.c.x, 0.0f + q.c.y, 0.0f + q.c.z, 0.0f);
+    } else if (!occluded || mode == kShSssExit) {
+      V3 add(q.c.x, q.c.y, q.c.z);
+      if (occluded) add = ld3(P.sh_e[p]);
+      P.L[p] = make_float4(q.L.x + add.x, q.L.y + add.y, q.L.z + add.z, q.L.w);
+    }
+  }
+  __device__ __forceinline__ uint32_t load_entry(uint32_t idx) const {
+    return idx < n_closest ? P.q_in[idx] : P.q_shadow_in[idx - n_closest];
+  }
+  __device__ __forceinline__ bool load_ray(uint32_t idx, uint32_t entry, uint32_t& tag, V3& o, V3& d, float& tmin, float& tmax) const {
+    if (idx < n_closest) {
+      tag = entry & kQPathMask;
+      float4 o4 = make_float4(P.cam_org[0], P.cam_org[1], P.cam_org[2], 0.0f), d4 = P.ray_d[tag];
+      if (!P.first) o4 = P.ray_o[tag];
+      o = ld3(o4), d = ld3(d4), tmin = o4.w, tmax = d4.w;
+      return false;
+    }
+    tag = entry;
+    float4 o4 = P.ray_o[tag], d4 = P.sh_d[tag];
+    o = ld3(o4), d = ld3(d4), tmin = o4.w, tmax = d4.w;
+    tag |= 0x80000000u;
+    return true;
+  }
   __device__ __forceinline__ bool load(uint32_t idx, uint32_t& tag, V3& o, V3& d, float& tmin, float& tmax) const {
     if (idx < n_closest) {
       tag = P.q_in[idx] & kQPathMask;
@@ -101,6 +148,8 @@ struct TraceSink {
   }
 };
 
+using TraceSink = TraceSinkT<false>;
+
 template <bool STATS, bool CURVES, bool WIDE = false>
 __global__ __launch_bounds__(kBlock, (WIDE ? kTraceBlocksPerCUWide : (CURVES ? kTraceBlocksPerCUCurves : kTraceBlocksPerCU))) void k_trace(PathState P, DScene sc) {
   __shared__ uint32_t stk[kPvLdsStack * kBlock];
@@ -117,7 +166,7 @@ __global__ __launch_bounds__(kBlock, (WIDE ? kTraceBlocksPerCUWide : (CURVES ? k
   const uint32_t n_closest = P.counts[kCntIn], n_shadow = P.counts[kCntShadowIn];
   TravStats st = {};
   uint32_t overflow = 0u;
-  TraceSink sink = {P, n_closest};
+  TraceSinkT<CURVES> sink = {P, n_closest};
   const unsigned long long t_start = P.wave_log ? wall_clock64() : 0ull;
   trace_pv<2, STATS, CURVES, WIDE>(sc, n_closest + n_shadow, &P.counts[kCntHead], sink, stk + threadIdx.x, kBlock,
                              P.spill + blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, st, &overflow,
