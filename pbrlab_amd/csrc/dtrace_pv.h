@@ -180,7 +180,7 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
         const uint32_t rank0 = rank_in(idle_mask);
         const bool taking = (state == kStIdle || finishing) && rank0 < take0;
         typename Sink::Pending pend = {};
-        if (finishing) pend = sink.done_issue(tag);
+        if (finishing) pend = sink.done_issue(tag, state == kStDoneOccluded);
         uint32_t entry = 0u;
         if (taking) entry = sink.load_entry(batch_cur + rank0);
         if (finishing) {

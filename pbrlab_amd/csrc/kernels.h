@@ -34,6 +34,7 @@ struct PathState {
   // ("not the first bounce", MIS weight of emission) is the same bit.
   float cam_org[3];
   uint32_t first;
+  uint32_t no_medium;  // no material of the scene can enter a medium: every shadow ray is an ordinary one (kShNormal), so an occluded one has nothing to deliver
 };
 
 enum : uint32_t { kFlagNotFirst = 1u };

@@ -75,9 +75,9 @@ struct TraceSinkT {
   struct Pending {
     float4 c, L;  // a shadow ray's pending contribution (+ mode) and its path's radiance
   };
-  __device__ __forceinline__ Pending done_issue(uint32_t tag) const {
+  __device__ __forceinline__ Pending done_issue(uint32_t tag, bool occluded) const {
     Pending q = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
-    if (tag & 0x80000000u) {
+    if ((tag & 0x80000000u) && !(occluded && P.no_medium)) {
       const uint32_t p = tag & 0x7FFFFFFFu;
       q.c = P.sh_c[p], q.L = P.L[p];
     }
@@ -89,6 +89,7 @@ struct TraceSinkT {
       P.hit[p] = make_float4(h.t, h.u, h.v, __uint_as_float(h.slot));
       return;
     }
+    if (occluded && P.no_medium) return;  // (an ordinary shadow ray that is occluded adds nothing)
     const uint32_t mode = __float_as_uint(q.c.w);
     if (mode == kShSssEntry) {
       if (!occluded) P.sss_A[p] = make_float4(0.0f + q.c.x, 0.0f + q.c.y, 0.0f + q.c.z, 0.0f);
@@ -135,6 +136,7 @@ struct TraceSinkT {
       P.hit[p] = make_float4(h.t, h.u, h.v, __uint_as_float(h.slot));
       return;
     }
+    if (occluded && P.no_medium) return;  // (an ordinary shadow ray that is occluded adds nothing: its payload is not even read)
     const float4 c = P.sh_c[p];
     const uint32_t mode = __float_as_uint(c.w);
     if (mode == kShSssEntry) {

@@ -988,6 +988,7 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
     P.sh_d = s->sh[0].p, P.sh_c = s->sh[1].p, P.sh_e = s->sh[2].p;
     P.counts = s->counts.p, P.stats = want_stats ? s->stats.p : nullptr, P.spill = s->spill.p;
     P.first = 0u, P.cam_org[0] = P.cam_org[1] = P.cam_org[2] = 0.f;
+    P.no_medium = s->has_sss ? 0u : 1u;
     P.wave_log = nullptr, P.wave_log_launch = 0;
     // debugging aid: PBRHIP_WAVE_LOG=<file> with PBRHIP_RENDER_STATS dumps start / end / turns of every wave of every
     // k_trace launch (scripts/wave_log.py reads it)
