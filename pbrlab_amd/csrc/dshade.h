@@ -86,8 +86,9 @@ __device__ __forceinline__ V3 texture_fetch3(const DScene& sc, uint32_t tex_id, 
   return V3(c[0], c[1], c[2]);
 }
 
-// std::lower_bound on a float CDF, clamped to the last entry (Q10)
-__device__ __forceinline__ uint32_t cdf_lower_bound(const float* cdf, uint32_t n, float u) {
+// std::lower_bound on a float CDF, clamped to the last entry (Q10).  (Cdf: a pointer to floats in global memory or in LDS)
+template <typename Cdf>
+__device__ __forceinline__ uint32_t cdf_lower_bound(Cdf cdf, uint32_t n, float u) {
   uint32_t lo = 0, len = n;
   while (len > 0) {
     uint32_t half = len >> 1;
@@ -108,19 +109,46 @@ struct Nee {
   V3 dir, emission;
   float dist, pdf_sigma;
 };
-__device__ __forceinline__ bool nee_sample(const DScene& sc, Rng& rng, V3 pos, V3 global_normal, bool hemisphere, Nee& n) {
-  if (sc.num_lights == 0) return false;
+// The light tables as the sampling reads them: from the scene in global memory, or from a copy in LDS (k_shade_principled stages
+// them when the scene has at most kLdsLights lights and light primitives: LDS reads stay off the vector-memory path).
+constexpr uint32_t kLdsLights = 32;
+constexpr uint32_t kLdsLightWords = kLdsLights * (1 + 2 + 1 + sizeof(LightRec) / 4);  // light cdf, heads, primitive cdf, records
+typedef const __attribute__((address_space(3))) float* LdsFloats;
+struct GlobalLightTables {
+  const DScene& sc;
+  __device__ __forceinline__ const float* cdf() const { return sc.light_cdf; }
+  __device__ __forceinline__ LightHead head(uint32_t li) const { return sc.light_heads[li]; }
+  __device__ __forceinline__ const float* prim_cdf(uint32_t first) const { return sc.lprim_cdf + first; }
+  __device__ __forceinline__ float4 rec(uint32_t idx, int k) const { return reinterpret_cast<const float4*>(sc.lrecs + idx)[k]; }
+};
+struct LdsLightTables {  // words: [0, 32) light cdf | [32, 96) heads | [96, 128) primitive cdf | [128, ...) records of 20 words
+  LdsFloats w;
+  __device__ __forceinline__ LdsFloats cdf() const { return w; }
+  __device__ __forceinline__ LightHead head(uint32_t li) const {
+    LightHead h;
+    h.first = __float_as_uint(w[kLdsLights + 2u * li]), h.count = __float_as_uint(w[kLdsLights + 2u * li + 1u]);
+    return h;
+  }
+  __device__ __forceinline__ LdsFloats prim_cdf(uint32_t first) const { return w + 3u * kLdsLights + first; }
+  __device__ __forceinline__ float4 rec(uint32_t idx, int k) const {
+    LdsFloats r = w + 4u * kLdsLights + idx * (uint32_t)(sizeof(LightRec) / 4) + 4u * (uint32_t)k;
+    return make_float4(r[0], r[1], r[2], r[3]);
+  }
+};
+template <typename Tables>
+__device__ __forceinline__ bool nee_sample_from(const Tables& lt, uint32_t num_lights, Rng& rng, V3 pos, V3 global_normal, bool hemisphere, Nee& n) {
+  if (num_lights == 0) return false;
   float u0 = draw(rng);
-  uint32_t li = cdf_lower_bound(sc.light_cdf, sc.num_lights, u0);
-  LightHead head = sc.light_heads[li];
+  uint32_t li = cdf_lower_bound(lt.cdf(), num_lights, u0);
+  LightHead head = lt.head(li);
   float u1 = draw(rng);
-  uint32_t pi = cdf_lower_bound(sc.lprim_cdf + head.first, head.count, u1);
+  uint32_t pi = cdf_lower_bound(lt.prim_cdf(head.first), head.count, u1);
   float u2 = draw(rng);
   float u3 = draw(rng);
   float bu, bv;
   triangle_uniform_sampler(u2, u3, bu, bv);
-  const float4* lr = reinterpret_cast<const float4*>(sc.lrecs + head.first + pi);
-  float4 a = lr[0], b = lr[1], c = lr[2], nn = lr[3], e = lr[4];
+  const uint32_t ri = head.first + pi;
+  float4 a = lt.rec(ri, 0), b = lt.rec(ri, 1), c = lt.rec(ri, 2), nn = lt.rec(ri, 3), e = lt.rec(ri, 4);
   V3 light_pos = lerp3(ld3(a), ld3(b), ld3(c), bu, bv);  // FetchLocalPosition, triangle-mesh.cc:102-112
   V3 light_normal = ld3(nn);
   float pdf = a.w;
@@ -131,6 +159,16 @@ __device__ __forceinline__ bool nee_sample(const DScene& sc, Rng& rng, V3 pos, V
   float wl_dot_np = dot(n.dir, global_normal);
   n.pdf_sigma = fabsf(pdf * n.dist * n.dist / (wl_dot_nl * wl_dot_np));
   return (!hemisphere) || (wl_dot_nl > 0.0f && wl_dot_np > 0.0f);
+}
+// lds_lights: the light tables staged in LDS (LdsLightTables layout), or null
+__device__ __forceinline__ bool nee_sample(const DScene& sc, Rng& rng, V3 pos, V3 global_normal, bool hemisphere, Nee& n,
+                                           const float* lds_lights = nullptr) {
+  if (lds_lights) {
+    const LdsLightTables lt = {(LdsFloats)lds_lights};
+    return nee_sample_from(lt, sc.num_lights, rng, pos, global_normal, hemisphere, n);
+  }
+  const GlobalLightTables lt = {sc};
+  return nee_sample_from(lt, sc.num_lights, rng, pos, global_normal, hemisphere, n);
 }
 // shader-utils.h:195-208
 __device__ __forceinline__ V3 nee_contribution(const Nee& n, V3 bsdf_f, float bsdf_pdf) {

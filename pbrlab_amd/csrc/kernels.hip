@@ -476,13 +476,31 @@ __device__ __forceinline__ void put_shadow(const PathState& P, V3 pos, const Nee
   if (mode == kShSssExit) P.sh_e[p] = mk4(c_occ, 0.f);  // what to add when the ray is occluded (only a medium exit has one)
 }
 
+// Block-cooperative copy of the light tables into LDS (LdsLightTables layout, dshade.h) when they are small enough; the
+// caller synchronises.  The shading kernels sample a light per hit: five 16-byte reads of a record, two searches in
+// cumulative tables -- from LDS they do not queue behind the path-state traffic of the vector-memory path.
+__device__ __forceinline__ bool stage_light_tables(const DScene& sc, float* lds) {
+  if (!(sc.num_lights > 0 && sc.num_lights <= kLdsLights && sc.num_lrecs <= kLdsLights)) return false;
+  constexpr uint32_t kRecWords = sizeof(LightRec) / 4;
+  for (uint32_t i = threadIdx.x; i < sc.num_lights; i += kBlock) {
+    lds[i] = sc.light_cdf[i];
+    lds[kLdsLights + 2u * i] = __uint_as_float(sc.light_heads[i].first);
+    lds[kLdsLights + 2u * i + 1u] = __uint_as_float(sc.light_heads[i].count);
+  }
+  for (uint32_t i = threadIdx.x; i < sc.num_lrecs; i += kBlock) lds[3u * kLdsLights + i] = sc.lprim_cdf[i];
+  for (uint32_t i = threadIdx.x; i < sc.num_lrecs * kRecWords; i += kBlock) lds[4u * kLdsLights + i] = reinterpret_cast<const float*>(sc.lrecs)[i];
+  return true;
+}
+
 // ------------------------------------------------------------------ k_shade_principled
 // CyclesPrincipledShader (cycles-principled-shader.cc:414-484) + the tail of GetRadiance (render.cc:76-87).
 // One path; returns the result bits (kRShadow | kRAlive | kQSssBit | kQDoomed) its caller stores or acts on.
 // PLAIN: the scene has no material that can enter a medium and no textured material (neither branch can be taken), so that
 // code -- and the registers it holds -- is compiled out of the wavefront kernel.
+// lds_bsdf: the scene's closure sets staged in LDS by the caller (k_shade_principled<PLAIN> when they fit), or null
 template <bool PLAIN = false>
-__device__ __forceinline__ uint32_t shade_principled_path(const PathState& P, const DScene& sc, uint32_t p, uint64_t rng_inc, bool first) {
+__device__ __forceinline__ uint32_t shade_principled_path(const PathState& P, const DScene& sc, uint32_t p, uint64_t rng_inc, bool first,
+                                                          const PrincipledBsdf* lds_bsdf = nullptr, const float* lds_lights = nullptr) {
   {
     const bool active = true;
     bool alive = false, shadow = false;
@@ -504,7 +522,17 @@ __device__ __forceinline__ uint32_t shade_principled_path(const PathState& P, co
         fr.ez = (s.face == kFront) ? s.n_s : -s.n_s;
         branchless_onb(fr.ez, fr.ex, fr.ey);
         V3 wo = to_local(fr, wo_g);
-        PrincipledBsdf b = sc.materials[s.material].bsdf;
+        PrincipledBsdf b;
+        if (lds_bsdf) {  // (LDS reads: off the vector-memory path the kernel is bound by)
+          constexpr uint32_t kWords = sizeof(PrincipledBsdf) / 4;
+          const auto* lw = (const __attribute__((address_space(3))) uint32_t*)reinterpret_cast<const uint32_t*>(lds_bsdf) + s.material * kWords;
+          uint32_t w[kWords];
+#pragma unroll
+          for (uint32_t k = 0; k < kWords; k++) w[k] = lw[k];
+          __builtin_memcpy(&b, w, sizeof(b));
+        } else {
+          b = sc.materials[s.material].bsdf;
+        }
         if (!PLAIN && sc.materials[s.material].textured) {  // ParamToBsdf per hit (cycles-principled-shader.cc:281-301)
           const PrincipledParam mp = sc.materials[s.material].param;
           V3 bc(mp.base_color[0], mp.base_color[1], mp.base_color[2]);
@@ -516,7 +544,7 @@ __device__ __forceinline__ uint32_t shade_principled_path(const PathState& P, co
         SampleWeight w = closure_sample_weight(wo, b);
         // DirectIllumination (shader-utils.h:166-212)
         V3 d1(0.f);
-        shadow = nee_sample(sc, rng, s.pos, fr.ez, true, nee);
+        shadow = nee_sample(sc, rng, s.pos, fr.ez, true, nee, lds_lights);
         if (shadow) {
           V3 f;
           float pdf;
@@ -624,17 +652,35 @@ __device__ __forceinline__ uint32_t shade_principled_path(const PathState& P, co
 #ifndef PB_SHADE_WAVES
 #define PB_SHADE_WAVES 3  // min waves per SIMD: <= 168 VGPRs (A/B on C2: 1 -> 20.5 ms, 2 -> 20.3, 3 -> 19.3, 4 spills -> 25.5)
 #endif
+#ifndef PB_LDS_MATS
+#define PB_LDS_MATS 64
+#endif
+constexpr uint32_t kLdsMats = PB_LDS_MATS;  // closure sets staged in LDS by the plain shading kernel (96 B each)
 template <bool PLAIN>
 __global__ __launch_bounds__(kBlock, PB_SHADE_WAVES) void k_shade_principled(PathState P, DScene sc, uint64_t rng_inc) {
+  __shared__ PrincipledBsdf lds_bsdf[kLdsMats ? kLdsMats : 1];
+  __shared__ float lds_lights[kLdsMats ? kLdsLightWords : 1];
+  const bool lights_staged = kLdsMats && stage_light_tables(sc, lds_lights);
+  const bool staged = kLdsMats && sc.num_materials <= kLdsMats;
+  if (staged) {
+    constexpr uint32_t kWords = sizeof(PrincipledBsdf) / 4;
+    static_assert(sizeof(PrincipledBsdf) % 4 == 0, "closure set is a whole number of words");
+    uint32_t* dst = reinterpret_cast<uint32_t*>(lds_bsdf);
+    for (uint32_t i = threadIdx.x; i < sc.num_materials * kWords; i += kBlock)
+      dst[i] = reinterpret_cast<const uint32_t*>(&sc.materials[i / kWords].bsdf)[i % kWords];
+  }
+  if (staged || lights_staged) __syncthreads();
   const uint32_t n = P.counts[kCntPrincipled];
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
     const uint32_t p = P.q_principled[i];
-    P.q_principled[i] = p | shade_principled_path<PLAIN>(P, sc, p, rng_inc, P.first != 0u);
+    P.q_principled[i] = p | shade_principled_path<PLAIN>(P, sc, p, rng_inc, P.first != 0u, staged ? lds_bsdf : nullptr,
+                                                         lights_staged ? lds_lights : nullptr);
   }
 }
 
 // ------------------------------------------------------------------ k_shade_hair (hair-shader.cc:153-229)
-__device__ __forceinline__ uint32_t shade_hair_path(const PathState& P, const DScene& sc, uint32_t p, uint64_t rng_inc, bool first) {
+__device__ __forceinline__ uint32_t shade_hair_path(const PathState& P, const DScene& sc, uint32_t p, uint64_t rng_inc, bool first,
+                                                    const float* lds_lights = nullptr) {
   {
     const bool active = true;
     bool alive = false, shadow = false;
@@ -660,7 +706,7 @@ __device__ __forceinline__ uint32_t shade_hair_path(const PathState& P, const DS
         HairSetup S;
         hair_prepare(wo, hb, S);
         V3 d1(0.f);
-        shadow = nee_sample(sc, rng, s.pos, fr.ex, false, nee);
+        shadow = nee_sample(sc, rng, s.pos, fr.ex, false, nee, lds_lights);
         if (shadow) {
           V3 wl = to_local(fr, nee.dir);
           float pdf;
@@ -701,10 +747,13 @@ __device__ __forceinline__ uint32_t shade_hair_path(const PathState& P, const DS
   }
 }
 __global__ __launch_bounds__(kBlock) void k_shade_hair(PathState P, DScene sc, uint64_t rng_inc) {
+  __shared__ float lds_lights[kLdsLightWords];
+  const bool lights_staged = stage_light_tables(sc, lds_lights);
+  if (lights_staged) __syncthreads();
   const uint32_t n = P.counts[kCntHair];
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
     const uint32_t p = P.q_hair[i];
-    P.q_hair[i] = p | shade_hair_path(P, sc, p, rng_inc, P.first != 0u);
+    P.q_hair[i] = p | shade_hair_path(P, sc, p, rng_inc, P.first != 0u, lights_staged ? lds_lights : nullptr);
   }
 }
 
@@ -752,7 +801,7 @@ __device__ __forceinline__ bool sss_scatter(WalkState& w, uint64_t rng_inc) {
 
 // hreg: the hit of the path's bounded ray when the caller holds it in registers, else it is read from P.hit.
 __device__ __forceinline__ uint32_t sss_step_path(const PathState& P, const DScene& sc, uint32_t p, uint64_t rng_inc,
-                                                  const Hit* hreg = nullptr) {
+                                                  const Hit* hreg = nullptr, const float* lds_lights = nullptr) {
   {
     const bool active = true;
     bool alive = false, shadow = false;
@@ -813,7 +862,7 @@ __device__ __forceinline__ uint32_t sss_step_path(const PathState& P, const DSce
           nb.diffuse_weight = wthr;
           SampleWeight w = closure_sample_weight(wo, nb);
           V3 d2(0.f);
-          shadow = nee_sample(sc, rng, s.pos, s.n_s, true, nee);  // :202-212 (Q5)
+          shadow = nee_sample(sc, rng, s.pos, s.n_s, true, nee, lds_lights);  // :202-212 (Q5)
           if (shadow) {
             V3 f;
             float pdf;
@@ -879,10 +928,13 @@ __device__ __forceinline__ uint32_t sss_step_path(const PathState& P, const DSce
   }
 }
 __global__ __launch_bounds__(kBlock) void k_sss_step(PathState P, DScene sc, uint64_t rng_inc) {
+  __shared__ float lds_lights[kLdsLightWords];
+  const bool lights_staged = stage_light_tables(sc, lds_lights);
+  if (lights_staged) __syncthreads();
   const uint32_t n = P.counts[kCntSss];
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
     const uint32_t p = P.q_sss[i];
-    P.q_sss[i] = p | sss_step_path(P, sc, p, rng_inc);
+    P.q_sss[i] = p | sss_step_path(P, sc, p, rng_inc, nullptr, lights_staged ? lds_lights : nullptr);
   }
 }
 
