@@ -170,6 +170,7 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
         }
       }
       bool fresh = false;  // the lane has a new ray in (o, d, tmin, hit.t)
+      uint32_t taken = 0u;  // queue entries handed out in this refill
       if constexpr (sink_splits<Sink>()) {
         // A splitting sink hands out its loads first and uses them afterwards: what the delivery of the finished rays needs
         // (done_issue) and the queue entries of the new rays (load_entry) are in flight together, one memory round trip
@@ -194,7 +195,7 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
           hit.t = tmax;
           fresh = true;
         }
-        batch_cur += take0;
+        taken = take0;
       } else {
       if (state >= kStDone) {
         if constexpr (Sink::kWalk) {
@@ -226,7 +227,7 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
           fresh = true;
         }
       }
-      batch_cur += take;
+      taken = take;
       }
       if (fresh) {
         inv = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
@@ -240,6 +241,7 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
         sp = 0, steps = 0;
         advance = true, have_next = true, next = 0u;  // root is always an internal node
       }
+      batch_cur += taken;
       if (STATS) {
         // (the tick count is taken after the new rays' loads have landed: the wave waits for them before it goes on)
         __builtin_amdgcn_s_waitcnt(0x0070);
