@@ -1,0 +1,64 @@
+"""Register / scratch budgets of the hot kernels, read from the gfx950 code object inside the built libpbrhip.so (no GPU needed).
+
+The traversal kernels live on exact budgets: `k_trace` must fit its waves-per-SIMD target without a byte of scratch (with any
+scratch in the loop it is ~30 % slower), and `k_sss_walk`'s scratch belongs to its scattering step, not to the traversal loop --
+28 bytes more of it, caused by moving one statement in dtrace_pv.h, cost C3 20 % (profiles/README.md).  These limits are the
+measured-good values; a change that exceeds one has to be re-measured on the GPU before the limit moves."""
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+# kernel (demangled prefix) -> (max VGPRs, max scratch bytes)
+BUDGETS = {
+    "k_trace<false, false, false>": (72, 0),    # binary tree, triangles: 7 waves per SIMD
+    "k_trace<false, true, false>": (80, 0),     # binary tree, curves: 6 waves
+    "k_trace<false, false, true>": (96, 0),     # 4-wide tree: 5 waves
+    "k_sss_walk<false, false, true>": (128, 72),
+    "k_sss_walk<false, false, false>": (128, 28),
+    "k_sss_walk<false, true, false>": (128, 36),
+    "k_shade_principled<true>": (168, 0),
+    "k_classify": (64, 0),
+    "k_compact": (96, 0),
+}
+
+
+def kernel_table():
+    lib = os.path.join(ROOT, "pbrlab_amd", "libpbrhip.so")
+    if not (os.path.exists(lib) and os.path.exists(os.path.join(LLVM, "clang-offload-bundler")) and shutil.which("c++filt")):
+        pytest.skip("built library or LLVM tools not available")
+    tmp = tempfile.mkdtemp()
+    try:
+        fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "dev.co")
+        subprocess.run([os.path.join(LLVM, "llvm-objcopy"), f"--dump-section=.hip_fatbin={fat}", lib], check=True, capture_output=True)
+        subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={fat}",
+                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True, capture_output=True)
+        notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], check=True, capture_output=True, text=True).stdout
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    table, cur = {}, {}
+    for line in notes.splitlines():
+        m = re.match(r"\s+\.(name|vgpr_count|private_segment_fixed_size):\s+(\S+)", line)
+        if not m:
+            continue
+        if m.group(1) == "name":
+            cur = table.setdefault(m.group(2), {})
+        else:
+            cur[m.group(1)] = int(m.group(2))
+    demangled = subprocess.run(["c++filt"] + list(table), check=True, capture_output=True, text=True).stdout.split("\n")
+    return {d.replace("void pb::", "").replace("pb::", "").split("(")[0]: v for d, v in zip(demangled, table.values())}
+
+
+def test_hot_kernels_stay_within_their_budgets():
+    table = kernel_table()
+    for name, (vgprs, scratch) in BUDGETS.items():
+        assert name in table, (name, sorted(table)[:8])
+        got = table[name]
+        assert got["vgpr_count"] <= vgprs, (name, got)
+        assert got["private_segment_fixed_size"] <= scratch, (name, got)
