@@ -1010,7 +1010,7 @@ struct WalkSink {
   __device__ __forceinline__ void done(uint32_t, const Hit&, bool) const {}
 };
 #ifndef PB_WALK_WAVES
-#define PB_WALK_WAVES 4  // waves per SIMD of k_sss_walk
+#define PB_WALK_WAVES 3  // waves per SIMD of k_sss_walk: <= 168 VGPRs, nothing spilled (4 waves = 128 VGPRs + 72 B of scratch on the 4-wide tree: C3 353 -> 347 ms at 3)
 #endif
 template <bool STATS, bool CURVES, bool WIDE = false>
 __global__ __launch_bounds__(kBlock, PB_WALK_WAVES) void k_sss_walk(PathState P, DScene sc, uint64_t rng_inc) {
