@@ -129,7 +129,7 @@ __device__ __forceinline__ void box_test2(const float4& n0, const float4& n1, co
 // The same slab test on the four boxes of a wide node (Bvh4Node): lx .. hz hold one bound of the four children each.
 // ta / tb: entry / exit distance of each box (widened like box_test2's); the caller compares them with the ray's interval.
 __device__ __forceinline__ void box_test4(const float4& lx, const float4& ly, const float4& lz, const float4& hx, const float4& hy,
-                                          const float4& hz, V3 o, V3 inv, float ta[4], float tb[4]) {
+                                          const float4& hz, V3 o, const float4& inv, float ta[4], float tb[4]) {
   const float e = 1.52587890625e-05f;
 #pragma unroll
   for (int h = 0; h < 2; h++) {
@@ -153,7 +153,7 @@ __device__ __forceinline__ void box_test4(const float4& lx, const float4& ly, co
 // child's entry distance (>= 0 as an integer; its two low bits hold the child index, wide_ref), 0xFFFFFFFF = not hit.
 constexpr uint32_t kWideMiss = 0xFFFFFFFFu;
 __device__ __forceinline__ void wide_node_keys(const float4& lx, const float4& ly, const float4& lz, const float4& hx, const float4& hy,
-                                               const float4& hz, V3 o, V3 inv, float tmin, float tmax, uint32_t k[4]) {
+                                               const float4& hz, V3 o, const float4& inv, float tmin, float tmax, uint32_t k[4]) {
   float ta[4], tb[4];
   box_test4(lx, ly, lz, hx, hy, hz, o, inv, ta, tb);
 #pragma unroll
@@ -224,7 +224,7 @@ __device__ __forceinline__ bool traverse_mode(const DScene& sc, V3 o, V3 d, floa
       const float4 lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5], refs = np[6];
       if (STATS) st.nodes++;
       uint32_t k[4];
-      wide_node_keys(lx, ly, lz, hx, hy, hz, o, inv, tmin, best_t, k);
+      wide_node_keys(lx, ly, lz, hx, hy, hz, o, make_float4(inv.x, inv.y, inv.z, 0.f), tmin, best_t, k);
 #pragma unroll
       for (int j = 3; j >= 1; j--) {
         if (k[j] == kWideMiss) continue;

@@ -127,6 +127,7 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
   // per-lane state
   uint32_t state = kStIdle, tag = 0;
   V3 o(0.f), d(0.f), inv(0.f);
+  float4 inv4 = make_float4(0.f, 0.f, 0.f, 0.f);  // WIDE: the same 1 / d as one aligned register quadruple (box_test4's packed operands)
   float tmin = 0.f;  // (the current tmax of the ray is hit.t)
   Hit hit = {0.f, 0.f, 0.f, kNone};
   int sp = 0;
@@ -231,6 +232,7 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
       }
       if (fresh) {
         inv = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        if (WIDE) inv4 = make_float4(inv.x, inv.y, inv.z, 0.f);
         if (CURVES) {
           const RayFrame f = ray_frame(d);
           const float w[10] = {f.dn.x, f.dn.y, f.dn.z, f.bx.x, f.bx.y, f.bx.z, f.by.x, f.by.y, f.by.z, f.inv_len};
@@ -266,7 +268,7 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
         if (WIDE && state == kStNode) {
           if (STATS) (any_ray ? st.anodes : st.nodes)++, steps++;
           uint32_t k[4];
-          wide_node_keys(D0, D1, D2, D4, D5, D6, o, inv, tmin, hit.t, k);
+          wide_node_keys(D0, D1, D2, D4, D5, D6, o, inv4, tmin, hit.t, k);
           auto ref_of = [&](uint32_t key) { return wide_ref(D7, key); };
           advance = true;
           have_next = k[0] != kWideMiss;
