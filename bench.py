@@ -241,7 +241,16 @@ def main():
         if int(flag.item()):
             uid = [my_id if rank == 0 else None]
             dist.broadcast_object_list(uid, src=0)
-            comm = pa.Comm(uid[0], rank, world)      # ncclCommInitRank: collective
+            try:
+                comm = pa.Comm(uid[0], rank, world)  # ncclCommInitRank: collective
+                ok = 1
+            except Exception as e:                   # (an error every rank sees, e.g. an RCCL version mismatch: fall back together)
+                print(f"bench: library communicator failed on rank {rank} ({e})", file=sys.stderr)
+                comm, ok = None, 0
+            flag = torch.tensor([ok], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if not int(flag.item()):
+                comm, exchange = None, "torch"
         else:
             exchange = "torch"                       # reported in config.exchange
 
