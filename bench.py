@@ -250,6 +250,8 @@ def main():
             flag = torch.tensor([ok], device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if not int(flag.item()):
+                if comm is not None:
+                    comm.close()                     # (created here, failed elsewhere: release the communicator and its stream)
                 comm, exchange = None, "torch"
         else:
             exchange = "torch"                       # reported in config.exchange

@@ -80,8 +80,10 @@ typedef struct {
   uint32_t tile_rank, tile_world;     /* 64x64 tiles (render.cc:107-108) with index % world == rank */
   uint32_t max_paths_in_flight;       /* 0 = default (half of the free HBM, <= 256 Mi): passes are rendered in chunks of this many paths */
   uint32_t flags;                     /* PBRHIP_RENDER_* */
-  uint32_t num_streams;               /* 0 = default: the passes of a chunk are split into path groups of geometrically shrinking size that run as a
-                                         pipeline (one HIP stream each; pbrhip.cpp::plan_groups); n > 0: n equal groups, all started at once (max 16) */
+  uint32_t num_streams;               /* the passes of a chunk are split into path groups, one HIP stream each (pbrhip.cpp::plan_groups).
+                                         0 = default: two equal groups started at once when the chunk holds at least 96 Mi paths,
+                                         otherwise one (pipelined plans were measured and lost); n > 0: n equal groups (at most 16),
+                                         of which at most 8 are in flight at a time */
   uint32_t tail_paths;                /* once a group has at most this many live paths, the rest of every path runs in ONE launch
                                          (k_tail) instead of one set of launches per bounce; 0 = default 262144, 0xFFFFFFFF = never */
   uint32_t shard_block;               /* edge of the square pixel blocks dealt to ranks (block index % tile_world == tile_rank);
@@ -210,8 +212,10 @@ int pbrhip_render_device(pbrhip_scene*, const pbrhip_render_desc*, const volatil
 /* (1) one process, several GPUs: scenes[i] is a committed copy of the same scene on its own device (pbrhip_scene_replicate;
  * several scenes may share a device).  One host thread per scene renders rank desc->tile_rank * n + i of
  * desc->tile_world * n; the shards are then copied device-to-device (xGMI peer copies: only the blocks a rank rendered
- * travel) into scenes[0]'s layer and from there to the host.  cancel / finish_pass as in pbrhip_render (*finish_pass = the
- * passes complete on EVERY device); stats: NULL or n records. */
+ * travel) into scenes[0]'s layer and from there to the host.  cancel / finish_pass as in pbrhip_render, except that the
+ * devices of a cancelled call stop at their own pass counts: *finish_pass = the passes complete on EVERY device (the
+ * minimum), a device that was ahead keeps its further passes in its pixels, and `count` says per pixel how many it holds;
+ * stats: NULL or n records. */
 int pbrhip_render_multi(pbrhip_scene* const* scenes, uint32_t n, const pbrhip_render_desc*,
                         const volatile unsigned char* cancel, float* rgba, uint32_t* count, size_t* finish_pass,
                         pbrhip_render_stats* stats);

@@ -206,6 +206,7 @@ inline bool Render(const Scene& scene, const uint32_t width, const uint32_t heig
   std::atomic_size_t local_fin(0);
   std::atomic_size_t* fin = finish_pass ? finish_pass : &local_fin;
   int rc;
+  fin->store(0);  // render.cc:209: zero before any worker starts (a counter reused from the previous frame must not be reported)
   {
     detail::ProgressPrinter progress(fin);
     rc = pbrhip_render(scene.handle(), &d, reinterpret_cast<const volatile unsigned char*>(&cancel_render_flag),
@@ -234,6 +235,7 @@ inline bool Render(const std::vector<const Scene*>& scenes, const uint32_t width
   std::atomic_size_t local_fin(0);
   std::atomic_size_t* fin = finish_pass ? finish_pass : &local_fin;
   int rc;
+  fin->store(0);  // render.cc:209: zero before any worker starts (a counter reused from the previous frame must not be reported)
   {
     detail::ProgressPrinter progress(fin);
     rc = pbrhip_render_multi(hs.data(), uint32_t(hs.size()), &d,

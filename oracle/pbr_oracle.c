@@ -509,7 +509,25 @@ static void flatten_prims(orc_scene* s) {
   }
 }
 
-static void prim_bounds(const orc_scene* s, uint32_t gid, float lo[3], float hi[3]) {
+static inline void bezier_eval(const float* cp, float u, float out[4]);
+
+/* Box of one contract primitive: a triangle's corners; a linear piece of a ribbon = its two end points B(i/4), B((i+1)/4)
+ * widened by the larger end radius.  This box is part of the intersection contract (hit_inside below). */
+static inline void tri_box(const float* geo, float lo[3], float hi[3]) {
+  for (int a = 0; a < 3; a++) {
+    lo[a] = fminf(fminf(geo[a], geo[3 + a]), geo[6 + a]);
+    hi[a] = fmaxf(fmaxf(geo[a], geo[3 + a]), geo[6 + a]);
+  }
+}
+static inline void piece_box(const float a[4], const float b[4], float lo[3], float hi[3]) {
+  float r = fmaxf(fabsf(a[3]), fabsf(b[3]));
+  for (int k = 0; k < 3; k++) lo[k] = fminf(a[k], b[k]) - r, hi[k] = fmaxf(a[k], b[k]) + r;
+}
+
+/* hull != 0: the bounds Embree reports for the scene (rtcGetSceneBounds; they place the camera): for a curve the convex
+ * hull of the control points widened by the largest control radius.  hull == 0: the box the tree is built over: the
+ * union of the boxes of the curve's four contract primitives. */
+static void prim_bounds(const orc_scene* s, uint32_t gid, int hull, float lo[3], float hi[3]) {
   const float* geo = s->prim_geo + (size_t)gid * ORC_GEO_STRIDE;
   for (int a = 0; a < 3; a++) lo[a] = INFINITY, hi[a] = -INFINITY;
   if (s->prims[gid].kind == 0) {
@@ -519,8 +537,7 @@ static void prim_bounds(const orc_scene* s, uint32_t gid, float lo[3], float hi[
         if (v < lo[a]) lo[a] = v;
         if (v > hi[a]) hi[a] = v;
       }
-  } else {
-    /* convex hull of the control points, widened by the largest control radius */
+  } else if (hull) {
     float r = 0.0f;
     for (int c = 0; c < 4; c++) {
       float rc = fabsf(geo[c * 4 + 3]);
@@ -532,6 +549,63 @@ static void prim_bounds(const orc_scene* s, uint32_t gid, float lo[3], float hi[
       }
     }
     for (int a = 0; a < 3; a++) lo[a] -= r, hi[a] += r;
+  } else {
+    float p[5][4];
+    for (int i = 0; i < 5; i++) bezier_eval(geo, (float)i * 0.25f, p[i]);
+    for (int i = 0; i < 4; i++) {
+      float l[3], h[3];
+      piece_box(p[i], p[i + 1], l, h);
+      for (int a = 0; a < 3; a++) {
+        if (l[a] < lo[a]) lo[a] = l[a];
+        if (h[a] > hi[a]) hi[a] = h[a];
+      }
+    }
+  }
+}
+
+/* rtcGetSceneBounds (raytracer_impl.cc:199-202) of the global scene: the union over the instances of the instance's
+ * bounds.  An instance (RTC_GEOMETRY_TYPE_INSTANCE, raytracer_impl.cc:61-81) reports the box of the transformed CORNERS of
+ * its local scene's box, which under rotation or shear is larger than the box of the transformed geometry; an instance
+ * whose matrix is bit for bit the identity reports the local box itself.  The local box: triangles by their corners,
+ * curves by the hull of their control points widened by the largest control radius. */
+static void scene_bounds(orc_scene* s) {
+  for (int a = 0; a < 3; a++) s->bmin[a] = INFINITY, s->bmax[a] = -INFINITY;
+  for (uint32_t i = 0; i < s->ninstances; i++) {
+    const orc_instance* in = &s->instances[i];
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    int any = 0;
+    for (uint32_t g = 0; g < in->ngeom; g++) {
+      const orc_mesh* m = inst_mesh(s, i, g);
+      uint32_t np = mesh_num_prims(m);
+      for (uint32_t p = 0; p < np; p++) {
+        any = 1;
+        if (m->kind == 0) {
+          for (int c = 0; c < 3; c++) {
+            f3 v = mesh_vertex(m, p, c);
+            const float w[3] = {v.x, v.y, v.z};
+            for (int a = 0; a < 3; a++) lo[a] = fminf(lo[a], w[a]), hi[a] = fmaxf(hi[a], w[a]);
+          }
+        } else {
+          float r = 0.0f, cl[3] = {INFINITY, INFINITY, INFINITY}, ch[3] = {-INFINITY, -INFINITY, -INFINITY};
+          for (int c = 0; c < 4; c++) {
+            const float* cp = m->cverts + ((size_t)m->cidx[p] + c) * 4;
+            r = fmaxf(r, fabsf(cp[3]));
+            for (int a = 0; a < 3; a++) cl[a] = fminf(cl[a], cp[a]), ch[a] = fmaxf(ch[a], cp[a]);
+          }
+          for (int a = 0; a < 3; a++) lo[a] = fminf(lo[a], cl[a] - r), hi[a] = fmaxf(hi[a], ch[a] + r);
+        }
+      }
+    }
+    if (!any) continue;
+    if (in->identity) {
+      for (int a = 0; a < 3; a++) s->bmin[a] = fminf(s->bmin[a], lo[a]), s->bmax[a] = fmaxf(s->bmax[a], hi[a]);
+    } else {
+      for (int c = 0; c < 8; c++) {
+        f3 v = xf_point(in->xf, f3_make((c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1], (c & 4) ? hi[2] : lo[2]));
+        const float w[3] = {v.x, v.y, v.z};
+        for (int a = 0; a < 3; a++) s->bmin[a] = fminf(s->bmin[a], w[a]), s->bmax[a] = fmaxf(s->bmax[a], w[a]);
+      }
+    }
   }
 }
 
@@ -686,16 +760,12 @@ static void build_bvh(orc_scene* s) {
   b.phi = (float*)xrealloc(NULL, sizeof(float) * 3 * (size_t)n);
   b.pc = (float*)xrealloc(NULL, sizeof(float) * 3 * (size_t)n);
   s->order = (uint32_t*)xrealloc(s->order, sizeof(uint32_t) * (size_t)n);
-  for (int a = 0; a < 3; a++) s->bmin[a] = INFINITY, s->bmax[a] = -INFINITY;
   for (uint32_t g = 0; g < n; g++) {
-    prim_bounds(s, g, b.plo + g * 3, b.phi + g * 3);
-    for (int a = 0; a < 3; a++) {
-      b.pc[g * 3 + a] = 0.5f * (b.plo[g * 3 + a] + b.phi[g * 3 + a]);
-      if (b.plo[g * 3 + a] < s->bmin[a]) s->bmin[a] = b.plo[g * 3 + a];
-      if (b.phi[g * 3 + a] > s->bmax[a]) s->bmax[a] = b.phi[g * 3 + a];
-    }
+    prim_bounds(s, g, 0, b.plo + g * 3, b.phi + g * 3);
+    for (int a = 0; a < 3; a++) b.pc[g * 3 + a] = 0.5f * (b.plo[g * 3 + a] + b.phi[g * 3 + a]);
     s->order[g] = g;
   }
+  scene_bounds(s);
   s->nnodes = 0;
   b.node_cap = 0;
   if (n > 0) build_node(&b, 0, n, 1);
@@ -720,18 +790,61 @@ uint32_t orc_bvh_depth(const orc_scene* s) { return s->bvh_depth; }
 
 /* ---------------------------------------------------------------- intersection kernels
  * Conventions (DESIGN.md "intersection contract"; Embree's are not reproducible here, F5):
- *  - a primitive hit is accepted for  tmin < t <= tmax ;
- *  - closest hit = smallest t, ties broken towards the smaller canonical primitive id
- *    (instance, geom, prim order), so the result does not depend on BVH shape or visit order;
- *  - any-hit = "some primitive has an accepted hit".
+ *  - a primitive hit is accepted for  tmin < t <= tmax  if, in addition, t lies inside the interval in which the ray
+ *    crosses the primitive's OWN box (hit_inside): a numerically degenerate sliver can pass the triangle test with a
+ *    meaningless distance far from the sliver; without this rule whether such a hit is ever seen depends on the order
+ *    in which subtrees are visited (a nearer true hit culls the sliver's box), with it the accepted set is a property of
+ *    (ray, primitive) alone;
+ *  - closest hit = smallest accepted t, ties broken towards the smaller canonical primitive id
+ *    (instance, geom, prim order), so the result does not depend on BVH shape or visit order: rtcIntersect1's
+ *    "closest accepted hit" (raytracer_impl.cc:268-278);
+ *  - any-hit = "some primitive has an accepted hit" (rtcOccluded1, raytracer_impl.cc:280-287).
+ * Why the rule makes every tree agree with the brute-force loop: every box above a primitive contains that primitive's
+ * box; the slab arithmetic below is monotone in the box (rounded subtraction, multiplication, min, max all are), the
+ * validation box is strictly inside the stored one and both widen the interval with the same function -- so whenever
+ * tmin < t <= tmax holds for a validated hit, the conservative test of every ancestor passes for [tmin, tmax].
  */
+/* conservative slab test: the box is widened by 2^-16 relative in space (a ray parallel to an axis with its origin exactly
+ * on a face of the tight box would give 0 * inf = NaN and be rejected) and the interval by 2^-16 relative before comparing */
+static inline float box_lo(float v) { return v - (fabsf(v) * 1.52587890625e-05f + 1e-30f); }
+static inline float box_hi(float v) { return v + (fabsf(v) * 1.52587890625e-05f + 1e-30f); }
+/* the interval in which the ray is inside the box lo..hi (faces as given), widened by 2^-16 relative */
+static inline void slab_interval(const float lo[3], const float hi[3], f3 o, f3 inv, float* ta, float* tb) {
+  float t0 = (lo[0] - o.x) * inv.x, t1 = (hi[0] - o.x) * inv.x;
+  float a = fminf(t0, t1), b = fmaxf(t0, t1);
+  t0 = (lo[1] - o.y) * inv.y, t1 = (hi[1] - o.y) * inv.y;
+  a = fmaxf(a, fminf(t0, t1)), b = fminf(b, fmaxf(t0, t1));
+  t0 = (lo[2] - o.z) * inv.z, t1 = (hi[2] - o.z) * inv.z;
+  a = fmaxf(a, fminf(t0, t1)), b = fminf(b, fmaxf(t0, t1));
+  *ta = fmaf(-fabsf(a), 1.52587890625e-05f, a);
+  *tb = fmaf(fabsf(b), 1.52587890625e-05f, b);
+}
+static inline int box_test(const float lo[3], const float hi[3], f3 o, f3 inv, float tmin, float tmax, float* tnear) {
+  const float l[3] = {box_lo(lo[0]), box_lo(lo[1]), box_lo(lo[2])}, h[3] = {box_hi(hi[0]), box_hi(hi[1]), box_hi(hi[2])};
+  float a, b;
+  slab_interval(l, h, o, inv, &a, &b);
+  *tnear = a;
+  return a <= b && b >= tmin && a <= tmax;
+}
+/* The validation of the contract: lo / hi = the primitive's own box (tri_box / piece_box); it is widened by 2^-17
+ * relative + 1e-31 (strictly inside what box_lo / box_hi store for any box that contains it, strictly outside the
+ * geometry) and the hit distance has to lie in the ray's interval through it. */
+static inline float vbox_lo(float v) { return fmaf(-fabsf(v), 7.62939453125e-06f, v) - 1e-31f; }
+static inline float vbox_hi(float v) { return fmaf(fabsf(v), 7.62939453125e-06f, v) + 1e-31f; }
+static inline int hit_inside(const float lo[3], const float hi[3], f3 o, f3 inv, float t) {
+  const float l[3] = {vbox_lo(lo[0]), vbox_lo(lo[1]), vbox_lo(lo[2])}, h[3] = {vbox_hi(hi[0]), vbox_hi(hi[1]), vbox_hi(hi[2])};
+  float a, b;
+  slab_interval(l, h, o, inv, &a, &b);
+  return a <= t && t <= b;
+}
+
 typedef struct {
   float t, u, v;
   uint32_t gid;
   f3 ng; /* unnormalised geometric normal (tri) or tangent dP/du (curve) */
 } orc_isect;
 
-static inline int tri_test(const float* geo, f3 o, f3 d, float tmin, float* t, float* u, float* v) {
+static inline int tri_test(const float* geo, f3 o, f3 d, f3 invd, float tmin, float* t, float* u, float* v) {
   f3 v0 = f3_make(geo[0], geo[1], geo[2]), v1 = f3_make(geo[3], geo[4], geo[5]), v2 = f3_make(geo[6], geo[7], geo[8]);
   f3 e1 = f3_sub(v1, v0), e2 = f3_sub(v2, v0);
   f3 p = f3_cross(d, e2);
@@ -746,6 +859,9 @@ static inline int tri_test(const float* geo, f3 o, f3 d, float tmin, float* t, f
   if (!(vv >= 0.0f && uu + vv <= 1.0f)) return 0;
   float tt = f3_dot(e2, q) * inv;
   if (!(tt > tmin)) return 0;
+  float lo[3], hi[3];
+  tri_box(geo, lo, hi);
+  if (!hit_inside(lo, hi, o, invd, tt)) return 0;
   *t = tt, *u = uu, *v = vv;
   return 1;
 }
@@ -774,14 +890,14 @@ static inline f3 bezier_tangent(const float* cp, float u) {
 
 /* Ray-facing flat ribbon (RTC_GEOMETRY_TYPE_FLAT_BEZIER_CURVE semantics, raytracer_impl.cc:158-159):
  * 4 linear sub-segments per cubic, u = curve parameter, v in [-1,1] across the width. */
-static inline int curve_test(const float* cp, f3 o, f3 d, float tmin, float tmax, float* t, float* u, float* v) {
+static inline int curve_test(const float* cp, f3 o, f3 d, f3 invd, float tmin, float tmax, float* t, float* u, float* v) {
   float inv_len = 1.0f / sqrtf(f3_dot(d, d));
   f3 dn = f3_scale(d, inv_len);
   f3 bx, by;
   branchless_onb(dn, &bx, &by);
-  float px[5], py[5], pz[5], pr[5];
+  float px[5], py[5], pz[5], pr[5], pc[5][4];
   for (int i = 0; i < 5; i++) {
-    float c[4];
+    float* c = pc[i];
     bezier_eval(cp, (float)i * 0.25f, c);
     f3 rel = f3_sub(f3_make(c[0], c[1], c[2]), o);
     px[i] = f3_dot(rel, bx), py[i] = f3_dot(rel, by), pz[i] = f3_dot(rel, dn), pr[i] = c[3];
@@ -800,6 +916,9 @@ static inline int curve_test(const float* cp, f3 o, f3 d, float tmin, float tmax
     float tt = (pz[i] + s * (pz[i + 1] - pz[i])) * inv_len;
     if (!(tt > tmin)) continue;
     if (found ? !(tt < best) : !(tt <= best)) continue;
+    float lo[3], hi[3];
+    piece_box(pc[i], pc[i + 1], lo, hi); /* every linear piece is a primitive of the contract */
+    if (!hit_inside(lo, hi, o, invd, tt)) continue;
     best = tt, found = 1;
     *t = tt, *u = ((float)i + s) * 0.25f, *v = dist / r;
   }
@@ -810,37 +929,20 @@ typedef struct {
   uint64_t nodes, tris, curves;
 } orc_trav_stats;
 
-static inline int prim_test(const orc_scene* s, uint32_t gid, f3 o, f3 d, float tmin, float tmax, orc_isect* is,
+static inline int prim_test(const orc_scene* s, uint32_t gid, f3 o, f3 d, f3 inv, float tmin, float tmax, orc_isect* is,
                             orc_trav_stats* st) {
   const float* geo = s->prim_geo + (size_t)gid * ORC_GEO_STRIDE;
   float t, u, v;
   if (s->prims[gid].kind == 0) {
     if (st) st->tris++;
-    if (!tri_test(geo, o, d, tmin, &t, &u, &v)) return 0;
+    if (!tri_test(geo, o, d, inv, tmin, &t, &u, &v)) return 0;
     if (!(t <= tmax)) return 0;
   } else {
     if (st) st->curves++;
-    if (!curve_test(geo, o, d, tmin, tmax, &t, &u, &v)) return 0;
+    if (!curve_test(geo, o, d, inv, tmin, tmax, &t, &u, &v)) return 0;
   }
   is->t = t, is->u = u, is->v = v, is->gid = gid;
   return 1;
-}
-
-/* conservative slab test: the box is widened by 2^-16 relative in space (a ray parallel to an axis with its origin exactly
- * on a face of the tight box would give 0 * inf = NaN and be rejected) and the interval by 2^-16 relative before comparing */
-static inline float box_lo(float v) { return v - (fabsf(v) * 1.52587890625e-05f + 1e-30f); }
-static inline float box_hi(float v) { return v + (fabsf(v) * 1.52587890625e-05f + 1e-30f); }
-static inline int box_test(const float lo[3], const float hi[3], f3 o, f3 inv, float tmin, float tmax, float* tnear) {
-  float t0 = (box_lo(lo[0]) - o.x) * inv.x, t1 = (box_hi(hi[0]) - o.x) * inv.x;
-  float a = fminf(t0, t1), b = fmaxf(t0, t1);
-  t0 = (box_lo(lo[1]) - o.y) * inv.y, t1 = (box_hi(hi[1]) - o.y) * inv.y;
-  a = fmaxf(a, fminf(t0, t1)), b = fminf(b, fmaxf(t0, t1));
-  t0 = (box_lo(lo[2]) - o.z) * inv.z, t1 = (box_hi(hi[2]) - o.z) * inv.z;
-  a = fmaxf(a, fminf(t0, t1)), b = fminf(b, fmaxf(t0, t1));
-  a = a - fabsf(a) * 1.52587890625e-05f;
-  b = b + fabsf(b) * 1.52587890625e-05f;
-  *tnear = a;
-  return a <= b && b >= tmin && a <= tmax;
 }
 
 static int better_hit(float t, uint32_t gid, float best_t, uint32_t best_gid) {
@@ -869,13 +971,13 @@ static int closest_hit(const orc_scene* s, f3 o, f3 d, float tmin, float tmax, i
   orc_isect best, cur;
   memset(&best, 0, sizeof(best));
   int found = 0;
+  const f3 inv = f3_make(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
   if (brute) {
     for (uint32_t g = 0; g < s->nprims; g++)
-      if (prim_test(s, g, o, d, tmin, best_t, &cur, st) && better_hit(cur.t, cur.gid, best_t, best_gid)) {
+      if (prim_test(s, g, o, d, inv, tmin, best_t, &cur, st) && better_hit(cur.t, cur.gid, best_t, best_gid)) {
         best = cur, best_t = cur.t, best_gid = cur.gid, found = 1;
       }
   } else if (s->nnodes > 0) {
-    f3 inv = f3_make(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     uint32_t stack[128];
     int sp = 0;
     stack[sp++] = 0;
@@ -888,7 +990,7 @@ static int closest_hit(const orc_scene* s, f3 o, f3 d, float tmin, float tmax, i
         uint32_t first = (uint32_t)(-1 - n->left), cnt = (uint32_t)n->right;
         for (uint32_t i = first; i < first + cnt; i++) {
           uint32_t g = s->order[i];
-          if (prim_test(s, g, o, d, tmin, best_t, &cur, st) && better_hit(cur.t, cur.gid, best_t, best_gid)) {
+          if (prim_test(s, g, o, d, inv, tmin, best_t, &cur, st) && better_hit(cur.t, cur.gid, best_t, best_gid)) {
             best = cur, best_t = cur.t, best_gid = cur.gid, found = 1;
           }
         }
@@ -921,13 +1023,13 @@ static int closest_hit(const orc_scene* s, f3 o, f3 d, float tmin, float tmax, i
 
 static int any_hit(const orc_scene* s, f3 o, f3 d, float tmin, float tmax, int brute, orc_trav_stats* st) {
   orc_isect cur;
+  const f3 inv = f3_make(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
   if (brute) {
     for (uint32_t g = 0; g < s->nprims; g++)
-      if (prim_test(s, g, o, d, tmin, tmax, &cur, st)) return 1;
+      if (prim_test(s, g, o, d, inv, tmin, tmax, &cur, st)) return 1;
     return 0;
   }
   if (s->nnodes == 0) return 0;
-  f3 inv = f3_make(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
   uint32_t stack[128];
   int sp = 0;
   stack[sp++] = 0;
@@ -939,7 +1041,7 @@ static int any_hit(const orc_scene* s, f3 o, f3 d, float tmin, float tmax, int b
     if (n->left < 0) {
       uint32_t first = (uint32_t)(-1 - n->left), cnt = (uint32_t)n->right;
       for (uint32_t i = first; i < first + cnt; i++)
-        if (prim_test(s, s->order[i], o, d, tmin, tmax, &cur, st)) return 1;
+        if (prim_test(s, s->order[i], o, d, inv, tmin, tmax, &cur, st)) return 1;
     } else {
       stack[sp++] = (uint32_t)n->right;
       stack[sp++] = (uint32_t)n->left;

@@ -2,9 +2,12 @@
 //
 // Stands in for Embree's rtcIntersect1 / rtcOccluded1 behind pbrlab's Raytracer facade
 // (src/raytracer/raytracer_impl.cc:268-287).  Intersection contract:
-//   * a primitive hit is accepted for  tmin < t <= tmax
-//   * closest hit = smallest t; equal t -> smaller canonical primitive id (instance, geom, prim)
-//     => the answer is independent of BVH shape and traversal order
+//   * a primitive hit is accepted for  tmin < t <= tmax  if t also lies inside the interval in which the ray crosses the
+//     primitive's OWN box (hit_inside): a degenerate sliver can pass the triangle test with a meaningless distance far from
+//     the sliver; with this rule the accepted set is a property of (ray, primitive) alone
+//   * closest hit = smallest accepted t; equal t -> smaller canonical primitive id (instance, geom, prim)
+//     => the answer is independent of BVH shape and traversal order (every stored box contains the validation boxes of the
+//     primitives below it, and the slab arithmetic is monotone in the box)
 //   * any-hit = "some primitive has an accepted hit"
 //   * boxes are tested conservatively (interval widened by 2^-16 relative)
 #pragma once
@@ -31,8 +34,26 @@ struct TravStats {
 
 __device__ __forceinline__ V3 ld3(const float4& a) { return V3(a.x, a.y, a.z); }
 
-// Moeller-Trumbore; u,v are the barycentrics of v1,v2 (what Lerp3 expects, pbrlab_math.h:35-38)
-__device__ __forceinline__ bool tri_test(V3 v0, V3 v1, V3 v2, V3 o, V3 d, float tmin, float& t, float& u, float& v) {
+// The validation of the intersection contract: lo / hi = the primitive's own box (a triangle's corners; a ribbon piece's end
+// points widened by the larger end radius), widened here by 2^-17 relative + 1e-31 -- strictly inside what BvhNode::widen_*
+// stores for any box that contains it, strictly outside the geometry -- and t has to lie in the ray's interval through it
+// (widened by 2^-16 relative with the function box_test2 / box_test4 use).  Operation for operation the checker's hit_inside.
+__device__ __forceinline__ float vbox_lo(float v) { return __builtin_fmaf(-fabsf(v), 7.62939453125e-06f, v) - 1e-31f; }
+__device__ __forceinline__ float vbox_hi(float v) { return __builtin_fmaf(fabsf(v), 7.62939453125e-06f, v) + 1e-31f; }
+__device__ __forceinline__ bool hit_inside(V3 lo, V3 hi, V3 o, V3 inv, float t) {
+  float t0 = (vbox_lo(lo.x) - o.x) * inv.x, t1 = (vbox_hi(hi.x) - o.x) * inv.x;
+  float a = __builtin_fminf(t0, t1), b = __builtin_fmaxf(t0, t1);
+  t0 = (vbox_lo(lo.y) - o.y) * inv.y, t1 = (vbox_hi(hi.y) - o.y) * inv.y;
+  a = __builtin_fmaxf(a, __builtin_fminf(t0, t1)), b = __builtin_fminf(b, __builtin_fmaxf(t0, t1));
+  t0 = (vbox_lo(lo.z) - o.z) * inv.z, t1 = (vbox_hi(hi.z) - o.z) * inv.z;
+  a = __builtin_fmaxf(a, __builtin_fminf(t0, t1)), b = __builtin_fminf(b, __builtin_fmaxf(t0, t1));
+  const float e = 1.52587890625e-05f;
+  a = __builtin_fmaf(-fabsf(a), e, a), b = __builtin_fmaf(fabsf(b), e, b);
+  return a <= t && t <= b;
+}
+
+// Moeller-Trumbore; u,v are the barycentrics of v1,v2 (what Lerp3 expects, pbrlab_math.h:35-38); inv = 1 / d
+__device__ __forceinline__ bool tri_test(V3 v0, V3 v1, V3 v2, V3 o, V3 d, V3 inv3, float tmin, float& t, float& u, float& v) {
   V3 e1 = v1 - v0, e2 = v2 - v0;
   V3 p = cross(d, e2);
   float det = dot(e1, p);
@@ -46,6 +67,11 @@ __device__ __forceinline__ bool tri_test(V3 v0, V3 v1, V3 v2, V3 o, V3 d, float 
   if (!(vv >= 0.0f && uu + vv <= 1.0f)) return false;
   float tt = dot(e2, q) * inv;
   if (!(tt > tmin)) return false;
+  const V3 lo(__builtin_fminf(__builtin_fminf(v0.x, v1.x), v2.x), __builtin_fminf(__builtin_fminf(v0.y, v1.y), v2.y),
+              __builtin_fminf(__builtin_fminf(v0.z, v1.z), v2.z));
+  const V3 hi(__builtin_fmaxf(__builtin_fmaxf(v0.x, v1.x), v2.x), __builtin_fmaxf(__builtin_fmaxf(v0.y, v1.y), v2.y),
+              __builtin_fmaxf(__builtin_fmaxf(v0.z, v1.z), v2.z));
+  if (!hit_inside(lo, hi, o, inv3, tt)) return false;
   t = tt, u = uu, v = vv;
   return true;
 }
@@ -74,14 +100,14 @@ __device__ __forceinline__ RayFrame ray_frame(V3 d) {
   branchless_onb(f.dn, f.bx, f.by);
   return f;
 }
-__device__ __forceinline__ bool segment_test(const float4& a, const float4& b, uint32_t i, V3 o, const RayFrame& f, float tmin, float tmax,
-                                             float& t, float& u, float& v);
-__device__ __forceinline__ bool segment_test(const float4& a, const float4& b, uint32_t i, V3 o, V3 d, float tmin, float tmax,
+__device__ __forceinline__ bool segment_test(const float4& a, const float4& b, uint32_t i, V3 o, const RayFrame& f, V3 inv3, float tmin,
+                                             float tmax, float& t, float& u, float& v);
+__device__ __forceinline__ bool segment_test(const float4& a, const float4& b, uint32_t i, V3 o, V3 d, V3 inv3, float tmin, float tmax,
                                              float& t, float& u, float& v) {
-  return segment_test(a, b, i, o, ray_frame(d), tmin, tmax, t, u, v);
+  return segment_test(a, b, i, o, ray_frame(d), inv3, tmin, tmax, t, u, v);
 }
-__device__ __forceinline__ bool segment_test(const float4& a, const float4& b, uint32_t i, V3 o, const RayFrame& f, float tmin, float tmax,
-                                             float& t, float& u, float& v) {
+__device__ __forceinline__ bool segment_test(const float4& a, const float4& b, uint32_t i, V3 o, const RayFrame& f, V3 inv3, float tmin,
+                                             float tmax, float& t, float& u, float& v) {
   const float inv_len = f.inv_len;
   const V3 dn = f.dn, bx = f.bx, by = f.by;
   V3 ra = V3(a.x, a.y, a.z) - o, rb = V3(b.x, b.y, b.z) - o;
@@ -97,6 +123,10 @@ __device__ __forceinline__ bool segment_test(const float4& a, const float4& b, u
   if (!(r > 0.0f && fabsf(dist) <= r)) return false;
   float tt = (pza + s * (pzb - pza)) * inv_len;
   if (!(tt > tmin && tt <= tmax)) return false;
+  const float rm = __builtin_fmaxf(fabsf(a.w), fabsf(b.w));
+  const V3 lo(__builtin_fminf(a.x, b.x) - rm, __builtin_fminf(a.y, b.y) - rm, __builtin_fminf(a.z, b.z) - rm);
+  const V3 hi(__builtin_fmaxf(a.x, b.x) + rm, __builtin_fmaxf(a.y, b.y) + rm, __builtin_fmaxf(a.z, b.z) + rm);
+  if (!hit_inside(lo, hi, o, inv3, tt)) return false;
   t = tt, u = ((float)i + s) * 0.25f, v = dist / r;
   return true;
 }
@@ -176,7 +206,7 @@ __device__ __forceinline__ uint32_t wide_ref(const float4& refs, uint32_t key) {
 // Leaf processing.  any: returns true on the first accepted hit.
 // MODE: 0 = closest hit, 1 = any hit, 2 = per lane (`any_rt`), as in trace_pv.
 template <int MODE, bool STATS, bool CURVES>
-__device__ __forceinline__ bool leaf_test(const DScene& sc, uint32_t leaf, V3 o, V3 d, float tmin, float& best_t,
+__device__ __forceinline__ bool leaf_test(const DScene& sc, uint32_t leaf, V3 o, V3 d, V3 inv, float tmin, float& best_t,
                                           Hit& hit, TravStats& st, bool any_rt) {
   const bool ANY = MODE == 2 ? any_rt : (MODE == 1);
   uint32_t first = (leaf & 0x3FFFFFFFu) >> 3, count = (leaf & 7u) + 1u;
@@ -188,11 +218,11 @@ __device__ __forceinline__ bool leaf_test(const DScene& sc, uint32_t leaf, V3 o,
     if (!CURVES || !is_curve) {
       float4 a = g[0], b = g[1], c = g[2];
       if (STATS) st.tris++;
-      ok = tri_test(ld3(a), ld3(b), ld3(c), o, d, tmin, t, u, v) && (t <= best_t);
+      ok = tri_test(ld3(a), ld3(b), ld3(c), o, d, inv, tmin, t, u, v) && (t <= best_t);
     } else {
       float4 a = g[0], b = g[1], c = g[2];
       if (STATS) st.curves++;
-      ok = segment_test(a, b, __float_as_uint(c.x), o, d, tmin, best_t, t, u, v);
+      ok = segment_test(a, b, __float_as_uint(c.x), o, d, inv, tmin, best_t, t, u, v);
     }
     if (!ok) continue;
     if (ANY) return true;
@@ -243,7 +273,7 @@ __device__ __forceinline__ bool traverse_mode(const DScene& sc, V3 o, V3 d, floa
           next = stack[(uint32_t)sp * stride];
         }
         if (!(next & kLeafBit)) break;
-        if (leaf_test<MODE, STATS, CURVES>(sc, next, o, d, tmin, best_t, hit, st, any_rt)) return true;
+        if (leaf_test<MODE, STATS, CURVES>(sc, next, o, d, inv, tmin, best_t, hit, st, any_rt)) return true;
         next = kEmptyChild;
       }
       cur = next;
@@ -279,7 +309,7 @@ __device__ __forceinline__ bool traverse_mode(const DScene& sc, V3 o, V3 d, floa
         next = stack[(uint32_t)sp * stride];
       }
       if (!(next & kLeafBit)) break;
-      if (leaf_test<MODE, STATS, CURVES>(sc, next, o, d, tmin, best_t, hit, st, any_rt)) return true;
+      if (leaf_test<MODE, STATS, CURVES>(sc, next, o, d, inv, tmin, best_t, hit, st, any_rt)) return true;
       next = kEmptyChild;
     }
     cur = next;

@@ -333,13 +333,13 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
           bool ok;
           if (!CURVES || is_tri) {
             if (STATS) (any_ray ? st.atris : st.tris)++;
-            ok = tri_test(ld3(D0), ld3(D1), ld3(D2), o, d, tmin, t, u, v) && (t <= hit.t);
+            ok = tri_test(ld3(D0), ld3(D1), ld3(D2), o, d, WIDE ? V3(inv4.x, inv4.y, inv4.z) : inv, tmin, t, u, v) && (t <= hit.t);
           } else {
             if (STATS) (any_ray ? st.acurves : st.curves)++;
             RayFrame f;
             f.dn = V3(frame[0], frame[stride], frame[2 * stride]), f.bx = V3(frame[3 * stride], frame[4 * stride], frame[5 * stride]);
             f.by = V3(frame[6 * stride], frame[7 * stride], frame[8 * stride]), f.inv_len = frame[9 * stride];
-            ok = segment_test(D0, D1, __float_as_uint(D2.x), o, f, tmin, hit.t, t, u, v);
+            ok = segment_test(D0, D1, __float_as_uint(D2.x), o, f, WIDE ? V3(inv4.x, inv4.y, inv4.z) : inv, tmin, hit.t, t, u, v);
           }
           if (ok && !any_ray && t == hit.t && hit.slot != kNone) ok = sc.shade[cur - slot0].gid < sc.shade[hit.slot & kHitSlotMask].gid;
           if (ok) {

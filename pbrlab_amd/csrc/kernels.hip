@@ -440,10 +440,11 @@ constexpr uint32_t kLightPretest = 8;
 __device__ __forceinline__ bool misses_all_lights(const DScene& sc, V3 o, V3 d, float tmin) {
   if (sc.lights_transformed) return false;  // the light records hold local positions, the raytracer tests transformed ones
   if (sc.num_lrecs <= kLightPretest) {
+    const V3 inv(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     for (uint32_t i = 0; i < sc.num_lrecs; i++) {
       const float4* lr = reinterpret_cast<const float4*>(sc.lrecs + i);
       float t, u, v;
-      if (tri_test(ld3(lr[0]), ld3(lr[1]), ld3(lr[2]), o, d, tmin, t, u, v)) return false;
+      if (tri_test(ld3(lr[0]), ld3(lr[1]), ld3(lr[2]), o, d, inv, tmin, t, u, v)) return false;
     }
     return true;
   }

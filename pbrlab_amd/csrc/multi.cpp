@@ -78,6 +78,20 @@ int rccl_missing() { return fail(PBRHIP_ECOMM, "RCCL unavailable: %s", g_rccl.er
     if (r_ != ncclSuccess) return fail(PBRHIP_ECOMM, "%s failed: %s (%s:%d)", #expr, (R)->GetErrorString(r_), __FILE__, __LINE__); \
   } while (0)
 
+// Calls between GroupStart and GroupEnd: a failure is recorded and the group is ALWAYS closed before the function returns
+// (the thread's group depth is shared with every other user of this librccl -- PyTorch included: a group left open would
+// queue their later collectives and never launch them).
+#define NCCLGRP(R, first, expr)                 \
+  do {                                          \
+    if ((first) == ncclSuccess) (first) = (expr); \
+  } while (0)
+#define NCCLGRP_END(R, first, what)                                                                                         \
+  do {                                                                                                                      \
+    ncclResult_t e_ = (R)->GroupEnd();                                                                                      \
+    if ((first) == ncclSuccess) (first) = e_;                                                                               \
+    if ((first) != ncclSuccess) return fail(PBRHIP_ECOMM, "%s failed: %s (%s:%d)", what, (R)->GetErrorString(first), __FILE__, __LINE__); \
+  } while (0)
+
 struct pbrhip_comm {
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1, device = 0;
@@ -138,9 +152,10 @@ extern "C" int pbrhip_comm_reduce_layer(pbrhip_comm* c, float* d_rgba, uint32_t*
     HIPCHK(hipSetDevice(c->device));
     // one ncclReduce(sum) over rgba (w*h*4 f32) and one over count (u32), fused in one group
     NCCLCHK(R, R->GroupStart());
-    NCCLCHK(R, R->Reduce(d_rgba, d_rgba, num_pixels * 4, ncclFloat32, ncclSum, root, c->comm, c->stream));
-    NCCLCHK(R, R->Reduce(d_count, d_count, num_pixels, ncclUint32, ncclSum, root, c->comm, c->stream));
-    NCCLCHK(R, R->GroupEnd());
+    ncclResult_t first = ncclSuccess;
+    NCCLGRP(R, first, R->Reduce(d_rgba, d_rgba, num_pixels * 4, ncclFloat32, ncclSum, root, c->comm, c->stream));
+    NCCLGRP(R, first, R->Reduce(d_count, d_count, num_pixels, ncclUint32, ncclSum, root, c->comm, c->stream));
+    NCCLGRP_END(R, first, "ncclReduce of the layer");
     HIPCHK(hipStreamSynchronize(c->stream));
     return PBRHIP_OK;
   });
@@ -205,9 +220,10 @@ extern "C" int pbrhip_comm_gather_layer(pbrhip_comm* c, pbrhip_scene* s, const p
     HIPCHK(s->xchg_recv.reserve(words));
     // every shard arrives over its own xGMI link: post all receives in one group
     NCCLCHK(R, R->GroupStart());
+    ncclResult_t first = ncclSuccess;
     for (uint32_t r = 0; r < world; r++)
-      if ((int)r != root && s->xk_cnt[r]) NCCLCHK(R, R->Recv(s->xchg_recv.p + woff[r], 5 * s->xk_cnt[r], ncclFloat32, (int)r, c->comm, st));
-    NCCLCHK(R, R->GroupEnd());
+      if ((int)r != root && s->xk_cnt[r]) NCCLGRP(R, first, R->Recv(s->xchg_recv.p + woff[r], 5 * s->xk_cnt[r], ncclFloat32, (int)r, c->comm, st));
+    NCCLGRP_END(R, first, "ncclRecv of the shards");
     for (uint32_t r = 0; r < world; r++)
       if ((int)r != root)
         launch_layer_unpack_add(st, s->xchg_pix.p + s->xk_off[r], (uint32_t)s->xk_cnt[r], s->xchg_recv.p + woff[r], d_rgba, d_count);

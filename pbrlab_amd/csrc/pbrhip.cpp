@@ -424,7 +424,48 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
   std::vector<float> lo(3 * (size_t)np), hi(3 * (size_t)np);
   std::vector<uint8_t> kinds(np);
   const float inf = std::numeric_limits<float>::infinity();
+  // Scene bounds (rtcGetSceneBounds, raytracer_impl.cc:199-202; they place the camera): the union of the instances'
+  // bounds.  An RTC_GEOMETRY_TYPE_INSTANCE (raytracer_impl.cc:61-81) reports the box of the transformed CORNERS of its local
+  // scene's box -- larger than the box of the transformed geometry under rotation or shear; an instance whose matrix is
+  // bit for bit the identity reports the local box.  Local box: triangles by their corners, curves by the hull of their
+  // control points widened by the largest control radius.  (The tree below is built over the transformed primitives.)
   float bmin[3] = {inf, inf, inf}, bmax[3] = {-inf, -inf, -inf};
+  for (uint32_t i = 0; i < s->instances.size(); i++) {
+    const HostInstance& inst = s->instances[i];
+    float ll[3] = {inf, inf, inf}, lh[3] = {-inf, -inf, -inf};
+    bool any = false;
+    for (uint32_t g = 0; g < inst.material_ids.size(); g++) {
+      const HostMesh& m = *inst_mesh(s, i, g);
+      for (uint32_t p = 0; p < m.num_prims(); p++) {
+        any = true;
+        if (m.kind == 0) {
+          for (int c = 0; c < 3; c++) {
+            const V3 v = mesh_vertex(m, p, c);
+            const float a[3] = {v.x, v.y, v.z};
+            for (int k = 0; k < 3; k++) ll[k] = fminf(ll[k], a[k]), lh[k] = fmaxf(lh[k], a[k]);
+          }
+        } else {
+          float r = 0.f, cl[3] = {inf, inf, inf}, ch[3] = {-inf, -inf, -inf};
+          for (int c = 0; c < 4; c++) {
+            const float* cp = m.cverts.data() + ((size_t)m.cidx[p] + c) * 4;
+            r = fmaxf(r, fabsf(cp[3]));
+            for (int k = 0; k < 3; k++) cl[k] = fminf(cl[k], cp[k]), ch[k] = fmaxf(ch[k], cp[k]);
+          }
+          for (int k = 0; k < 3; k++) ll[k] = fminf(ll[k], cl[k] - r), lh[k] = fmaxf(lh[k], ch[k] + r);
+        }
+      }
+    }
+    if (!any) continue;
+    if (inst.identity) {
+      for (int k = 0; k < 3; k++) bmin[k] = fminf(bmin[k], ll[k]), bmax[k] = fmaxf(bmax[k], lh[k]);
+    } else {
+      for (int c = 0; c < 8; c++) {
+        const V3 v = xf_point(inst.xf, V3((c & 1) ? lh[0] : ll[0], (c & 2) ? lh[1] : ll[1], (c & 4) ? lh[2] : ll[2]));
+        const float a[3] = {v.x, v.y, v.z};
+        for (int k = 0; k < 3; k++) bmin[k] = fminf(bmin[k], a[k]), bmax[k] = fmaxf(bmax[k], a[k]);
+      }
+    }
+  }
   for (uint32_t g = 0; g < np; g++) {
     const PrimRef& pr = prims[g];
     const HostMesh& m = *inst_mesh(s, pr.instance_id, pr.geom_id);
@@ -438,19 +479,8 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
         for (int k = 0; k < 3; k++) l[k] = std::min(l[k], a[k]), h[k] = std::max(h[k], a[k]);
       }
     } else {
-      // scene bounds (they place the camera): convex hull of the control points widened by the largest control radius,
-      // per whole curve -- the intersection contract shared with the checker
       float cps[16];
       world_curve(inst, m, pr.prim_id, cps);
-      if (pr.sub == 0) {
-        float r = 0.f, cl[3] = {inf, inf, inf}, ch[3] = {-inf, -inf, -inf};
-        for (int c = 0; c < 4; c++) {
-          const float* cp = cps + c * 4;
-          r = std::max(r, fabsf(cp[3]));
-          for (int k = 0; k < 3; k++) cl[k] = std::min(cl[k], cp[k]), ch[k] = std::max(ch[k], cp[k]);
-        }
-        for (int k = 0; k < 3; k++) bmin[k] = std::min(bmin[k], cl[k] - r), bmax[k] = std::max(bmax[k], ch[k] + r);
-      }
       // BVH box of this piece: its two end points widened by the larger end radius (the ribbon between them never
       // leaves that box, and a hit is reported at the depth of the axis point)
       float a[4], b[4];
@@ -458,10 +488,7 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
       const float r = std::max(fabsf(a[3]), fabsf(b[3]));
       for (int k = 0; k < 3; k++) l[k] = std::min(a[k], b[k]) - r, h[k] = std::max(a[k], b[k]) + r;
     }
-    for (int k = 0; k < 3; k++) {
-      lo[3 * g + k] = l[k], hi[3 * g + k] = h[k];
-      if (pr.kind == 0) bmin[k] = std::min(bmin[k], l[k]), bmax[k] = std::max(bmax[k], h[k]);
-    }
+    for (int k = 0; k < 3; k++) lo[3 * g + k] = l[k], hi[3 * g + k] = h[k];
   }
   memcpy(s->bmin, bmin, sizeof(bmin));
   memcpy(s->bmax, bmax, sizeof(bmax));
@@ -1015,7 +1042,10 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
     const uint32_t bulk_div = env_u32("PBRHIP_BULK_DIV", 0u);
     const bool trace_sched = getenv("PBRHIP_TRACE_SCHED") != nullptr;
     const bool sss_walk = env_u32("PBRHIP_SSS_WALK", 1u) != 0u;  // 0: one wavefront iteration per step of a random walk (A/B)
-    if (int rc = ensure_groups(s, kMaxGroups)) return rc;
+    // lanes (stream + counters + 73 MB of traversal spill area each) for the groups this call can have in flight: the first
+    // chunk is the largest, so its plan has the most groups
+    const uint32_t max_lanes = std::min<uint32_t>((uint32_t)kMaxGroups, (uint32_t)plan_groups(std::min(chunk_passes, d->num_sample), npix, want_groups).size());
+    if (int rc = ensure_groups(s, std::max(1u, max_lanes))) return rc;
     struct Group {
       PathState P;
       uint32_t n0, first_pass, npass, slot0;  // paths at the start, pass range, first path slot
@@ -1129,7 +1159,7 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
           for (const Group& gr : G)
             if (gr.started && !gr.finished && gr.n > std::max<uint64_t>(tail_paths, bulk_div ? gr.n0 / bulk_div : 0u)) bulk++;
           int lane = -1;
-          for (int l = 0; l < kMaxGroups; l++)
+          for (int l = 0; l < (int)std::max(1u, max_lanes); l++)
             if (!lane_busy[l]) {
               lane = l;
               break;

@@ -579,49 +579,36 @@ def test_random_materials_parity(pa, seed):
         assert nd == 0, (seed, tail, nd)
 
 
+@pytest.mark.parametrize("extra_slivers", [0, 30])
 @pytest.mark.parametrize("seed", range(6))
-def test_triangle_soup_and_ties(pa, seed):
+def test_triangle_soup_and_ties(pa, seed, extra_slivers):
     """Random triangle soups with exact duplicates, coplanar overlaps, slivers, degenerate (zero-area) triangles and shared
-    edges: equal hit distances must resolve to the smaller canonical id whatever the tree looks like -- oracle BVH, oracle
-    brute force, GPU SAH tree and GPU LBVH tree must agree bit for bit (axis-aligned rays through vertices and edges too)."""
-    from pbrlab_amd import scenes
-    rng = np.random.RandomState(500 + seed)
-    n = 400
-    v = (rng.rand(n, 3, 3).astype(np.float32) * 2 - 1)
-    v[:, 1:] = v[:, :1] + (v[:, 1:] - v[:, :1]) * np.float32(0.3)           # smallish triangles
-    v[:60] = np.round(v[:60] * 4) / 4                                        # snapped to a grid: shared vertices / edges
-    v[60:100, :, 2] = np.float32(0.25)                                      # coplanar, overlapping
-    v[100:120] = v[60:80]                                                    # exact duplicates
-    v[120:130, 2] = v[120:130, 1]                                            # degenerate
-    v[130:140, 2] = v[130:140, 0] + (v[130:140, 1] - v[130:140, 0]) * np.float32(1.000001)   # slivers
-    verts = np.concatenate([v.reshape(-1, 3), np.ones((n * 3, 1), np.float32)], 1)
-    faces = np.arange(n * 3, dtype=np.uint32).reshape(n, 3)
-    mat = dict(scenes.PRINCIPLED_DEFAULTS, kind="principled", name="m")
-    desc = scenes.SceneDesc(verts, np.zeros((0, 4), np.float32), [mat],
-                            [scenes.Shape("a", faces[:250], None, np.zeros(250, np.uint32)),
-                             scenes.Shape("b", faces[250:], None, np.zeros(n - 250, np.uint32))])
-    so = O.oracle_scene_from_desc(desc)
-    lo, hi = so.FetchSceneAABB()
-    rays = scenes.random_rays((lo, hi), 6000, seed=seed)
-    extra = np.zeros(2000, O.RAY_DT)                                         # straight at vertices / along grid lines
-    tgt = verts[rng.randint(len(verts), size=2000), :3]
-    org = np.array([0.3, -0.2, 3.0], np.float32)
-    extra["org"] = org
-    extra["dir"] = tgt - org
-    extra[:500]["org"] = tgt[:500] + np.array([0, 0, 2], np.float32)
-    extra[:500]["dir"] = (0, 0, -1)
-    extra["tmin"], extra["tmax"] = 0.0, 1e30
-    rays = np.concatenate([rays, extra])
-    ho = so.trace_closest(rays)
-    hb = so.trace_closest(rays[:1500], brute_force=True)
-    assert_hits_equal(ho[:1500], hb)
-    assert (ho["instance_id"] != 0xFFFFFFFF).sum() > 1500
+    edges (tests/_soups.py): equal hit distances must resolve to the smaller canonical id and an accepted hit must be a
+    property of (ray, primitive) alone, whatever the tree looks like -- oracle BVH, oracle brute force (EVERY ray, incl. ray
+    6858 of seed 1 on which a brute-force loop and the near-first traversals disagreed until round 3), GPU SAH tree, its
+    4-wide collapse, the binary tree walked instead (PBRHIP_WIDE=0) and the GPU LBVH tree must agree bit for bit."""
+    import _soups
+    desc, so, rays = _soups.triangle_soup(seed, extra_slivers)
+    hb = so.trace_closest(rays, brute_force=True)
+    assert_hits_equal(so.trace_closest(rays), hb)
+    assert (hb["instance_id"] != 0xFFFFFFFF).sum() > 1500
+    short = rays.copy()
+    short["tmax"] = np.where(np.isfinite(hb["t"]) & (hb["instance_id"] != 0xFFFFFFFF), hb["t"], 1.0)    # tmax == hit distance: accepted (t <= tmax)
+    ob = so.trace_any(short, brute_force=True)
+    assert np.array_equal(so.trace_any(short), ob)
     for builder in (pa.api.BVH_HOST_SAH, pa.api.BVH_GPU_LBVH):
         sg = pa.scene_from_desc(desc, bvh_builder=builder)
-        assert_hits_equal(sg.trace_closest(rays), ho)
-        short = rays.copy()
-        short["tmax"] = np.where(np.isfinite(ho["t"]) & (ho["instance_id"] != 0xFFFFFFFF), ho["t"], 1.0)    # tmax == hit distance: accepted (t <= tmax)
-        assert np.array_equal(sg.trace_any(short), so.trace_any(short))
+        for wide in ("1", "0") if builder == pa.api.BVH_HOST_SAH else ("1",):
+            os.environ["PBRHIP_WIDE"] = wide
+            try:
+                assert_hits_equal(sg.trace_closest(rays), hb)
+                assert np.array_equal(sg.trace_any(short), ob)
+                os.environ["PBRHIP_SIMPLE_TRAVERSAL"] = "1"      # the one-ray-per-lane traversal (second implementation)
+                assert_hits_equal(sg.trace_closest(rays), hb)
+                assert np.array_equal(sg.trace_any(short), ob)
+            finally:
+                os.environ.pop("PBRHIP_WIDE", None)
+                os.environ.pop("PBRHIP_SIMPLE_TRAVERSAL", None)
 
 
 @pytest.mark.parametrize("seed", range(4))
