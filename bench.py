@@ -316,9 +316,10 @@ def main():
         _, solo = api.Render(scene, W, H, spp, tile_rank=rank, tile_world=world, device_out=ptrs,
                              flags=api.RENDER_TIMING, max_paths_in_flight=args.max_paths, num_streams=1, shard_block=shard_block)
         torch.cuda.synchronize()
-        node_b = int(sst.get("node_bytes") or NODE_B)  # 128 when k_trace walks the 4-wide tree (triangle-only scenes)
+        node_b = int(sst.get("node_bytes") or NODE_B)    # 64: a node of the Q tree (4 children, quantised boxes) or of the binary tree
+        curve_b = int(sst.get("curve_bytes") or CURVE_B)  # 32 when a curve piece is two 16-byte points of a chain (Q tree), 64 for a slot
         bytes_step = (node_b * (sst["closest_nodes"] + sst["shadow_nodes"]) + TRI_B * (sst["closest_tris"] + sst["shadow_tris"]) +
-                      CURVE_B * (sst["closest_curves"] + sst["shadow_curves"]) + RAY_B * sst["closest_rays"] +
+                      curve_b * (sst["closest_curves"] + sst["shadow_curves"]) + RAY_B * sst["closest_rays"] +
                       SHADOW_RAY_B * sst["shadow_rays"])
         launches = agg["n_trace_closest"] / args.steps
         ms_step = agg["ms_trace_closest"] / args.steps
@@ -348,7 +349,7 @@ def main():
                         bound = "valu"
             roofline = {"bound": bound, "kernel": "k_trace (closest-hit rays of bounce k + shadow rays of bounce k-1)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                        "note": "achieved / frac = ALGORITHMIC bytes (64 B per visit of a binary node, 128 B per visit of a 4-wide node -- node_bytes --, 48 B per triangle test, 52 B per ray: SURVEY 8d) / kernel "
+                        "note": "achieved / frac = ALGORITHMIC bytes (64 B per node visit -- binary tree or the Q tree's quantised 4-wide node --, 48 B per triangle test, 32 B per curve-piece test on the Q tree (64 on the binary tree), 52 B per ray: SURVEY 8d) / kernel "
                                 "time (HIP events on the launch's own stream, timed region) -- NOT a ceiling: the scene is served from L2 / "
                                 "Infinity Cache, so it can exceed 1.  The ceilings are frac_hbm_counter (HBM-side bytes from the FETCH_SIZE / "
                                 "WRITE_SIZE PMC passes per launch / solo launch duration / 8 TB/s) and valu.frac (VALU issue); `bound` names "
@@ -359,7 +360,7 @@ def main():
                                  "achieved": bytes_step / (solo_ms * 1e-3) / 1e9,
                                  "frac": bytes_step / (solo_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_frame": solo["ms_total"]},
                         "traffic": traffic, "frac_hbm_counter": frac_hbm_counter, "valu": valu, "pmc_source": pmc_note,
-                        "algorithmic_bytes_per_launch": bytes_step / max(launches, 1), "node_bytes": node_b,
+                        "algorithmic_bytes_per_launch": bytes_step / max(launches, 1), "node_bytes": node_b, "curve_bytes": curve_b,
                         "avg_launch_ms": ms_step / max(launches, 1), "launches_per_step": launches,
                         "rays_per_step": sst["closest_rays"] + sst["shadow_rays"],
                         "kernel_ms_per_step": {{"trace_closest": "trace", "surface": "classify"}.get(k[3:], k[3:]): solo[k]

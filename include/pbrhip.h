@@ -110,7 +110,8 @@ typedef struct {
                            Russian roulette was already known to fail and the ray cannot reach an area light (it misses every
                            light primitive, or the bounding box of every light), so nothing it could find changes the image (closest + tail_closest + pruned = the reference's count) */
   uint64_t passes_done; /* passes every pixel of this rank holds when the call returns (= num_sample unless cancelled) */
-  uint64_t node_bytes;  /* footprint of one node of the tree k_trace walked: 128 (4-wide tree, triangle-only scenes) or 64 (binary) */
+  uint64_t node_bytes;  /* footprint of one node of the tree k_trace walked: 64 (the Q tree: 4 children, quantised boxes; or the binary tree) */
+  uint64_t curve_bytes; /* bytes fetched per curve-piece test: 32 (Q tree: two 16-byte points of a chain) or 64 (binary tree: one slot) */
 } pbrhip_render_stats;
 
 const char* pbrhip_last_error(void);

@@ -237,26 +237,74 @@ void build_bvh(const std::vector<float>& lo, const std::vector<float>& hi, const
   out->depth = depth;
 }
 
-uint32_t collapse_bvh4(const std::vector<BvhNode>& N2, std::vector<Bvh4Node>* out) {
+// Quantises the boxes of up to four children into a QNode (dscene.h).  Per axis: step s = the smallest power of two with
+// (extent / s) + 2 <= 255, org = the node's lower bound rounded down; a child's bounds are rounded outwards on that grid and
+// then checked -- and moved out further if need be -- with the expression the traversal evaluates, fmaf(q, s, org) in single
+// precision; when the grid is too fine for that arithmetic (a step below the resolution of org) the step doubles.
+static bool quantise_node(const QChild* c, int n, QNode* nd) {
+  memset(nd, 0, sizeof(*nd));
+  uint32_t* qw[6] = {&nd->qlo_x, &nd->qlo_y, &nd->qlo_z, &nd->qhi_x, &nd->qhi_y, &nd->qhi_z};
+  for (int a = 0; a < 3; a++) {
+    float lo = std::numeric_limits<float>::infinity(), hi = -lo;
+    for (int i = 0; i < n; i++) lo = std::min(lo, c[i].lo[a]), hi = std::max(hi, c[i].hi[a]);
+    if (!(lo <= hi) || !std::isfinite(lo) || !std::isfinite(hi)) return false;
+    int e;
+    frexpf(std::max((hi - lo) / 253.0f, 1.1754944e-38f), &e);  // 2^(e-1) <= x < 2^e
+    float sc = ldexpf(1.0f, e);
+    for (int tries = 0;; tries++) {
+      if (tries > 40 || !std::isfinite(sc)) return false;
+      const float org = lo;
+      bool ok = true;
+      uint32_t wl = 0, wh = 0;
+      for (int i = 0; i < 4 && ok; i++) {
+        if (i >= n) {  // unused child (reference kEmptyChild): never visited, any bytes will do
+          wl |= 255u << (8 * i);
+          continue;
+        }
+        int ql = (int)floor(((double)c[i].lo[a] - (double)org) / (double)sc);
+        int qh = (int)ceil(((double)c[i].hi[a] - (double)org) / (double)sc);
+        ql = std::max(0, std::min(255, ql)), qh = std::max(0, std::min(255, qh));
+        while (ql > 0 && !(fmaf((float)ql, sc, org) <= c[i].lo[a])) ql--;
+        while (qh < 255 && !(fmaf((float)qh, sc, org) >= c[i].hi[a])) qh++;
+        if (!(fmaf((float)ql, sc, org) <= c[i].lo[a] && fmaf((float)qh, sc, org) >= c[i].hi[a])) ok = false;
+        wl |= (uint32_t)ql << (8 * i), wh |= (uint32_t)qh << (8 * i);
+      }
+      if (ok) {
+        nd->org[a] = org;
+        (a == 0 ? nd->sx : (a == 1 ? nd->sy : nd->sz)) = sc;
+        *qw[a] = wl, *qw[3 + a] = wh;
+        break;
+      }
+      sc *= 2.0f;
+    }
+  }
+  return true;
+}
+
+uint32_t build_qtree(const std::vector<BvhNode>& N2, const std::function<int(uint32_t, const float*, const float*, QChild*)>& map_leaf,
+                     std::vector<QNode>* out) {
   out->clear();
   if (N2.empty()) return 0;
-  struct Child {
-    uint32_t ref;
-    float lo[3], hi[3];
-  };
-  auto children_of = [&](uint32_t node, Child* c) {
+  // children of a node of the binary tree as they appear in the Q tree (a leaf can become two): at most 4
+  auto children_of = [&](uint32_t node, QChild* c) {
     int n = 0;
     const BvhNode& b = N2[node];
     for (int k = 0; k < 2; k++) {
       const uint32_t ref = k ? b.c1 : b.c0;
       if (ref == kEmptyChild) continue;
-      c[n].ref = ref;
-      for (int a = 0; a < 3; a++) c[n].lo[a] = b.lo[a][k], c[n].hi[a] = b.hi[a][k];
-      n++;
+      float lo[3], hi[3];
+      for (int a = 0; a < 3; a++) lo[a] = b.lo[a][k], hi[a] = b.hi[a][k];
+      if (ref & kLeafBit) {
+        n += map_leaf(ref, lo, hi, c + n);
+      } else {
+        c[n].ref = ref;
+        for (int a = 0; a < 3; a++) c[n].lo[a] = lo[a], c[n].hi[a] = hi[a];
+        n++;
+      }
     }
     return n;
   };
-  auto area = [](const Child& c) {
+  auto area = [](const QChild& c) {
     const float dx = c.hi[0] - c.lo[0], dy = c.hi[1] - c.lo[1], dz = c.hi[2] - c.lo[2];
     return dx * dy + dy * dz + dz * dx;
   };
@@ -271,38 +319,58 @@ uint32_t collapse_bvh4(const std::vector<BvhNode>& N2, std::vector<Bvh4Node>* ou
     const Item it = work.back();
     work.pop_back();
     levels = std::max(levels, it.level);
-    Child c[4];
-    int n = children_of(it.node2, c);
+    QChild c[8];
+    int n = children_of(it.node2, c);  // <= 4
     while (n < 4) {
-      int best = -1;
-      for (int i = 0; i < n; i++)
-        if (!(c[i].ref & kLeafBit) && (best < 0 || area(c[i]) > area(c[best]))) best = i;
+      // replace the inner child of largest surface area whose own children still fit by those children
+      int best = -1, bm = 0;
+      QChild bg[4];
+      for (int i = 0; i < n; i++) {
+        if ((c[i].ref & kLeafBit) || (best >= 0 && !(area(c[i]) > area(c[best])))) continue;
+        QChild g[4];
+        const int m = children_of(c[i].ref, g);
+        if (m == 0 || n - 1 + m > 4) continue;
+        best = i, bm = m;
+        for (int j = 0; j < m; j++) bg[j] = g[j];
+      }
       if (best < 0) break;
-      Child g[2];
-      const int m = children_of(c[best].ref, g);
-      c[best] = g[0];
-      if (m > 1) c[n++] = g[1];
+      c[best] = bg[0];
+      for (int j = 1; j < bm; j++) c[n++] = bg[j];
     }
-    Bvh4Node nd;
-    memset(&nd, 0, sizeof(nd));
-    for (int i = 0; i < 4; i++) {
-      nd.c[i] = kEmptyChild;
-      for (int a = 0; a < 3; a++) nd.lo[a][i] = nd.hi[a][i] = std::numeric_limits<float>::quiet_NaN();
+    QNode nd;
+    if (!quantise_node(c, n, &nd)) {
+      out->clear();
+      return 0;
     }
+    for (int i = 0; i < 4; i++) nd.c[i] = kEmptyChild;
     for (int i = 0; i < n; i++) {
-      for (int a = 0; a < 3; a++) nd.lo[a][i] = c[i].lo[a], nd.hi[a][i] = c[i].hi[a];
       if (c[i].ref & kLeafBit) {
         nd.c[i] = c[i].ref;
       } else {
         const uint32_t id = (uint32_t)out->size();
         out->emplace_back();
-        nd.c[i] = 2u * id;  // item index: a wide node is two 64-byte items
+        nd.c[i] = id;
         work.push_back({c[i].ref, id, it.level + 1u});
       }
     }
     (*out)[it.out] = nd;
   }
-  return 3u * levels;
+  // the stack a near-first traversal can need: on the way down every node leaves at most (children - 1) entries behind.
+  // need(node) = max over its inner children of (children - 1 + need(child)), at least (children - 1); children have
+  // larger indices than their parent, so one backward sweep does it
+  (void)levels;
+  std::vector<uint32_t> need(out->size(), 0);
+  for (size_t i = out->size(); i-- > 0;) {
+    const QNode& nd = (*out)[i];
+    uint32_t nc = 0, deepest = 0;
+    for (int k = 0; k < 4; k++) {
+      if (nd.c[k] == kEmptyChild) continue;
+      nc++;
+      if (!(nd.c[k] & kLeafBit)) deepest = std::max(deepest, need[nd.c[k]]);
+    }
+    need[i] = (nc ? nc - 1u : 0u) + deepest;
+  }
+  return need[0];
 }
 
 }  // namespace pb

@@ -26,9 +26,10 @@ constexpr uint32_t kEmptyChild = 0xFFFFFFFFu;  // (a leaf reference that can nev
 #endif
 constexpr int kMaxLeaf = PB_MAX_LEAF;
 #ifndef PB_STACK_DEPTH
-#define PB_STACK_DEPTH 40
+#define PB_STACK_DEPTH 64
 #endif
-constexpr int kStackDepth = PB_STACK_DEPTH;
+constexpr int kStackDepth = PB_STACK_DEPTH;  // traversal stack entries per ray (a tree that can need more is refused at commit)
+constexpr int kSimpleLdsStack = 40;          // of which the one-ray-per-lane traversal (dtrace.h::traverse: k_tail, trace hooks) keeps this many in LDS
 // The host builder numbers the first kTopNodes nodes breadth first (levels 0..5 of a full tree): DScene::top_nodes of
 // them form the top of the tree and are staged in LDS by k_trace (4 KB per block).  0 for trees without that numbering.
 #ifndef PB_TOP_NODES
@@ -55,17 +56,28 @@ struct alignas(16) BvhNode {
 };
 static_assert(sizeof(BvhNode) == 64, "node must be 64 B");
 
-// The same tree with four children per node (bvh_build.cpp::collapse_bvh4: every node of the binary tree absorbs the
-// children of its largest children): 128 B = two 64-byte items; [bound][axis][child] so that one 16-byte load holds the four
-// children's values of one bound.  Child references as above, an inner child's reference being its ITEM index (2 x node).
-// Boxes are the binary tree's (already widened).  An unused child has NaN bounds (never hit) and reference kEmptyChild.
-struct alignas(16) Bvh4Node {
-  float lo[3][4];
-  float hi[3][4];
+// The same tree with four children per node and quantised boxes (bvh_build.cpp::build_qtree: every node of the binary tree
+// absorbs the children of its largest children): 64 B = ONE item.  Per axis the node has an origin `org` and a power-of-two
+// step `s`; child i's box is [fma(qlo[i], s, org), fma(qhi[i], s, org)] in single precision with 8-bit qlo / qhi (byte i of the
+// word), rounded outwards: the builder evaluates that very expression and moves a bound out until the result encloses the
+// binary tree's (already widened) box.  The traversal rebuilds the bounds the same way and then runs the binary tree's slab
+// arithmetic on them, so the quantised test inherits its properties (monotone in the box, correct for axis-parallel rays).
+// Child references: an inner child = its item index; a triangle leaf = kLeafBit | first << 3 | (count - 1) with `first` the
+// index into the tree's own compact triangle slots (DScene::q_tri0); a curve leaf = kLeafBit | kCurveBit | first << 3 |
+// (count - 1) with `first` a POINT index (DScene::q_pt0): the linear pieces of a strand are stored as a chain of points
+// (xyz + radius, 16 B), piece p = points p, p + 1, piece-in-cubic index = p & 3 (every cubic starts at a multiple of 4).
+// An unused child has reference kEmptyChild.
+struct alignas(16) QNode {
+  float org[3], sx;
+  float sy, sz;
+  uint32_t qlo_x, qlo_y;
+  uint32_t qlo_z, qhi_x, qhi_y, qhi_z;
   uint32_t c[4];
-  uint32_t pad[4];
 };
-static_assert(sizeof(Bvh4Node) == 128, "wide node must be 128 B");
+static_assert(sizeof(QNode) == 64, "quantised wide node must be 64 B");
+// during a traversal of the Q tree a curve hit is held as kQPointHit | point index; it becomes the hit code every other
+// stage sees (slot | routing bits, below) through DScene::q_hitcode when the ray is delivered
+constexpr uint32_t kQPointHit = 0x80000000u;
 
 constexpr uint32_t kSlotHasNormals = 1u;
 constexpr uint32_t kSlotIsCurve = 2u;
@@ -174,8 +186,11 @@ struct DScene {
   const float* tex_pixels;
   const TexDesc* textures;
   uint32_t num_nodes, num_slots, num_lights, num_materials, num_curves, num_textures, num_lrecs;
-  const float4* wide;           // 4-wide tree: wide_nodes x Bvh4Node followed by a copy of the slots (one array of 64-byte items), or null
+  const float4* wide;           // Q tree (4-wide, quantised): wide_nodes x QNode, its compact triangle slots (64 B: corners, .w of the third
+                                // word = the hit code slot | routing bits), the points of the curve pieces (16 B); or null
   uint32_t wide_nodes;
+  uint32_t q_tri0, q_pt0;       // 16-byte index of triangle slot 0 / point 0 in `wide`
+  const uint32_t* q_hitcode;    // per point p: the hit code of piece p (slot | routing bits)
   uint32_t top_nodes;           // nodes 0 .. top_nodes-1 are the breadth-first top of the tree (<= kTopNodes; 0: not numbered that way)
   uint32_t lights_transformed;  // an emissive instance has a transform: lrecs / light_boxes are not what the raytracer sees
 };

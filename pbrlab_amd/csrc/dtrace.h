@@ -156,23 +156,27 @@ __device__ __forceinline__ void box_test2(const float4& n0, const float4& n1, co
   h1 = a1 <= b1 && b1 >= tmin && a1 <= tmax;
 }
 
-// The same slab test on the four boxes of a wide node (Bvh4Node): lx .. hz hold one bound of the four children each.
+// The slab test on the four quantised boxes of a wide node (QNode, dscene.h).  w0 = (org.x, org.y, org.z, s.x), w1 = (s.y, s.z,
+// qlo.x, qlo.y), w2 = (qlo.z, qhi.x, qhi.y, qhi.z); byte i of a q word belongs to child i.  A bound is rebuilt as
+// fma(q, s, org) (v_cvt_f32_ubyte + v_pk_fma_f32) -- the builder has checked with this very expression that the result
+// encloses the binary tree's box -- and from there on the arithmetic is box_test2's, operation for operation: the test is
+// monotone in the box like the binary tree's, rays parallel to an axis included.
 // ta / tb: entry / exit distance of each box (widened like box_test2's); the caller compares them with the ray's interval.
-__device__ __forceinline__ void box_test4(const float4& lx, const float4& ly, const float4& lz, const float4& hx, const float4& hy,
-                                          const float4& hz, V3 o, const float4& inv, float ta[4], float tb[4]) {
+__device__ __forceinline__ void box_test4q(const float4& w0, const float4& w1, const float4& w2, V3 o, const float4& inv, float ta[4],
+                                           float tb[4]) {
   const float e = 1.52587890625e-05f;
+  const uint32_t lx = __float_as_uint(w1.z), ly = __float_as_uint(w1.w), lz = __float_as_uint(w2.x);
+  const uint32_t hx = __float_as_uint(w2.y), hy = __float_as_uint(w2.z), hz = __float_as_uint(w2.w);
+  const f2 sx = {w0.w, w0.w}, sy = {w1.x, w1.x}, sz = {w1.y, w1.y}, gx = {w0.x, w0.x}, gy = {w0.y, w0.y}, gz = {w0.z, w0.z};
+  const f2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z}, ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
 #pragma unroll
   for (int h = 0; h < 2; h++) {
-    const f2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
-    const f2 ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
-    const f2 ax = h ? f2{lx.z, lx.w} : f2{lx.x, lx.y}, bx = h ? f2{hx.z, hx.w} : f2{hx.x, hx.y};
-    const f2 ay = h ? f2{ly.z, ly.w} : f2{ly.x, ly.y}, by = h ? f2{hy.z, hy.w} : f2{hy.x, hy.y};
-    const f2 az = h ? f2{lz.z, lz.w} : f2{lz.x, lz.y}, bz = h ? f2{hz.z, hz.w} : f2{hz.x, hz.y};
-    f2 p = (ax - ox) * ix, q = (bx - ox) * ix;
+    auto two = [h](uint32_t w) { return h ? f2{(float)((w >> 16) & 255u), (float)(w >> 24)} : f2{(float)(w & 255u), (float)((w >> 8) & 255u)}; };
+    f2 p = (__builtin_elementwise_fma(two(lx), sx, gx) - ox) * ix, q = (__builtin_elementwise_fma(two(hx), sx, gx) - ox) * ix;
     f2 a = __builtin_elementwise_min(p, q), b = __builtin_elementwise_max(p, q);
-    p = (ay - oy) * iy, q = (by - oy) * iy;
+    p = (__builtin_elementwise_fma(two(ly), sy, gy) - oy) * iy, q = (__builtin_elementwise_fma(two(hy), sy, gy) - oy) * iy;
     a = __builtin_elementwise_max(a, __builtin_elementwise_min(p, q)), b = __builtin_elementwise_min(b, __builtin_elementwise_max(p, q));
-    p = (az - oz) * iz, q = (bz - oz) * iz;
+    p = (__builtin_elementwise_fma(two(lz), sz, gz) - oz) * iz, q = (__builtin_elementwise_fma(two(hz), sz, gz) - oz) * iz;
     a = __builtin_elementwise_max(a, __builtin_elementwise_min(p, q)), b = __builtin_elementwise_min(b, __builtin_elementwise_max(p, q));
     ta[2 * h] = __builtin_fmaf(-fabsf(a.x), e, a.x), ta[2 * h + 1] = __builtin_fmaf(-fabsf(a.y), e, a.y);
     tb[2 * h] = __builtin_fmaf(fabsf(b.x), e, b.x), tb[2 * h + 1] = __builtin_fmaf(fabsf(b.y), e, b.y);
@@ -182,13 +186,14 @@ __device__ __forceinline__ void box_test4(const float4& lx, const float4& ly, co
 // One step at a wide node: the children the ray's interval [tmin, tmax] hits, nearest first.  k[0..3] ascending; a key is the
 // child's entry distance (>= 0 as an integer; its two low bits hold the child index, wide_ref), 0xFFFFFFFF = not hit.
 constexpr uint32_t kWideMiss = 0xFFFFFFFFu;
-__device__ __forceinline__ void wide_node_keys(const float4& lx, const float4& ly, const float4& lz, const float4& hx, const float4& hy,
-                                               const float4& hz, V3 o, const float4& inv, float tmin, float tmax, uint32_t k[4]) {
+__device__ __forceinline__ void wide_node_keys(const float4& w0, const float4& w1, const float4& w2, const float4& refs, V3 o,
+                                               const float4& inv, float tmin, float tmax, uint32_t k[4]) {
   float ta[4], tb[4];
-  box_test4(lx, ly, lz, hx, hy, hz, o, inv, ta, tb);
+  box_test4q(w0, w1, w2, o, inv, ta, tb);
+  const uint32_t r[4] = {__float_as_uint(refs.x), __float_as_uint(refs.y), __float_as_uint(refs.z), __float_as_uint(refs.w)};
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    const bool h = ta[i] <= tb[i] && tb[i] >= tmin && ta[i] <= tmax;
+    const bool h = ta[i] <= tb[i] && tb[i] >= tmin && ta[i] <= tmax && r[i] != kEmptyChild;
     const int bits = (int)__float_as_uint(ta[i]);
     k[i] = h ? ((uint32_t)(bits < 0 ? 0 : bits) & ~3u) | (uint32_t)i : kWideMiss;
   }
@@ -203,34 +208,63 @@ __device__ __forceinline__ uint32_t wide_ref(const float4& refs, uint32_t key) {
   return (key & 2u) ? b : a;
 }
 
+// canonical id of a hit held by a traversal of the Q tree (ties between equal distances go to the smaller one): a triangle's
+// hit code carries its slot, a curve hit is held as kQPointHit | point
+__device__ __forceinline__ uint32_t q_gid(const DScene& sc, uint32_t code) {
+  const uint32_t c = (code & kQPointHit) ? sc.q_hitcode[code & ~kQPointHit] : code;
+  return sc.shade[c & kHitSlotMask].gid;
+}
+// the hit code the other stages see
+__device__ __forceinline__ uint32_t q_final_code(const DScene& sc, uint32_t code) {
+  return (code != kNone && (code & kQPointHit)) ? sc.q_hitcode[code & ~kQPointHit] : code;
+}
+
 // Leaf processing.  any: returns true on the first accepted hit.
 // MODE: 0 = closest hit, 1 = any hit, 2 = per lane (`any_rt`), as in trace_pv.
-template <int MODE, bool STATS, bool CURVES>
+template <int MODE, bool STATS, bool CURVES, bool WIDE = false>
 __device__ __forceinline__ bool leaf_test(const DScene& sc, uint32_t leaf, V3 o, V3 d, V3 inv, float tmin, float& best_t,
                                           Hit& hit, TravStats& st, bool any_rt) {
   const bool ANY = MODE == 2 ? any_rt : (MODE == 1);
   uint32_t first = (leaf & 0x3FFFFFFFu) >> 3, count = (leaf & 7u) + 1u;
   bool is_curve = (leaf & kCurveBit) != 0;
   for (uint32_t s = first; s < first + count; s++) {
-    const float4* g = sc.slots + (size_t)s * 4;
     float t, u, v;
     bool ok;
-    if (!CURVES || !is_curve) {
-      float4 a = g[0], b = g[1], c = g[2];
-      if (STATS) st.tris++;
-      ok = tri_test(ld3(a), ld3(b), ld3(c), o, d, inv, tmin, t, u, v) && (t <= best_t);
+    uint32_t code;
+    if (WIDE) {  // Q tree: compact triangle slots / chains of curve points (dscene.h)
+      if (!CURVES || !is_curve) {
+        const float4* g = sc.wide + sc.q_tri0 + (size_t)s * 4;
+        float4 a = g[0], b = g[1], c = g[2];
+        if (STATS) st.tris++;
+        ok = tri_test(ld3(a), ld3(b), ld3(c), o, d, inv, tmin, t, u, v) && (t <= best_t);
+        code = __float_as_uint(c.w);
+      } else {
+        const float4* g = sc.wide + sc.q_pt0 + s;
+        float4 a = g[0], b = g[1];
+        if (STATS) st.curves++;
+        ok = segment_test(a, b, s & 3u, o, d, inv, tmin, best_t, t, u, v);
+        code = kQPointHit | s;
+      }
     } else {
+      const float4* g = sc.slots + (size_t)s * 4;
       float4 a = g[0], b = g[1], c = g[2];
-      if (STATS) st.curves++;
-      ok = segment_test(a, b, __float_as_uint(c.x), o, d, inv, tmin, best_t, t, u, v);
+      if (!CURVES || !is_curve) {
+        if (STATS) st.tris++;
+        ok = tri_test(ld3(a), ld3(b), ld3(c), o, d, inv, tmin, t, u, v) && (t <= best_t);
+      } else {
+        if (STATS) st.curves++;
+        ok = segment_test(a, b, __float_as_uint(c.x), o, d, inv, tmin, best_t, t, u, v);
+      }
+      code = s | __float_as_uint(c.w);  // + routing bits (dscene.h)
     }
     if (!ok) continue;
     if (ANY) return true;
     if (t == best_t && hit.slot != kNone) {  // tie: the smaller canonical primitive id wins
-      if (!(sc.shade[s].gid < sc.shade[hit.slot & kHitSlotMask].gid)) continue;
+      const bool less = WIDE ? q_gid(sc, code) < q_gid(sc, hit.slot) : sc.shade[s].gid < sc.shade[hit.slot & kHitSlotMask].gid;
+      if (!less) continue;
     }
     best_t = t;
-    hit.t = t, hit.u = u, hit.v = v, hit.slot = s | __float_as_uint(g[2].w);  // + routing bits (dscene.h)
+    hit.t = t, hit.u = u, hit.v = v, hit.slot = code;
   }
   return false;
 }
@@ -239,7 +273,18 @@ __device__ __forceinline__ bool leaf_test(const DScene& sc, uint32_t leaf, V3 o,
 // WIDE: the 4-wide tree (sc.wide must not be null): nearest hit child next, the others pushed farthest first.
 template <int MODE, bool STATS, bool CURVES, bool WIDE = false>
 __device__ __forceinline__ bool traverse_mode(const DScene& sc, V3 o, V3 d, float tmin, float tmax, Hit& hit,
-                                              uint32_t* stack, uint32_t stride, TravStats& st, uint32_t* overflow, bool any_rt) {
+                                              uint32_t* stack, uint32_t stride, TravStats& st, uint32_t* overflow, bool any_rt,
+                                              uint32_t* spill, uint32_t spill_stride) {
+  // stack: entries 0 .. kSimpleLdsStack-1 (stack[i * stride], LDS); deeper ones in spill[(i - kSimpleLdsStack) * spill_stride]
+  auto push = [&](int& sp, uint32_t v) {
+    if (sp < kSimpleLdsStack) stack[(uint32_t)sp * stride] = v, sp++;
+    else if (sp < kStackDepth) spill[(uint32_t)(sp - kSimpleLdsStack) * spill_stride] = v, sp++;
+    else *overflow = 1u;
+  };
+  auto pop = [&](int& sp) {
+    sp--;
+    return sp < kSimpleLdsStack ? stack[(uint32_t)sp * stride] : spill[(uint32_t)(sp - kSimpleLdsStack) * spill_stride];
+  };
   hit.slot = kNone;
   hit.t = tmax, hit.u = 0.f, hit.v = 0.f;
   if (sc.num_nodes == 0) return false;
@@ -251,29 +296,26 @@ __device__ __forceinline__ bool traverse_mode(const DScene& sc, V3 o, V3 d, floa
     // cur is an internal node
     if (WIDE) {
       const float4* np = sc.wide + (size_t)cur * 4u;  // (a wide node's reference is its 64-byte item index)
-      const float4 lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5], refs = np[6];
+      const float4 w0 = np[0], w1 = np[1], w2 = np[2], refs = np[3];
       if (STATS) st.nodes++;
       uint32_t k[4];
-      wide_node_keys(lx, ly, lz, hx, hy, hz, o, make_float4(inv.x, inv.y, inv.z, 0.f), tmin, best_t, k);
+      wide_node_keys(w0, w1, w2, refs, o, make_float4(inv.x, inv.y, inv.z, 0.f), tmin, best_t, k);
 #pragma unroll
       for (int j = 3; j >= 1; j--) {
         if (k[j] == kWideMiss) continue;
-        if (sp < kStackDepth) {
-          stack[(uint32_t)sp * stride] = wide_ref(refs, k[j]);
-          sp++;
-        } else {
-          *overflow = 1u;
-        }
+        push(sp, wide_ref(refs, k[j]));
       }
       uint32_t next = k[0] == kWideMiss ? kEmptyChild : wide_ref(refs, k[0]);
       for (;;) {
         if (next == kEmptyChild) {
-          if (sp == 0) return hit.slot != kNone;
-          sp--;
-          next = stack[(uint32_t)sp * stride];
+          if (sp == 0) {
+            hit.slot = q_final_code(sc, hit.slot);
+            return hit.slot != kNone;
+          }
+          next = pop(sp);
         }
         if (!(next & kLeafBit)) break;
-        if (leaf_test<MODE, STATS, CURVES>(sc, next, o, d, inv, tmin, best_t, hit, st, any_rt)) return true;
+        if (leaf_test<MODE, STATS, CURVES, true>(sc, next, o, d, inv, tmin, best_t, hit, st, any_rt)) return true;
         next = kEmptyChild;
       }
       cur = next;
@@ -290,12 +332,7 @@ __device__ __forceinline__ bool traverse_mode(const DScene& sc, V3 o, V3 d, floa
     if (h0 && h1) {
       uint32_t nearc = c0, farc = c1;
       if (t1 < t0) nearc = c1, farc = c0;
-      if (sp < kStackDepth) {
-        stack[(uint32_t)sp * stride] = farc;
-        sp++;
-      } else {
-        *overflow = 1u;
-      }
+      push(sp, farc);
       next = nearc;
     } else if (h0) {
       next = c0;
@@ -305,8 +342,7 @@ __device__ __forceinline__ bool traverse_mode(const DScene& sc, V3 o, V3 d, floa
     for (;;) {
       if (next == kEmptyChild) {
         if (sp == 0) return hit.slot != kNone;
-        sp--;
-        next = stack[(uint32_t)sp * stride];
+        next = pop(sp);
       }
       if (!(next & kLeafBit)) break;
       if (leaf_test<MODE, STATS, CURVES>(sc, next, o, d, inv, tmin, best_t, hit, st, any_rt)) return true;
@@ -317,8 +353,9 @@ __device__ __forceinline__ bool traverse_mode(const DScene& sc, V3 o, V3 d, floa
 }
 template <bool ANY, bool STATS, bool CURVES, bool WIDE = false>
 __device__ __forceinline__ bool traverse(const DScene& sc, V3 o, V3 d, float tmin, float tmax, Hit& hit,
-                                         uint32_t* stack, uint32_t stride, TravStats& st, uint32_t* overflow) {
-  return traverse_mode<ANY ? 1 : 0, STATS, CURVES, WIDE>(sc, o, d, tmin, tmax, hit, stack, stride, st, overflow, ANY);
+                                         uint32_t* stack, uint32_t stride, TravStats& st, uint32_t* overflow, uint32_t* spill,
+                                         uint32_t spill_stride) {
+  return traverse_mode<ANY ? 1 : 0, STATS, CURVES, WIDE>(sc, o, d, tmin, tmax, hit, stack, stride, st, overflow, ANY, spill, spill_stride);
 }
 
 }  // namespace pb

@@ -72,8 +72,10 @@ struct SinkSplits<Sink, decltype((void)Sink::kSplit)> { static constexpr bool va
 template <typename Sink>
 __device__ constexpr bool sink_splits() { return SinkSplits<Sink>::value; }
 
-// WIDE: the 4-wide tree (sc.wide: Bvh4Node, dscene.h) instead of the binary one -- half the dependent fetches per ray, twice
-// the box arithmetic per fetch; hit children are visited nearest first (sorted by entry distance), like the binary tree's.
+// WIDE: the Q tree (sc.wide: QNode, dscene.h: four children per 64-byte node with quantised boxes, compact triangle slots,
+// curve pieces as chains of 16-byte points) instead of the binary one -- half the dependent fetches per ray and half the bytes
+// per fetch; hit children are visited nearest first (sorted by entry distance), like the binary tree's.  `cur` then counts
+// 16-byte words of sc.wide instead of 64-byte items.
 template <int MODE, bool STATS, bool CURVES, bool WIDE, typename Sink>
 __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t* head, Sink& sink, uint32_t* stk_base,
                                          uint32_t stride, uint32_t* spill, uint32_t spill_stride, TravStats& st,
@@ -135,12 +137,12 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
   uint32_t rem = 0;  // primitives of the current leaf still to test after the current one
   bool any_ray = (MODE == 1);
   uint32_t cur = 0;  // index of the current 64-byte item (node; TRI/CURVE: num_nodes + slot)
-  float4 D0 = make_float4(0, 0, 0, 0), D1 = D0, D2 = D0;  // prefetched node / primitive slot
+  float4 D0 = make_float4(0, 0, 0, 0), D1 = D0, D2 = D0;  // prefetched node / primitive slot (a curve piece of the Q tree: its two points in D0, D1)
   float2 D3 = make_float2(0, 0);                           // a node's two child references
-  float4 D4 = D0, D5 = D0, D6 = D0, D7 = D0;              // WIDE: D0..D2 / D4..D6 = lower / upper bounds x, y, z of the four children, D7 = their references
-  // items (64 B) of the array the traversal walks: the binary tree's nodes then the slots, or the wide nodes (two items each) then the slots
+  float4 D3w = D0;                                         // WIDE: the four child references of a QNode (D0..D2 = origin, steps, quantised bounds)
+  // the array the traversal walks: the binary tree's nodes then the slots (64-byte items), or the Q tree (16-byte words)
   const float4* const items = WIDE ? sc.wide : reinterpret_cast<const float4*>(sc.nodes);
-  const uint32_t slot0 = WIDE ? 2u * sc.wide_nodes : sc.num_nodes;  // item index of slot 0
+  const uint32_t slot0 = sc.num_nodes;  // binary tree: item index of slot 0
 
   for (;;) {
     // `advance`: the lane needs a new item; `next` is its reference when have_next, else it is popped
@@ -172,6 +174,7 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
       }
       bool fresh = false;  // the lane has a new ray in (o, d, tmin, hit.t)
       uint32_t taken = 0u;  // queue entries handed out in this refill
+      if (WIDE && CURVES && state >= kStDone) hit.slot = q_final_code(sc, hit.slot);  // a curve hit of the Q tree gets its hit code here, with the other lanes' 
       if constexpr (sink_splits<Sink>()) {
         // A splitting sink hands out its loads first and uses them afterwards: what the delivery of the finished rays needs
         // (done_issue) and the queue entries of the new rays (load_entry) are in flight together, one memory round trip
@@ -268,8 +271,8 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
         if (WIDE && state == kStNode) {
           if (STATS) (any_ray ? st.anodes : st.nodes)++, steps++;
           uint32_t k[4];
-          wide_node_keys(D0, D1, D2, D4, D5, D6, o, inv4, tmin, hit.t, k);
-          auto ref_of = [&](uint32_t key) { return wide_ref(D7, key); };
+          wide_node_keys(D0, D1, D2, D3w, o, inv4, tmin, hit.t, k);
+          auto ref_of = [&](uint32_t key) { return wide_ref(D3w, key); };
           advance = true;
           have_next = k[0] != kWideMiss;
           next = ref_of(k[0]);
@@ -339,17 +342,22 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
             RayFrame f;
             f.dn = V3(frame[0], frame[stride], frame[2 * stride]), f.bx = V3(frame[3 * stride], frame[4 * stride], frame[5 * stride]);
             f.by = V3(frame[6 * stride], frame[7 * stride], frame[8 * stride]), f.inv_len = frame[9 * stride];
-            ok = segment_test(D0, D1, __float_as_uint(D2.x), o, f, WIDE ? V3(inv4.x, inv4.y, inv4.z) : inv, tmin, hit.t, t, u, v);
+            ok = segment_test(D0, D1, WIDE ? ((cur - sc.q_pt0) & 3u) : __float_as_uint(D2.x), o, f, WIDE ? V3(inv4.x, inv4.y, inv4.z) : inv, tmin,
+                              hit.t, t, u, v);
           }
-          if (ok && !any_ray && t == hit.t && hit.slot != kNone) ok = sc.shade[cur - slot0].gid < sc.shade[hit.slot & kHitSlotMask].gid;
+          // the hit code: slot + routing bits (dscene.h); Q tree: a triangle slot carries its code, a curve hit is held as its point
+          const uint32_t code = !WIDE ? ((cur - slot0) | __float_as_uint(D2.w))
+                                      : ((CURVES && is_curve) ? (kQPointHit | (cur - sc.q_pt0)) : __float_as_uint(D2.w));
+          if (ok && !any_ray && t == hit.t && hit.slot != kNone)
+            ok = WIDE ? q_gid(sc, code) < q_gid(sc, hit.slot) : sc.shade[cur - slot0].gid < sc.shade[hit.slot & kHitSlotMask].gid;
           if (ok) {
-            hit.t = t, hit.u = u, hit.v = v, hit.slot = (cur - slot0) | __float_as_uint(D2.w);  // + routing bits (dscene.h)
+            hit.t = t, hit.u = u, hit.v = v, hit.slot = code;
           }
           if (any_ray && ok) {
             state = kStDoneOccluded;
             if (STATS) st.ahist[steps <= 16u ? 0 : (28 - __clz(steps - 1u) > 7 ? 7 : 28 - __clz(steps - 1u))]++, st.amax_steps = steps > st.amax_steps ? steps : st.amax_steps;
           } else if (rem != 0u) {  // next primitive of the same leaf
-            rem--, cur++;
+            rem--, cur += WIDE ? ((CURVES && is_curve) ? 1u : 4u) : 1u;
             need_load = true;
           } else {
             advance = true;  // leaf done: pop
@@ -379,19 +387,22 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
       if (advance) {
         need_load = true;
         if (next & kLeafBit) {
-          cur = ((next & 0x3FFFFFFFu) >> 3) + slot0;  // slots follow the nodes in one array of 64-byte items
+          const uint32_t first = (next & 0x3FFFFFFFu) >> 3;
           rem = next & 7u;
           state = (CURVES && (next & kCurveBit)) ? kStCurve : kStTri;
+          if (WIDE) cur = (CURVES && (next & kCurveBit)) ? sc.q_pt0 + first : sc.q_tri0 + 4u * first;
+          else cur = first + slot0;  // slots follow the nodes in one array of 64-byte items
         } else {
-          cur = next;
+          cur = WIDE ? 4u * next : next;
           state = kStNode;
         }
       }
     }
     if (WIDE && need_load) {
-      const float4* g = items + (size_t)cur * 4u;
-      D0 = g[0], D1 = g[1], D2 = g[2];
-      if (state == kStNode) D4 = g[3], D5 = g[4], D6 = g[5], D7 = g[6];
+      const float4* g = items + cur;
+      D0 = g[0], D1 = g[1];
+      if (!CURVES || state != kStCurve) D2 = g[2];
+      if (state == kStNode) D3w = g[3];
     } else if (need_load) {
       if (kTopNodes > 0 && cur < ntop) {  // the top of the tree: every ray passes through it
         const float4* g = top + cur * 4u;
@@ -405,7 +416,10 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
     }
   }
   if constexpr (!Sink::kWalk) {
-    if (state >= kStDone) sink.done(tag, hit, state == kStDoneOccluded);  // rays that finished after the queue ran dry
+    if (state >= kStDone) {  // rays that finished after the queue ran dry
+      if (WIDE && CURVES) hit.slot = q_final_code(sc, hit.slot);
+      sink.done(tag, hit, state == kStDoneOccluded);
+    }
   }
 }
 

@@ -5,6 +5,7 @@
 
 #include <stdint.h>
 
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -71,10 +72,18 @@ struct FlatBvh {
 void build_bvh(const std::vector<float>& lo, const std::vector<float>& hi, const std::vector<uint8_t>& kinds,
                FlatBvh* out);
 
-// The binary tree collapsed to four children per node (dscene.h::Bvh4Node): a node takes its two children and, while it has
-// room, replaces the inner child of largest surface area by that child's two children.  Returns the stack depth a
-// near-first traversal of the wide tree can need (three pushes per level).
-uint32_t collapse_bvh4(const std::vector<BvhNode>& nodes, std::vector<Bvh4Node>* out);
+// The binary tree collapsed to four children per node with quantised boxes (dscene.h::QNode): a node takes its two
+// children and, while it has room, replaces the inner child of largest surface area by that child's two children.
+// map_leaf turns a leaf reference of the binary tree into one or two children of the Q tree (its references use the Q
+// tree's own triangle slots and curve points; a curve leaf whose two pieces are not neighbours in a chain becomes two):
+// it fills ref / lo / hi (boxes as stored in the binary tree: already widened) and returns the count.
+// Returns the stack depth a near-first traversal of the Q tree can need (three pushes per level).
+struct QChild {
+  uint32_t ref;
+  float lo[3], hi[3];
+};
+uint32_t build_qtree(const std::vector<BvhNode>& nodes, const std::function<int(uint32_t, const float*, const float*, QChild*)>& map_leaf,
+                     std::vector<QNode>* out);
 
 // The same tree format built on the GPU (bvh_gpu.hip: Morton-order linear BVH).  nodes_out: DEVICE array of
 // max(n - 1, 1) nodes; order_out: slot -> primitive index; depth_out: traversal stack depth needed.

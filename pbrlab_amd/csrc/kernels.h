@@ -68,10 +68,16 @@ enum : uint32_t {
 #define PB_TRACE_BLOCKS_CURVES 6
 #endif
 #ifndef PB_TRACE_BLOCKS_WIDE
-#define PB_TRACE_BLOCKS_WIDE 5
+#define PB_TRACE_BLOCKS_WIDE 6
 #endif
-constexpr uint32_t kTraceBlocksPerCUWide = PB_TRACE_BLOCKS_WIDE;  // the 4-wide tree's kernel holds a 128-byte node in registers
+#ifndef PB_TRACE_BLOCKS_WIDE_CURVES
+#define PB_TRACE_BLOCKS_WIDE_CURVES 6
+#endif
+constexpr uint32_t kTraceBlocksPerCUWide = PB_TRACE_BLOCKS_WIDE, kTraceBlocksPerCUWideCurves = PB_TRACE_BLOCKS_WIDE_CURVES;  // the Q tree's kernels
 constexpr uint32_t kTraceBlocksPerCU = PB_TRACE_BLOCKS, kTraceBlocksPerCUCurves = PB_TRACE_BLOCKS_CURVES;
+constexpr uint32_t trace_blocks_per_cu(bool curves, bool wide) {
+  return wide ? (curves ? kTraceBlocksPerCUWideCurves : kTraceBlocksPerCUWide) : (curves ? kTraceBlocksPerCUCurves : kTraceBlocksPerCU);
+}
 constexpr uint32_t kTraceGridCap = 256 * (kTraceBlocksPerCU > kTraceBlocksPerCUCurves ? kTraceBlocksPerCU : kTraceBlocksPerCUCurves);  // persistent traversal: at most the resident blocks (sizes the spill area)
 constexpr uint32_t kShadeGridCap = 256 * 8;
 constexpr int kMaxGroups = 8;

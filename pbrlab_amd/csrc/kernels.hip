@@ -153,7 +153,7 @@ struct TraceSinkT {
 using TraceSink = TraceSinkT<false>;
 
 template <bool STATS, bool CURVES, bool WIDE = false>
-__global__ __launch_bounds__(kBlock, (WIDE ? kTraceBlocksPerCUWide : (CURVES ? kTraceBlocksPerCUCurves : kTraceBlocksPerCU))) void k_trace(PathState P, DScene sc) {
+__global__ __launch_bounds__(kBlock, trace_blocks_per_cu(CURVES, WIDE)) void k_trace(PathState P, DScene sc) {
   __shared__ uint32_t stk[kPvLdsStack * kBlock];
   __shared__ float frm[CURVES ? 10 * kBlock : 1];
   // the top of the tree in LDS (triangle-only scenes: with the ribbon frames of curve scenes it would cost a block per CU)
@@ -1054,9 +1054,11 @@ __global__ __launch_bounds__(kBlock, PB_WALK_WAVES) void k_sss_walk(PathState P,
 #define PB_TAIL_WAVES 3  // min waves per SIMD of k_tail (<= 168 VGPRs: three blocks per CU hold 196 k lanes, so every path of a 256 Ki tail starts at once;
                          // A/B on C2: 2 -> 59.1 ms per frame / 12.1 ms for an eighth, 3 -> 58.6 / 11.8)
 #endif
-template <bool CURVES, bool STATS, bool WIDE = false>
+template <bool STATS, bool CURVES, bool WIDE = false>
 __global__ __launch_bounds__(kBlock, PB_TAIL_WAVES) void k_tail(PathState P, DScene sc, uint64_t rng_inc) {
-  __shared__ uint32_t stk[kStackDepth * kBlock];
+  __shared__ uint32_t stk[kSimpleLdsStack * kBlock];
+  uint32_t* const spill = P.spill + blockIdx.x * kBlock + threadIdx.x;  // stack entries beyond the LDS part (the group's spill area: this grid is smaller than k_trace's)
+  const uint32_t spill_stride = gridDim.x * kBlock;
   const uint32_t n = P.counts[kCntIn];
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, nwaves = gridDim.x * (kBlock >> 6);
@@ -1106,14 +1108,14 @@ __global__ __launch_bounds__(kBlock, PB_TAIL_WAVES) void k_tail(PathState P, DSc
         if (want_shadow) {
           const float4 o4 = P.ray_o[p], d4 = P.sh_d[p];
           Hit h;
-          const bool occluded = traverse<true, false, CURVES, WIDE>(sc, ld3(o4), ld3(d4), o4.w, d4.w, h, stack, kBlock, st, &overflow);
+          const bool occluded = traverse<true, false, CURVES, WIDE>(sc, ld3(o4), ld3(d4), o4.w, d4.w, h, stack, kBlock, st, &overflow, spill, spill_stride);
           sink.done(p | 0x80000000u, h, occluded);
           n_shadow++;
         }
         if (want_closest) {
           const float4 o4 = P.ray_o[p], d4 = P.ray_d[p];
           Hit h;
-          traverse<false, false, CURVES, WIDE>(sc, ld3(o4), ld3(d4), o4.w, d4.w, h, stack, kBlock, st, &overflow);
+          traverse<false, false, CURVES, WIDE>(sc, ld3(o4), ld3(d4), o4.w, d4.w, h, stack, kBlock, st, &overflow, spill, spill_stride);
           P.hit[p] = make_float4(h.t, h.u, h.v, __uint_as_float(h.slot));
           n_closest++;
         }
@@ -1132,7 +1134,7 @@ __global__ __launch_bounds__(kBlock, PB_TAIL_WAVES) void k_tail(PathState P, DSc
         if (odd) o4 = make_float4(ox, oy, oz, ow), d4 = make_float4(sx, sy, sz, sw), go = left_shadow;
         Hit h = {0.f, 0.f, 0.f, kNone};
         bool occluded = false;
-        if (go) occluded = traverse_mode<2, false, CURVES, WIDE>(sc, ld3(o4), ld3(d4), o4.w, d4.w, h, stack, kBlock, st, &overflow, odd);
+        if (go) occluded = traverse_mode<2, false, CURVES, WIDE>(sc, ld3(o4), ld3(d4), o4.w, d4.w, h, stack, kBlock, st, &overflow, odd, spill, spill_stride);
         const bool occ_right = __shfl((int)occluded, (int)(lane | 1u)) != 0;
         if (want_shadow) {
           Hit none = {0.f, 0.f, 0.f, kNone};
@@ -1231,45 +1233,46 @@ struct HookSink {
     else hits[i] = hook_result(sc, ld3(rays[2 * i]), ld3(rays[2 * i + 1]), h);
   }
 };
-template <bool ANY, bool WIDE>  // WIDE: the 4-wide tree (triangle-only scenes), as k_trace uses it
+template <bool ANY, bool CURVES, bool WIDE>  // CURVES / WIDE: the variant k_trace runs for this scene (the Q tree, with or without curves)
 __global__ __launch_bounds__(kBlock) void k_hook_pv(DScene sc, const float4* __restrict__ rays, uint32_t n, HookHit* hits,
                                                     uint8_t* occ, uint32_t* counts, uint32_t* spill) {
   __shared__ uint32_t stk[kPvLdsStack * kBlock];
-  __shared__ float frm[WIDE ? 1 : 10 * kBlock];
+  __shared__ float frm[CURVES ? 10 * kBlock : 1];
   TravStats st = {};
   uint32_t overflow = 0u;
   HookSink sink = {sc, rays, hits, occ};
-  trace_pv<ANY ? 1 : 0, false, !WIDE, WIDE>(sc, n, &counts[kCntHead], sink, stk + threadIdx.x, kBlock,
-                             spill + blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, st, &overflow, WIDE ? nullptr : frm + threadIdx.x);
+  trace_pv<ANY ? 1 : 0, false, CURVES, WIDE>(sc, n, &counts[kCntHead], sink, stk + threadIdx.x, kBlock,
+                             spill + blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, st, &overflow, CURVES ? frm + threadIdx.x : nullptr);
   if (overflow) counts[kCntOverflow] = 1u;
 }
 // One ray per thread, plain stack traversal (dtrace.h): an independent second implementation, selected with
 // PBRHIP_SIMPLE_TRAVERSAL=1, that must agree with the production traversal bit for bit.
-template <bool WIDE>
+template <bool CURVES, bool WIDE>
 __global__ __launch_bounds__(kBlock) void k_hook_closest(DScene sc, const float4* __restrict__ rays, uint32_t n,
-                                                         HookHit* __restrict__ out, uint32_t* overflow_flag) {
-  __shared__ uint32_t stk[kStackDepth * kBlock];
+                                                         HookHit* __restrict__ out, uint32_t* overflow_flag, uint32_t* spill) {
+  __shared__ uint32_t stk[kSimpleLdsStack * kBlock];
   TravStats st = {};
   uint32_t overflow = 0u;
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
     float4 o4 = rays[2 * i], d4 = rays[2 * i + 1];
     Hit h;
-    traverse<false, false, !WIDE, WIDE>(sc, ld3(o4), ld3(d4), o4.w, fminf(d4.w, INFINITY), h, stk + threadIdx.x, kBlock, st, &overflow);
+    traverse<false, false, CURVES, WIDE>(sc, ld3(o4), ld3(d4), o4.w, fminf(d4.w, INFINITY), h, stk + threadIdx.x, kBlock, st, &overflow,
+                                         spill + blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock);
     out[i] = hook_result(sc, ld3(o4), ld3(d4), h);
   }
   if (overflow) *overflow_flag = 1u;
 }
-template <bool WIDE>
+template <bool CURVES, bool WIDE>
 __global__ __launch_bounds__(kBlock) void k_hook_any(DScene sc, const float4* __restrict__ rays, uint32_t n,
-                                                     uint8_t* __restrict__ out, uint32_t* overflow_flag) {
-  __shared__ uint32_t stk[kStackDepth * kBlock];
+                                                     uint8_t* __restrict__ out, uint32_t* overflow_flag, uint32_t* spill) {
+  __shared__ uint32_t stk[kSimpleLdsStack * kBlock];
   TravStats st = {};
   uint32_t overflow = 0u;
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
     float4 o4 = rays[2 * i], d4 = rays[2 * i + 1];
     Hit h;
-    out[i] = traverse<true, false, !WIDE, WIDE>(sc, ld3(o4), ld3(d4), o4.w, fminf(d4.w, INFINITY), h, stk + threadIdx.x, kBlock, st,
-                                                &overflow)
+    out[i] = traverse<true, false, CURVES, WIDE>(sc, ld3(o4), ld3(d4), o4.w, fminf(d4.w, INFINITY), h, stk + threadIdx.x, kBlock, st,
+                                                 &overflow, spill + blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock)
                  ? 1
                  : 0;
   }
@@ -1287,11 +1290,19 @@ __global__ void k_advance(uint32_t* counts) {
 }
 
 // ------------------------------------------------------------------ launchers
-// the 4-wide tree serves triangle-only scenes whose tree was built on the host (PBRHIP_WIDE=0: never; read per launch)
+// the Q tree serves the scenes whose tree was built on the host (PBRHIP_WIDE=0: never; read per launch)
 static inline bool use_wide(const DScene& sc) {
   const char* e = getenv("PBRHIP_WIDE");
-  return sc.wide != nullptr && sc.num_curves == 0 && !(e && atoi(e) == 0);
+  return sc.wide != nullptr && !(e && atoi(e) == 0);
 }
+// launches KERNEL<..., CURVES, WIDE> for this scene: (curves, binary), (no curves, binary), (curves, Q), (no curves, Q)
+#define PB_LAUNCH_TRAV(KERNEL, PRE, curves, wide, ...)                                          \
+  do {                                                                                          \
+    if ((wide) && (curves)) hipLaunchKernelGGL((KERNEL<PRE, true, true>), __VA_ARGS__);         \
+    else if (wide) hipLaunchKernelGGL((KERNEL<PRE, false, true>), __VA_ARGS__);                 \
+    else if (curves) hipLaunchKernelGGL((KERNEL<PRE, true, false>), __VA_ARGS__);               \
+    else hipLaunchKernelGGL((KERNEL<PRE, false, false>), __VA_ARGS__);                          \
+  } while (0)
 bool trace_uses_wide(const DScene& sc) { return use_wide(sc); }
 static inline uint32_t grid_for(uint32_t n, uint32_t cap) {
   uint32_t g = (n + kBlock - 1) / kBlock;
@@ -1312,16 +1323,12 @@ void launch_trace(hipStream_t s, const PathState& P, const DScene& sc, uint32_t 
   const char* e = getenv("PBRHIP_RAYS_PER_WAVE");  // (tuning knob; read per launch)
   const uint32_t rays_per_wave = e ? (uint32_t)strtoul(e, nullptr, 10) : 4u;
   uint32_t blocks = (n_upper + 4u * rays_per_wave - 1u) / (4u * rays_per_wave);
-  const bool curves = sc.num_curves != 0;
+  const bool curves = sc.num_curves != 0 || getenv("PBRHIP_FORCE_CURVES") != nullptr;
   const bool wide = use_wide(sc);
-  const uint32_t cap = 256u * (wide ? kTraceBlocksPerCUWide : (curves ? kTraceBlocksPerCUCurves : kTraceBlocksPerCU));
+  const uint32_t cap = 256u * trace_blocks_per_cu(curves, wide);
   dim3 g(blocks < 1u ? 1u : (blocks < cap ? blocks : cap));
-  if (wide && stats) hipLaunchKernelGGL((k_trace<true, false, true>), g, dim3(kBlock), 0, s, P, sc);
-  else if (wide) hipLaunchKernelGGL((k_trace<false, false, true>), g, dim3(kBlock), 0, s, P, sc);
-  else if (stats && curves) hipLaunchKernelGGL((k_trace<true, true>), g, dim3(kBlock), 0, s, P, sc);
-  else if (stats) hipLaunchKernelGGL((k_trace<true, false>), g, dim3(kBlock), 0, s, P, sc);
-  else if (curves) hipLaunchKernelGGL((k_trace<false, true>), g, dim3(kBlock), 0, s, P, sc);
-  else hipLaunchKernelGGL((k_trace<false, false>), g, dim3(kBlock), 0, s, P, sc);
+  if (stats) PB_LAUNCH_TRAV(k_trace, true, curves, wide, g, dim3(kBlock), 0, s, P, sc);
+  else PB_LAUNCH_TRAV(k_trace, false, curves, wide, g, dim3(kBlock), 0, s, P, sc);
 }
 static inline uint32_t tiles_grid(uint32_t n_upper, int items_per_thread) {
   const uint32_t tile = (uint32_t)items_per_thread * kBlock;
@@ -1351,12 +1358,8 @@ void launch_sss_walk(hipStream_t s, const PathState& P, const DScene& sc, uint32
   const bool curves = sc.num_curves != 0;
   const char* ww = getenv("PBRHIP_WIDE_WALK");
   const bool wide = use_wide(sc) && !(ww && atoi(ww) == 0);
-  if (wide && stats) hipLaunchKernelGGL((k_sss_walk<true, false, true>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
-  else if (wide) hipLaunchKernelGGL((k_sss_walk<false, false, true>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
-  else if (stats && curves) hipLaunchKernelGGL((k_sss_walk<true, true>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
-  else if (stats) hipLaunchKernelGGL((k_sss_walk<true, false>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
-  else if (curves) hipLaunchKernelGGL((k_sss_walk<false, true>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
-  else hipLaunchKernelGGL((k_sss_walk<false, false>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
+  if (stats) PB_LAUNCH_TRAV(k_sss_walk, true, curves, wide, g, dim3(kBlock), 0, s, P, sc, rng_inc);
+  else PB_LAUNCH_TRAV(k_sss_walk, false, curves, wide, g, dim3(kBlock), 0, s, P, sc, rng_inc);
 }
 void launch_accumulate(hipStream_t s, const PathState& P, const uint32_t* pix_index, uint32_t npix, uint32_t npass,
                        float* rgba, uint32_t* count) {
@@ -1369,12 +1372,9 @@ void launch_tail(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n
   uint32_t blocks = (n_upper + 3u) / 4u;  // one path per wave while that fits, at most 2 blocks per CU
   dim3 g(blocks < 1u ? 1u : (blocks < PB_TAIL_BLOCKS ? blocks : PB_TAIL_BLOCKS));
   const bool curves = sc.num_curves != 0;
-  if (use_wide(sc) && stats) hipLaunchKernelGGL((k_tail<false, true, true>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
-  else if (use_wide(sc)) hipLaunchKernelGGL((k_tail<false, false, true>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
-  else if (stats && curves) hipLaunchKernelGGL((k_tail<true, true>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
-  else if (stats) hipLaunchKernelGGL((k_tail<false, true>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
-  else if (curves) hipLaunchKernelGGL((k_tail<true, false>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
-  else hipLaunchKernelGGL((k_tail<false, false>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
+  const bool wide = use_wide(sc);
+  if (stats) PB_LAUNCH_TRAV(k_tail, true, curves, wide, g, dim3(kBlock), 0, s, P, sc, rng_inc);
+  else PB_LAUNCH_TRAV(k_tail, false, curves, wide, g, dim3(kBlock), 0, s, P, sc, rng_inc);
 }
 void launch_layer_pack(hipStream_t s, const uint32_t* pix, uint32_t npix, const float* rgba, const uint32_t* count, float* shard) {
   if (!npix) return;
@@ -1391,31 +1391,32 @@ void launch_advance(hipStream_t s, const PathState& P) { hipLaunchKernelGGL(k_ad
 // counts: kCntNum zeroed words (queue head + overflow flag); spill: traversal-stack spill area
 void launch_hook_closest(hipStream_t s, const DScene& sc, const float4* rays, uint32_t n, HookHit* out, uint32_t* counts,
                          uint32_t* spill, bool simple) {
-  const bool wide = use_wide(sc);
-  if (simple && wide)
-    hipLaunchKernelGGL(k_hook_closest<true>, dim3(grid_for(n, 4096)), dim3(kBlock), 0, s, sc, rays, n, out, counts + kCntOverflow);
-  else if (simple)
-    hipLaunchKernelGGL(k_hook_closest<false>, dim3(grid_for(n, 4096)), dim3(kBlock), 0, s, sc, rays, n, out, counts + kCntOverflow);
-  else if (wide)
-    hipLaunchKernelGGL((k_hook_pv<false, true>), dim3(grid_for(n, kTraceGridCap)), dim3(kBlock), 0, s, sc, rays, n, out,
-                       (uint8_t*)nullptr, counts, spill);
-  else
-    hipLaunchKernelGGL((k_hook_pv<false, false>), dim3(grid_for(n, kTraceGridCap)), dim3(kBlock), 0, s, sc, rays, n, out,
-                       (uint8_t*)nullptr, counts, spill);
+  // the variant of the traversal the render of this scene runs; the binary tree's hooks always carry the curve code
+  const bool wide = use_wide(sc), curves = !wide || sc.num_curves != 0;
+  if (simple) {
+    if (wide && curves) hipLaunchKernelGGL((k_hook_closest<true, true>), dim3(grid_for(n, 4096)), dim3(kBlock), 0, s, sc, rays, n, out, counts + kCntOverflow, spill);
+    else if (wide) hipLaunchKernelGGL((k_hook_closest<false, true>), dim3(grid_for(n, 4096)), dim3(kBlock), 0, s, sc, rays, n, out, counts + kCntOverflow, spill);
+    else hipLaunchKernelGGL((k_hook_closest<true, false>), dim3(grid_for(n, 4096)), dim3(kBlock), 0, s, sc, rays, n, out, counts + kCntOverflow, spill);
+    return;
+  }
+  const dim3 g(grid_for(n, kTraceGridCap));
+  if (wide && curves) hipLaunchKernelGGL((k_hook_pv<false, true, true>), g, dim3(kBlock), 0, s, sc, rays, n, out, (uint8_t*)nullptr, counts, spill);
+  else if (wide) hipLaunchKernelGGL((k_hook_pv<false, false, true>), g, dim3(kBlock), 0, s, sc, rays, n, out, (uint8_t*)nullptr, counts, spill);
+  else hipLaunchKernelGGL((k_hook_pv<false, true, false>), g, dim3(kBlock), 0, s, sc, rays, n, out, (uint8_t*)nullptr, counts, spill);
 }
 void launch_hook_any(hipStream_t s, const DScene& sc, const float4* rays, uint32_t n, uint8_t* out, uint32_t* counts,
                      uint32_t* spill, bool simple) {
-  const bool wide = use_wide(sc);
-  if (simple && wide)
-    hipLaunchKernelGGL(k_hook_any<true>, dim3(grid_for(n, 4096)), dim3(kBlock), 0, s, sc, rays, n, out, counts + kCntOverflow);
-  else if (simple)
-    hipLaunchKernelGGL(k_hook_any<false>, dim3(grid_for(n, 4096)), dim3(kBlock), 0, s, sc, rays, n, out, counts + kCntOverflow);
-  else if (wide)
-    hipLaunchKernelGGL((k_hook_pv<true, true>), dim3(grid_for(n, kTraceGridCap)), dim3(kBlock), 0, s, sc, rays, n,
-                       (HookHit*)nullptr, out, counts, spill);
-  else
-    hipLaunchKernelGGL((k_hook_pv<true, false>), dim3(grid_for(n, kTraceGridCap)), dim3(kBlock), 0, s, sc, rays, n,
-                       (HookHit*)nullptr, out, counts, spill);
+  const bool wide = use_wide(sc), curves = !wide || sc.num_curves != 0;
+  if (simple) {
+    if (wide && curves) hipLaunchKernelGGL((k_hook_any<true, true>), dim3(grid_for(n, 4096)), dim3(kBlock), 0, s, sc, rays, n, out, counts + kCntOverflow, spill);
+    else if (wide) hipLaunchKernelGGL((k_hook_any<false, true>), dim3(grid_for(n, 4096)), dim3(kBlock), 0, s, sc, rays, n, out, counts + kCntOverflow, spill);
+    else hipLaunchKernelGGL((k_hook_any<true, false>), dim3(grid_for(n, 4096)), dim3(kBlock), 0, s, sc, rays, n, out, counts + kCntOverflow, spill);
+    return;
+  }
+  const dim3 g(grid_for(n, kTraceGridCap));
+  if (wide && curves) hipLaunchKernelGGL((k_hook_pv<true, true, true>), g, dim3(kBlock), 0, s, sc, rays, n, (HookHit*)nullptr, out, counts, spill);
+  else if (wide) hipLaunchKernelGGL((k_hook_pv<true, false, true>), g, dim3(kBlock), 0, s, sc, rays, n, (HookHit*)nullptr, out, counts, spill);
+  else hipLaunchKernelGGL((k_hook_pv<true, true, false>), g, dim3(kBlock), 0, s, sc, rays, n, (HookHit*)nullptr, out, counts, spill);
 }
 
 }  // namespace pb

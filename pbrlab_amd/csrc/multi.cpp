@@ -271,6 +271,7 @@ extern "C" int pbrhip_scene_replicate(const pbrhip_scene* src, int device, pbrhi
     }
     if (int r = copy_buf(s->d_nodes, device, src->d_nodes, src->device)) return r;
     if (int r = copy_buf(s->d_wide, device, src->d_wide, src->device)) return r;
+    if (int r = copy_buf(s->d_qhit, device, src->d_qhit, src->device)) return r;
     if (int r = copy_buf(s->d_shade, device, src->d_shade, src->device)) return r;
     if (int r = copy_buf(s->d_materials, device, src->d_materials, src->device)) return r;
     if (int r = copy_buf(s->d_light_cdf, device, src->d_light_cdf, src->device)) return r;
@@ -285,6 +286,7 @@ extern "C" int pbrhip_scene_replicate(const pbrhip_scene* src, int device, pbrhi
     dd = src->dscene;
     dd.nodes = s->d_nodes.p, dd.slots = reinterpret_cast<const float4*>(s->d_nodes.p + dd.num_nodes), dd.shade = s->d_shade.p;
     dd.wide = src->dscene.wide ? s->d_wide.p : nullptr;
+    dd.q_hitcode = src->dscene.wide ? s->d_qhit.p : nullptr;
     dd.materials = s->d_materials.p, dd.light_cdf = s->d_light_cdf.p, dd.light_heads = s->d_heads.p;
     dd.lprim_cdf = s->d_lprim_cdf.p, dd.lrecs = s->d_lrecs.p, dd.light_boxes = s->d_light_boxes.p;
     dd.tex_pixels = s->d_tex_pixels.p, dd.textures = s->d_tex_descs.p;

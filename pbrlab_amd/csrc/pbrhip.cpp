@@ -640,21 +640,88 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
     if (num_nodes) HIPCHK(hipMemcpyAsync(s->d_nodes.p, bvh.nodes.data(), (size_t)num_nodes * sizeof(BvhNode), hipMemcpyHostToDevice, st));
   }
   if (ns) HIPCHK(hipMemcpyAsync(s->d_nodes.p + num_nodes, slots.data(), (size_t)ns * 64, hipMemcpyHostToDevice, st));
-  // the 4-wide tree of the traversal kernels (triangle-only scenes with a host-built tree; PBRHIP_WIDE=0 at commit: none),
-  // followed by its own copy of the slots
-  std::vector<Bvh4Node> wide;
+  // The Q tree of the traversal kernels (host-built trees; PBRHIP_WIDE=0 at commit: none): the binary tree collapsed to four
+  // children per node with quantised boxes (64 B per node), followed by its own compact triangle slots and by the curve
+  // pieces stored as chains of points (16 B per piece instead of a 64-byte slot): dscene.h::QNode.
+  std::vector<QNode> wide;
+  std::vector<float4> qtri, qpts;
+  std::vector<uint32_t> qhit;
   const char* wide_env = getenv("PBRHIP_WIDE");
-  bool any_curve = false;
-  for (uint8_t kd : kinds) any_curve = any_curve || kd != 0;
-  if (!gpu_built && num_nodes && !any_curve && !(wide_env && atoi(wide_env) == 0)) {  // (scenes with curves keep the binary tree: DESIGN.md section 3)
-    if (collapse_bvh4(bvh.nodes, &wide) > (uint32_t)kStackDepth) wide.clear();
+  static_assert(kMaxLeaf <= 2, "build_qtree expects at most two primitives per leaf of the binary tree");
+  if (!gpu_built && num_nodes && !(wide_env && atoi(wide_env) == 0)) {
+    // points: the cubics in canonical order; a cubic whose first point equals the last point of its predecessor (same mesh,
+    // bit for bit: the segments of a strand) continues that chain, otherwise a new chain starts at the next multiple of 4
+    std::vector<uint32_t> piece_point(np, kNone);
+    {
+      uint32_t prev_inst = kNone, prev_geom = kNone;
+      for (uint32_t g = 0; g < np; g++) {
+        const PrimRef& pr = prims[g];
+        if (pr.kind != 1 || pr.sub != 0) continue;
+        float wcps[16], pt[5][4];
+        world_curve(s->instances[pr.instance_id], *inst_mesh(s, pr.instance_id, pr.geom_id), pr.prim_id, wcps);
+        for (int j = 0; j < 5; j++) bezier_point(wcps, (float)j * 0.25f, pt[j]);
+        const bool chained = !qpts.empty() && pr.instance_id == prev_inst && pr.geom_id == prev_geom &&
+                             memcmp(&qpts.back(), pt[0], 16) == 0;
+        if (!chained) {
+          while (qpts.size() % 4) qpts.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
+          qpts.push_back(make_float4(pt[0][0], pt[0][1], pt[0][2], pt[0][3]));
+        }
+        const uint32_t start = (uint32_t)qpts.size() - 1u;  // index of this cubic's first point (a multiple of 4)
+        for (int j = 1; j < 5; j++) qpts.push_back(make_float4(pt[j][0], pt[j][1], pt[j][2], pt[j][3]));
+        for (uint32_t sub = 0; sub < 4; sub++) piece_point[g + sub] = start + sub;  // (the four pieces of a cubic are consecutive gids)
+        prev_inst = pr.instance_id, prev_geom = pr.geom_id;
+      }
+      for (int k = 0; k < 4; k++) qpts.push_back(make_float4(0.f, 0.f, 0.f, 0.f));  // (the last piece reads point p + 1)
+    }
+    // compact triangle slots (.w of the third word = the complete hit code) and the per-point hit codes
+    std::vector<uint32_t> tri_rank(ns, 0);
+    qhit.assign(qpts.size(), kNone);
+    for (uint32_t k = 0; k < ns; k++) {
+      const uint32_t g = bvh.slot_gid[k];
+      const uint32_t code = k | __builtin_bit_cast(uint32_t, slots[4 * (size_t)k + 2].w);
+      if (prims[g].kind == 0) {
+        tri_rank[k] = (uint32_t)(qtri.size() / 4);
+        for (int c = 0; c < 4; c++) qtri.push_back(slots[4 * (size_t)k + c]);
+        qtri.back() = make_float4(0.f, 0.f, 0.f, 0.f);
+        qtri[qtri.size() - 2].w = __builtin_bit_cast(float, code);
+      } else {
+        qhit[piece_point[g]] = code;
+      }
+    }
+    auto map_leaf = [&](uint32_t ref, const float* blo, const float* bhi, QChild* o) -> int {
+      const uint32_t first = (ref & 0x3FFFFFFFu) >> 3, count = (ref & 7u) + 1u;
+      if (!(ref & kCurveBit)) {
+        o[0].ref = kLeafBit | (tri_rank[first] << 3) | (count - 1u);
+        for (int a = 0; a < 3; a++) o[0].lo[a] = blo[a], o[0].hi[a] = bhi[a];
+        return 1;
+      }
+      uint32_t p0 = piece_point[bvh.slot_gid[first]];
+      if (count == 2) {
+        uint32_t p1 = piece_point[bvh.slot_gid[first + 1]];
+        if ((p0 > p1 ? p0 - p1 : p1 - p0) != 1u) {  // not neighbours in a chain: two leaves, each with its own (widened) box
+          for (uint32_t i = 0; i < 2; i++) {
+            const uint32_t g = bvh.slot_gid[first + i];
+            o[i].ref = kLeafBit | kCurveBit | (piece_point[g] << 3);
+            for (int a = 0; a < 3; a++) o[i].lo[a] = BvhNode::widen_lo(lo[3 * (size_t)g + a]), o[i].hi[a] = BvhNode::widen_hi(hi[3 * (size_t)g + a]);
+          }
+          return 2;
+        }
+        p0 = std::min(p0, p1);
+      }
+      o[0].ref = kLeafBit | kCurveBit | (p0 << 3) | (count - 1u);
+      for (int a = 0; a < 3; a++) o[0].lo[a] = blo[a], o[0].hi[a] = bhi[a];
+      return 1;
+    };
+    if (qpts.size() >= (1u << 27) || build_qtree(bvh.nodes, map_leaf, &wide) > (uint32_t)kStackDepth) wide.clear();
   }
-  if (wide.empty()) s->d_wide.release();
-  if (getenv("PBRHIP_DEBUG")) fprintf(stderr, "pbrhip: commit: %u binary nodes, %zu wide nodes, %zu slots\n", num_nodes, wide.size(), (size_t)ns);
+  if (wide.empty()) s->d_wide.release(), s->d_qhit.release();
+  if (getenv("PBRHIP_DEBUG")) fprintf(stderr, "pbrhip: commit: %u binary nodes, %zu wide nodes, %zu slots, %zu triangle slots + %zu points in the Q tree\n", num_nodes, wide.size(), (size_t)ns, qtri.size() / 4, qpts.size());
   if (!wide.empty()) {
-    HIPCHK(s->d_wide.reserve(((size_t)wide.size() * 2 + ns) * 4));
-    HIPCHK(hipMemcpyAsync(s->d_wide.p, wide.data(), wide.size() * sizeof(Bvh4Node), hipMemcpyHostToDevice, st));
-    if (ns) HIPCHK(hipMemcpyAsync(s->d_wide.p + wide.size() * 8, slots.data(), (size_t)ns * 64, hipMemcpyHostToDevice, st));
+    HIPCHK(s->d_wide.reserve(wide.size() * 4 + qtri.size() + qpts.size()));
+    HIPCHK(hipMemcpyAsync(s->d_wide.p, wide.data(), wide.size() * sizeof(QNode), hipMemcpyHostToDevice, st));
+    if (!qtri.empty()) HIPCHK(hipMemcpyAsync(s->d_wide.p + wide.size() * 4, qtri.data(), qtri.size() * 16, hipMemcpyHostToDevice, st));
+    if (!qpts.empty()) HIPCHK(hipMemcpyAsync(s->d_wide.p + wide.size() * 4 + qtri.size(), qpts.data(), qpts.size() * 16, hipMemcpyHostToDevice, st));
+    HIPCHK(s->d_qhit.upload(qhit, st));
   }
   HIPCHK(s->d_shade.upload(shade, st));
   HIPCHK(s->d_materials.upload(mats, st));
@@ -687,6 +754,7 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
   d.num_curves = 0;
   for (uint8_t kd : kinds) d.num_curves += kd ? 1u : 0u;
   d.wide = wide.empty() ? nullptr : s->d_wide.p, d.wide_nodes = (uint32_t)wide.size();
+  d.q_tri0 = (uint32_t)wide.size() * 4u, d.q_pt0 = d.q_tri0 + (uint32_t)qtri.size(), d.q_hitcode = wide.empty() ? nullptr : s->d_qhit.p;
   d.top_nodes = gpu_built ? 0u : std::min<uint32_t>(num_nodes, (uint32_t)kTopNodes);
   // light sampling works on the meshes' local positions (light-manager.h:128-136 "TODO transform"), the raytracer on the
   // transformed ones: the doomed-path pretest against the light primitives (kernels.hip::misses_all_lights) is only the
@@ -1042,7 +1110,7 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
     const uint32_t bulk_div = env_u32("PBRHIP_BULK_DIV", 0u);
     const bool trace_sched = getenv("PBRHIP_TRACE_SCHED") != nullptr;
     const bool sss_walk = env_u32("PBRHIP_SSS_WALK", 1u) != 0u;  // 0: one wavefront iteration per step of a random walk (A/B)
-    // lanes (stream + counters + 73 MB of traversal spill area each) for the groups this call can have in flight: the first
+    // lanes (stream + counters + 117 MB of traversal spill area each) for the groups this call can have in flight: the first
     // chunk is the largest, so its plan has the most groups
     const uint32_t max_lanes = std::min<uint32_t>((uint32_t)kMaxGroups, (uint32_t)plan_groups(std::min(chunk_passes, d->num_sample), npix, want_groups).size());
     if (int rc = ensure_groups(s, std::max(1u, max_lanes))) return rc;
@@ -1257,7 +1325,8 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
     publish(done);
   }
   S.passes_done = done;
-  S.node_bytes = trace_uses_wide(s->dscene) ? sizeof(Bvh4Node) : sizeof(BvhNode);
+  S.node_bytes = trace_uses_wide(s->dscene) ? sizeof(QNode) : sizeof(BvhNode);
+  S.curve_bytes = trace_uses_wide(s->dscene) ? 32 : 64;
   S.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   if (stats) *stats = S;
   return PBRHIP_OK;

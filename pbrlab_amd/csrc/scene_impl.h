@@ -93,7 +93,8 @@ struct pbrhip_scene {
   bool bvh_built_on_gpu = false;
   // device scene
   pb::DevBuf<pb::BvhNode> d_nodes;
-  pb::DevBuf<float4> d_wide;  // the 4-wide tree + its copy of the slots (DScene::wide), host-built trees only
+  pb::DevBuf<float4> d_wide;  // the Q tree: quantised 4-wide nodes + its triangle slots + curve points (DScene::wide), host-built trees only
+  pb::DevBuf<uint32_t> d_qhit;  // hit code per curve point of the Q tree (DScene::q_hitcode)
   pb::DevBuf<pb::ShadeRec> d_shade;
   pb::DevBuf<pb::Material> d_materials;
   pb::DevBuf<float> d_light_cdf, d_lprim_cdf, d_tex_pixels;
@@ -124,7 +125,7 @@ struct pbrhip_scene {
   uint32_t xk_key[7] = {0, 0, 0, 0, 0, 0, 0};     // w, h, world, block, first rank, end rank, skipped rank
 
   size_t device_bytes() const {
-    return d_nodes.n * sizeof(pb::BvhNode) + d_wide.n * sizeof(float4) + d_shade.n * sizeof(pb::ShadeRec) + d_materials.n * sizeof(pb::Material) +
+    return d_nodes.n * sizeof(pb::BvhNode) + d_wide.n * sizeof(float4) + d_qhit.n * 4 + d_shade.n * sizeof(pb::ShadeRec) + d_materials.n * sizeof(pb::Material) +
            d_lrecs.n * sizeof(pb::LightRec);
   }
 };

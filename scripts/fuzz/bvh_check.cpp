@@ -1,4 +1,5 @@
 // host BVH builder under ASan/UBSan: random / degenerate inputs, structural validation of the flattened tree
+#include <math.h>
 #include <algorithm>
 #include <cstdio>
 #include <random>
@@ -57,48 +58,92 @@ int main() {
       }
     }
     if (leaves_prims != n) return printf("FAIL: %zu prims in leaves, %u expected\n", leaves_prims, n), 1;
-    // the 4-wide tree collapsed from it: the same leaves once each, every box one of the binary tree's, inner references = item
-    // indices of nodes visited once, unused children NaN + kEmptyChild, the reported stack bound >= 3 per level
-    std::vector<Bvh4Node> w;
-    const uint32_t bound = collapse_bvh4(b.nodes, &w);
+    // the Q tree collapsed from it (dscene.h::QNode).  Curve leaves are mapped as the scene commit maps them: piece g of the
+    // input is point g here, so a two-piece leaf whose pieces are not neighbours becomes two leaves.  Checked: every
+    // primitive in exactly one leaf, every node reachable once, every quantised child box -- rebuilt with the device's expression
+    // fmaf(q, s, org) -- contains the binary tree's widened box of each of its primitives and is not looser than two steps, the
+    // reported stack need is the true maximum.
+    std::vector<uint32_t> tri_rank(n, 0);
+    { uint32_t r = 0; for (uint32_t s2 = 0; s2 < n; s2++) if (!kinds[b.slot_gid[s2]]) tri_rank[s2] = r++; }
+    auto map_leaf = [&](uint32_t ref, const float* blo, const float* bhi, QChild* o) -> int {
+      const uint32_t first = (ref & 0x3FFFFFFFu) >> 3, cnt = (ref & 7u) + 1u;
+      if (!(ref & kCurveBit)) {
+        o[0].ref = kLeafBit | (tri_rank[first] << 3) | (cnt - 1u);
+        for (int a = 0; a < 3; a++) o[0].lo[a] = blo[a], o[0].hi[a] = bhi[a];
+        return 1;
+      }
+      uint32_t p0 = b.slot_gid[first];
+      if (cnt == 2) {
+        const uint32_t p1 = b.slot_gid[first + 1];
+        if ((p0 > p1 ? p0 - p1 : p1 - p0) != 1u) {
+          for (uint32_t i = 0; i < 2; i++) {
+            const uint32_t g = b.slot_gid[first + i];
+            o[i].ref = kLeafBit | kCurveBit | (g << 3);
+            for (int a = 0; a < 3; a++) o[i].lo[a] = BvhNode::widen_lo(lo[3 * g + a]), o[i].hi[a] = BvhNode::widen_hi(hi[3 * g + a]);
+          }
+          return 2;
+        }
+        p0 = std::min(p0, p1);
+      }
+      o[0].ref = kLeafBit | kCurveBit | (p0 << 3) | (cnt - 1u);
+      for (int a = 0; a < 3; a++) o[0].lo[a] = blo[a], o[0].hi[a] = bhi[a];
+      return 1;
+    };
+    std::vector<QNode> w;
+    const uint32_t bound = build_qtree(b.nodes, map_leaf, &w);
     if (w.empty() || w.size() > b.nodes.size()) return printf("FAIL: wide node count\n"), 1;
-    std::vector<int> visited(w.size(), 0), leaf_seen(n, 0);
-    struct It { uint32_t id, level; };
-    std::vector<It> st2{{0u, 1u}};
-    uint32_t levels = 0;
+    std::vector<int> visited(w.size(), 0), prim_seen(n, 0);
+    std::vector<uint32_t> tri_slot_of_rank;
+    for (uint32_t s2 = 0; s2 < n; s2++) if (!kinds[b.slot_gid[s2]]) tri_slot_of_rank.push_back(s2);
+    struct It { uint32_t id, pending; };
+    std::vector<It> st2{{0u, 0u}};
+    uint32_t need = 0;
     size_t wide_prims = 0;
     while (!st2.empty()) {
       It it = st2.back(); st2.pop_back();
       if (it.id >= w.size() || visited[it.id]++) return printf("FAIL: wide node index / revisit\n"), 1;
-      levels = std::max(levels, it.level);
-      const Bvh4Node& nd = w[it.id];
+      const QNode& nd = w[it.id];
+      const float sc[3] = {nd.sx, nd.sy, nd.sz};
+      const uint32_t ql[3] = {nd.qlo_x, nd.qlo_y, nd.qlo_z}, qh[3] = {nd.qhi_x, nd.qhi_y, nd.qhi_z};
       int used = 0;
+      for (int c = 0; c < 4; c++) used += nd.c[c] != kEmptyChild;
+      if (used == 0) return printf("FAIL: wide node without children\n"), 1;
+      need = std::max(need, it.pending + (uint32_t)used - 1u);
       for (int c = 0; c < 4; c++) {
-        if (nd.c[c] == kEmptyChild) {
-          for (int a = 0; a < 3; a++) if (nd.lo[a][c] == nd.lo[a][c] || nd.hi[a][c] == nd.hi[a][c]) return printf("FAIL: unused child without NaN box\n"), 1;
-          continue;
+        if (nd.c[c] == kEmptyChild) continue;
+        float bl[3], bh[3];
+        for (int a = 0; a < 3; a++) {
+          int e;
+          if (frexpf(sc[a], &e) != 0.5f) return printf("FAIL: step is not a power of two\n"), 1;
+          bl[a] = fmaf((float)((ql[a] >> (8 * c)) & 255u), sc[a], nd.org[a]), bh[a] = fmaf((float)((qh[a] >> (8 * c)) & 255u), sc[a], nd.org[a]);
         }
-        used++;
-        float bl[3] = {nd.lo[0][c], nd.lo[1][c], nd.lo[2][c]}, bh[3] = {nd.hi[0][c], nd.hi[1][c], nd.hi[2][c]};
+        auto check_prim = [&](uint32_t g) {
+          for (int a = 0; a < 3; a++)
+            if (!(bl[a] <= BvhNode::widen_lo(lo[3 * g + a]) && bh[a] >= BvhNode::widen_hi(hi[3 * g + a]))) return false;
+          return true;
+        };
         if (nd.c[c] & kLeafBit) {
           uint32_t first = (nd.c[c] & 0x3FFFFFFFu) >> 3, cnt = (nd.c[c] & 7u) + 1u;
-          if (first + cnt > n) return printf("FAIL: wide leaf range\n"), 1;
-          for (uint32_t s2 = first; s2 < first + cnt; s2++) {
-            if (leaf_seen[s2]++) return printf("FAIL: slot in two wide leaves\n"), 1;
-            uint32_t g = b.slot_gid[s2];
-            if (!inside(bl, bh, &lo[3 * g], &hi[3 * g])) return printf("FAIL: wide leaf box\n"), 1;
+          for (uint32_t k = 0; k < cnt; k++) {
+            uint32_t g;
+            if (nd.c[c] & kCurveBit) g = first + k;
+            else {
+              if (first + k >= tri_slot_of_rank.size()) return printf("FAIL: triangle slot range\n"), 1;
+              g = b.slot_gid[tri_slot_of_rank[first + k]];
+            }
+            if (g >= n || prim_seen[g]++) return printf("FAIL: primitive in two wide leaves\n"), 1;
+            if ((kinds[g] != 0) != ((nd.c[c] & kCurveBit) != 0)) return printf("FAIL: wide leaf kind\n"), 1;
+            if (!check_prim(g)) return printf("FAIL: quantised box does not contain its primitive (case %d)\n", it), 1;
           }
           wide_prims += cnt;
         } else {
-          if (nd.c[c] & 1u) return printf("FAIL: inner reference is not an item index\n"), 1;
-          st2.push_back({nd.c[c] / 2u, it.level + 1u});
+          st2.push_back({nd.c[c], it.pending + (uint32_t)used - 1u});
         }
       }
-      if (used == 0) return printf("FAIL: wide node without children\n"), 1;
     }
     if (wide_prims != n) return printf("FAIL: %zu prims in wide leaves, %u expected\n", wide_prims, n), 1;
     for (int v : visited) if (v != 1) return printf("FAIL: unreachable wide node\n"), 1;
-    if (bound != 3u * levels) return printf("FAIL: stack bound %u for %u levels\n", bound, levels), 1;
+    if (bound != need) return printf("FAIL: stack need %u reported, %u found\n", bound, need), 1;
     cases++;
   }
   printf("bvh builder: %zu cases ok\n", cases);

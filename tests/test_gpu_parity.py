@@ -424,15 +424,18 @@ def test_whole_frames_on_the_benchmark_scenes(pa, config, monkeypatch):
     ndiff, rel = image_check(a.rgba, rgba)
     assert ndiff == 0 and rel == 0.0, (ndiff, rel)
     assert a.rgba[..., :3].max() > 0
-    if config != "c4":  # triangle-only scenes run on the 4-wide tree by default: the binary tree must give the same frame
-        monkeypatch.setenv("PBRHIP_WIDE", "0")
-        b = pa.RenderLayer()
-        _, st = pa.Render(sg, W, H, SPP, layer=b, flags=pa.api.RENDER_STATS)
-        assert st["node_bytes"] == 64
-        monkeypatch.delenv("PBRHIP_WIDE")
-        _, st = pa.Render(sg, W, H, SPP, layer=a, flags=pa.api.RENDER_STATS)
-        assert st["node_bytes"] == 128
-        assert np.array_equal(a.rgba.view(np.uint32), b.rgba.view(np.uint32)) and np.array_equal(a.count, b.count)
+    # host-built trees are walked through the Q tree (quantised 4-wide nodes, curve pieces as chains of points) by default:
+    # the binary tree must give the same frame
+    monkeypatch.setenv("PBRHIP_WIDE", "0")
+    b = pa.RenderLayer()
+    _, st = pa.Render(sg, W, H, SPP, layer=b, flags=pa.api.RENDER_STATS)
+    assert st["node_bytes"] == 64 and st["curve_bytes"] == 64
+    nodes_binary = st["closest_nodes"] / max(st["closest_rays"], 1)
+    monkeypatch.delenv("PBRHIP_WIDE")
+    _, st = pa.Render(sg, W, H, SPP, layer=a, flags=pa.api.RENDER_STATS)
+    assert st["node_bytes"] == 64 and st["curve_bytes"] == 32
+    assert st["closest_nodes"] / max(st["closest_rays"], 1) < 0.62 * nodes_binary       # about half the node visits per ray
+    assert np.array_equal(a.rgba.view(np.uint32), b.rgba.view(np.uint32)) and np.array_equal(a.count, b.count)
 
 
 def test_headline_configuration_spot_parity(pa):
@@ -481,10 +484,11 @@ def test_gpu_built_bvh_gives_identical_results(pa, pairs, name):
         assert np.array_equal(layer.rgba.view(np.uint32), rgba.view(np.uint32))
 
 
-@pytest.mark.parametrize("name", ["lambert", "ggx", "sss", "textured"])
+@pytest.mark.parametrize("name", ["lambert", "ggx", "sss", "textured", "hair"])
 def test_wide_and_binary_trees_agree(pa, pairs, name, monkeypatch):
-    """Triangle-only scenes are traversed through the 4-wide tree (k_trace, k_tail, the trace hooks); PBRHIP_WIDE=0 selects the
-    binary tree at every launch.  Hits and images must not depend on the choice (and both equal the oracle)."""
+    """Host-built trees are traversed through the Q tree (k_trace, k_sss_walk, k_tail, the trace hooks: quantised 4-wide nodes,
+    compact triangle slots, curve pieces as chains of points); PBRHIP_WIDE=0 selects the binary tree at every launch.  Hits
+    and images must not depend on the choice (and both equal the oracle)."""
     from pbrlab_amd import scenes
     desc, sg, so = pairs[name]
     lo, hi = so.FetchSceneAABB()

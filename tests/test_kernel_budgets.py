@@ -19,10 +19,12 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 BUDGETS = {
     "k_trace<false, false, false>": (72, 0),    # binary tree, triangles: 7 waves per SIMD
     "k_trace<false, true, false>": (80, 0),     # binary tree, curves: 6 waves
-    "k_trace<false, false, true>": (96, 0),     # 4-wide tree: 5 waves
+    "k_trace<false, false, true>": (80, 0),     # Q tree, triangles: 6 waves
+    "k_trace<false, true, true>": (80, 0),      # Q tree, curves: 6 waves
     "k_sss_walk<false, false, true>": (168, 0),  # 3 waves per SIMD, nothing spilled
     "k_sss_walk<false, false, false>": (168, 0),
     "k_sss_walk<false, true, false>": (168, 0),
+    "k_sss_walk<false, true, true>": (168, 0),
     "k_shade_principled<true>": (168, 0),
     "k_classify": (64, 0),
     "k_compact": (96, 0),
