@@ -9,11 +9,12 @@
  * Transcendental mode (orc_set_math_mode):
  *   ORC_MATH_LIBM  cosf/sinf/expf/logf of the host libm  == what the reference calls
  *                  (std::cos(float) etc.).  This is "the reference's arithmetic".
- *   ORC_MATH_F64R  (float)cos((double)x) etc.: the double-precision libm result rounded once to
- *                  float, i.e. the correctly rounded float result except in ~1e-8 of calls.  The
- *                  HIP kernels compute the same quantity with the device's double-precision
- *                  functions, so GPU-vs-oracle[F64R] is (all but) bit-exact, and the libm-vs-F64R
- *                  difference is measured on the CPU alone (tests/test_oracle_math_modes.py).
+ *   ORC_MATH_F64R  the function evaluated in double precision and rounded once to float, by the
+ *                  fixed implementation of include/pbr_f64r.h (double +, -, *, /, fma only; within
+ *                  0.5 ulp + 2^-20 ulp of the true value: tests/test_f64r.py).  The HIP kernels
+ *                  compile the same header, so GPU-vs-oracle[F64R] is bit-exact, and the
+ *                  libm-vs-F64R difference is measured on the CPU alone
+ *                  (tests/test_oracle_math_modes.py).
  * sqrt and division are IEEE correctly rounded in both modes and on the device.
  */
 #ifndef ORC_MATH_H_
@@ -35,18 +36,12 @@ extern int g_orc_math_mode;
 #define ORC_EPS 1e-3f
 #define ORC_INF 1.844E18f
 
-static inline float orc_cosf(float x) {
-  return g_orc_math_mode == ORC_MATH_LIBM ? cosf(x) : (float)cos((double)x);
-}
-static inline float orc_sinf(float x) {
-  return g_orc_math_mode == ORC_MATH_LIBM ? sinf(x) : (float)sin((double)x);
-}
-static inline float orc_expf(float x) {
-  return g_orc_math_mode == ORC_MATH_LIBM ? expf(x) : (float)exp((double)x);
-}
-static inline float orc_logf(float x) {
-  return g_orc_math_mode == ORC_MATH_LIBM ? logf(x) : (float)log((double)x);
-}
+#include "../include/pbr_f64r.h" /* the fixed f64r implementation, compiled verbatim by the HIP kernels too */
+
+static inline float orc_cosf(float x) { return g_orc_math_mode == ORC_MATH_LIBM ? cosf(x) : f64r_cosf(x); }
+static inline float orc_sinf(float x) { return g_orc_math_mode == ORC_MATH_LIBM ? sinf(x) : f64r_sinf(x); }
+static inline float orc_expf(float x) { return g_orc_math_mode == ORC_MATH_LIBM ? expf(x) : f64r_expf(x); }
+static inline float orc_logf(float x) { return g_orc_math_mode == ORC_MATH_LIBM ? logf(x) : f64r_logf(x); }
 
 /* std::max(a,b) / std::min(a,b) exactly as libstdc++ defines them (NaN behaviour included). */
 static inline float orc_max(float a, float b) { return (a < b) ? b : a; }

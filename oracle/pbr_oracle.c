@@ -2020,6 +2020,11 @@ float orc_kat_fastmath(int op, float x, float y2) {
   }
   return 0.f;
 }
+/* the shared f64r functions over an array (tests/test_f64r.py): op 0 sin, 1 cos, 2 exp, 3 log */
+void orc_kat_f64r(int op, const float* x, size_t n, float* out) {
+  for (size_t i = 0; i < n; i++)
+    out[i] = op == 0 ? f64r_sinf(x[i]) : (op == 1 ? f64r_cosf(x[i]) : (op == 2 ? f64r_expf(x[i]) : f64r_logf(x[i])));
+}
 float orc_kat_fresnel(float c, float eta) { return orc_fresnel_dielectric_cos(c, eta); }
 float orc_kat_power_heuristic(float a, float b) { return orc_power_heuristic(a, b); }
 void orc_kat_lambert_sample(float u0, float u1, float out[5]) {

@@ -3,6 +3,7 @@
 // primitives of a single kind, 64-byte nodes that carry both children's boxes so that one node fetch
 // decides both descents.  Large subtrees are built on worker threads.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -285,72 +286,172 @@ uint32_t build_qtree(const std::vector<BvhNode>& N2, const std::function<int(uin
                      std::vector<QNode>* out) {
   out->clear();
   if (N2.empty()) return 0;
-  // children of a node of the binary tree as they appear in the Q tree (a leaf can become two): at most 4
-  auto children_of = [&](uint32_t node, QChild* c) {
-    int n = 0;
-    const BvhNode& b = N2[node];
-    for (int k = 0; k < 2; k++) {
-      const uint32_t ref = k ? b.c1 : b.c0;
-      if (ref == kEmptyChild) continue;
-      float lo[3], hi[3];
-      for (int a = 0; a < 3; a++) lo[a] = b.lo[a][k], hi[a] = b.hi[a][k];
-      if (ref & kLeafBit) {
-        n += map_leaf(ref, lo, hi, c + n);
-      } else {
-        c[n].ref = ref;
-        for (int a = 0; a < 3; a++) c[n].lo[a] = lo[a], c[n].hi[a] = hi[a];
-        n++;
+  // The binary tree as a tree of boxes whose leaves are the Q tree's leaf references (a leaf of the binary tree whose two
+  // curve pieces are not neighbours in a chain is an inner vertex with two leaves here).  Children follow their parent.
+  struct V {
+    float lo[3], hi[3];
+    int32_t l = -1, r = -1;  // children, or -1: leaf
+    uint32_t ref = 0;        // leaf: the Q tree's reference
+    uint32_t prims = 0;      // leaf: primitives behind the reference
+  };
+  std::vector<V> T;
+  T.reserve(N2.size() * 3);
+  {
+    struct Todo {
+      uint32_t node2;
+      int32_t v;
+    };
+    std::vector<Todo> todo;
+    T.emplace_back();
+    todo.push_back({0u, 0});
+    while (!todo.empty()) {
+      const Todo t = todo.back();
+      todo.pop_back();
+      const BvhNode& b = N2[t.node2];
+      int32_t kids[2] = {-1, -1};
+      int nk = 0;
+      for (int k = 0; k < 2; k++) {
+        const uint32_t ref = k ? b.c1 : b.c0;
+        if (ref == kEmptyChild) continue;
+        float lo[3], hi[3];
+        for (int a = 0; a < 3; a++) lo[a] = b.lo[a][k], hi[a] = b.hi[a][k];
+        const int32_t v = (int32_t)T.size();
+        T.emplace_back();
+        for (int a = 0; a < 3; a++) T[v].lo[a] = lo[a], T[v].hi[a] = hi[a];
+        kids[nk++] = v;
+        if (!(ref & kLeafBit)) {
+          todo.push_back({ref, v});
+          continue;
+        }
+        QChild c[2];
+        const int m = map_leaf(ref, lo, hi, c);
+        if (m == 1) {
+          T[v].ref = c[0].ref, T[v].prims = (c[0].ref & 7u) + 1u;
+          for (int a = 0; a < 3; a++) T[v].lo[a] = c[0].lo[a], T[v].hi[a] = c[0].hi[a];
+        } else {
+          for (int j = 0; j < 2; j++) {
+            const int32_t w = (int32_t)T.size();
+            T.emplace_back();
+            T[w].ref = c[j].ref, T[w].prims = (c[j].ref & 7u) + 1u;
+            for (int a = 0; a < 3; a++) T[w].lo[a] = c[j].lo[a], T[w].hi[a] = c[j].hi[a];
+            (j ? T[v].r : T[v].l) = w;
+          }
+        }
       }
+      // vertex t.v takes the node's children; a node with one child (a scene of one leaf) passes it through
+      if (nk == 2) T[t.v].l = kids[0], T[t.v].r = kids[1];
+      else if (nk == 1) T[t.v].l = kids[0], T[t.v].r = -1;
     }
-    return n;
+    // the root's own box: the union of its children
+    for (int a = 0; a < 3; a++) {
+      T[0].lo[a] = std::numeric_limits<float>::infinity(), T[0].hi[a] = -T[0].lo[a];
+      for (int32_t k : {T[0].l, T[0].r})
+        if (k >= 0) T[0].lo[a] = std::min(T[0].lo[a], T[k].lo[a]), T[0].hi[a] = std::max(T[0].hi[a], T[k].hi[a]);
+    }
+  }
+  auto area = [](const V& v) {
+    const float dx = v.hi[0] - v.lo[0], dy = v.hi[1] - v.lo[1], dz = v.hi[2] - v.lo[2];
+    const float a = dx * dy + dy * dz + dz * dx;
+    return a >= 0.f && std::isfinite(a) ? (double)a : 0.0;
   };
-  auto area = [](const QChild& c) {
-    const float dx = c.hi[0] - c.lo[0], dy = c.hi[1] - c.lo[1], dz = c.hi[2] - c.lo[2];
-    return dx * dy + dy * dz + dz * dx;
-  };
+  // Which descendants become the (up to four) children of a Q node is chosen by dynamic programming over the surface-area
+  // cost (a node visit costs kCostNode, a primitive test kCostPrim, each weighted with the area of its box):
+  //   f[v][1] = cost of the subtree of v with v a child of its Q node (v a leaf: its tests; else a Q node of its own)
+  //   f[v][k] = cheapest way to present the subtree of v as k children of the Q node above (k = 2..4)
+  // The greedy rule (expand the largest child while it fits) left 2.6 children per node on the hair scene.
+  // (every leaf is tested below exactly one frontier whatever the choice, so only the sum of the areas of the vertices that
+  // become Q nodes is being minimised: the result does not depend on the two cost constants)
+  constexpr double kCostNode = 1.0, kCostPrim = 1.0, kInfCost = 1e300;
+  const size_t nv = T.size();
+  std::vector<double> f(nv * 4, kInfCost);          // f[v * 4 + (k - 1)]
+  std::vector<uint8_t> split(nv * 4, 0), own(nv, 0);  // split[v][k]: children handed to the left subtree; own[v]: k of v's own Q node
+  for (size_t v = nv; v-- > 0;) {
+    const V& t = T[v];
+    if (t.l < 0) {
+      f[v * 4] = area(t) * kCostPrim * t.prims;
+      continue;
+    }
+    if (t.r < 0) {  // pass-through (one child)
+      for (int k = 0; k < 4; k++) f[v * 4 + k] = f[(size_t)t.l * 4 + k], split[v * 4 + k] = (uint8_t)(k + 1);
+      own[v] = 1;
+      continue;
+    }
+    double best = kInfCost;
+    for (int k = 2; k <= 4; k++) {
+      double g = kInfCost;
+      for (int i = 1; i < k; i++) {
+        const double c = f[(size_t)t.l * 4 + (i - 1)] + f[(size_t)t.r * 4 + (k - i - 1)];
+        if (c < g) g = c, split[v * 4 + (k - 1)] = (uint8_t)i;
+      }
+      f[v * 4 + (k - 1)] = g;
+      if (g < best) best = g, own[v] = (uint8_t)k;
+    }
+    f[v * 4] = area(t) * kCostNode + best;
+  }
+  // emit: the Q node of vertex v has the frontier of size own[v] below v as its children
   struct Item {
-    uint32_t node2, out, level;
+    int32_t v;
+    uint32_t out;
   };
   std::vector<Item> work;
   out->emplace_back();
-  work.push_back({0u, 0u, 1u});
+  work.push_back({0, 0u});
   uint32_t levels = 0;
   while (!work.empty()) {
     const Item it = work.back();
     work.pop_back();
-    levels = std::max(levels, it.level);
-    QChild c[8];
-    int n = children_of(it.node2, c);  // <= 4
-    while (n < 4) {
-      // replace the inner child of largest surface area whose own children still fit by those children
-      int best = -1, bm = 0;
-      QChild bg[4];
-      for (int i = 0; i < n; i++) {
-        if ((c[i].ref & kLeafBit) || (best >= 0 && !(area(c[i]) > area(c[best])))) continue;
-        QChild g[4];
-        const int m = children_of(c[i].ref, g);
-        if (m == 0 || n - 1 + m > 4) continue;
-        best = i, bm = m;
-        for (int j = 0; j < m; j++) bg[j] = g[j];
+    int32_t fr[4];
+    int n = 0;
+    {
+      struct Part {
+        int32_t v;
+        int k;
+      };
+      Part st[8];
+      int sp = 0;
+      const V& t = T[it.v];
+      if (t.l < 0) {
+        fr[n++] = it.v;  // (a scene of one leaf: the root node holds it)
+      } else if (t.r < 0) {
+        st[sp++] = {t.l, 1};
+      } else {
+        const int k = own[it.v], i = split[(size_t)it.v * 4 + (k - 1)];
+        st[sp++] = {t.r, k - i}, st[sp++] = {t.l, i};
       }
-      if (best < 0) break;
-      c[best] = bg[0];
-      for (int j = 1; j < bm; j++) c[n++] = bg[j];
+      while (sp > 0) {
+        const Part p = st[--sp];
+        const V& u = T[p.v];
+        if (p.k == 1 || u.l < 0) {
+          fr[n++] = p.v;
+        } else if (u.r < 0) {
+          st[sp++] = {u.l, p.k};
+        } else {
+          const int i = split[(size_t)p.v * 4 + (p.k - 1)];
+          st[sp++] = {u.r, p.k - i}, st[sp++] = {u.l, i};
+        }
+      }
+    }
+    QChild c[4];
+    for (int i = 0; i < n; i++) {
+      const V& u = T[fr[i]];
+      c[i].ref = u.l < 0 ? u.ref : 0u;
+      for (int a = 0; a < 3; a++) c[i].lo[a] = u.lo[a], c[i].hi[a] = u.hi[a];
     }
     QNode nd;
-    if (!quantise_node(c, n, &nd)) {
+    if (n == 0 || !quantise_node(c, n, &nd)) {
       out->clear();
       return 0;
     }
     for (int i = 0; i < 4; i++) nd.c[i] = kEmptyChild;
     for (int i = 0; i < n; i++) {
-      if (c[i].ref & kLeafBit) {
-        nd.c[i] = c[i].ref;
+      const V& u = T[fr[i]];
+      if (u.l < 0) {
+        nd.c[i] = u.ref;
       } else {
         const uint32_t id = (uint32_t)out->size();
         out->emplace_back();
         nd.c[i] = id;
-        work.push_back({c[i].ref, id, it.level + 1u});
+        work.push_back({fr[i], id});
       }
     }
     (*out)[it.out] = nd;

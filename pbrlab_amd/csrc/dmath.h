@@ -4,8 +4,9 @@
 // tree).  The whole library is compiled with -ffp-contract=off, IEEE division and square root
 // (hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt) and denormals enabled, so that '+', '*',
 // '/', sqrt round exactly once in the order written here -- the order the reference writes them.
-// cos/sin/exp/log go through the device's double-precision functions and are rounded once to float
-// ("f64r"); the hair closure uses the reference's own fmaf polynomials.
+// cos/sin/exp/log are evaluated in double precision by a fixed polynomial implementation shared with the checker
+// (include/pbr_f64r.h) and rounded once to float ("f64r"); the hair closure uses the reference's own
+// fmaf polynomials.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -27,11 +28,20 @@ constexpr float kFltMin = 1.17549435082228750797e-38f;
 constexpr float kFltMax = 3.40282346638528859812e+38f;
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 
+}  // namespace pb
 // ------------------------------------------------------------------ transcendental policy (f64r)
-PB_HD float f_cos(float x) { return (float)cos((double)x); }
-PB_HD float f_sin(float x) { return (float)sin((double)x); }
-PB_HD float f_exp(float x) { return (float)exp((double)x); }
-PB_HD float f_log(float x) { return (float)log((double)x); }
+// cos / sin / exp / log = the double-precision value rounded once to float, from the fixed implementation the checker
+// compiles too (include/pbr_f64r.h: IEEE double arithmetic and fma only -- no OCML / libm call, no Payne-Hanek branch).
+#ifndef PB_F64R_FN
+#define PB_F64R_FN __host__ __device__ __forceinline__
+#endif
+#define F64R_FN PB_F64R_FN
+#include "../../include/pbr_f64r.h"
+namespace pb {
+PB_HD float f_cos(float x) { return f64r_cosf(x); }
+PB_HD float f_sin(float x) { return f64r_sinf(x); }
+PB_HD float f_exp(float x) { return f64r_expf(x); }
+PB_HD float f_log(float x) { return f64r_logf(x); }
 
 // std::max / std::min as libstdc++ defines them (comparison order matters for NaN)
 PB_HD float smax(float a, float b) { return (a < b) ? b : a; }

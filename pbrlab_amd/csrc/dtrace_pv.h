@@ -30,7 +30,11 @@ constexpr int kPvLdsStack = PB_LDS_STACK;  // stack entries per lane kept in LDS
 #ifndef PB_REFILL
 #define PB_REFILL 32
 #endif
-constexpr int kPvRefillIdle = PB_REFILL;         // refill when at least this many lanes are idle
+constexpr int kPvRefillIdle = PB_REFILL;         // refill when at least this many lanes are idle (triangle-only scenes)
+#ifndef PB_REFILL_CURVES
+#define PB_REFILL_CURVES 24
+#endif
+constexpr int kPvRefillIdleCurves = PB_REFILL_CURVES;  // the same for scenes with curves (A/B on C4, round 3: 32 -> 216.6 ms per frame, 24 -> 213.0, 16 -> 209)
 // Weights of one lane in the phase vote.  Measured on C2 (A/B, k_trace ms per frame): node:tri = 2:1 64.1, 1:1 60.9,
 // 3:4 59.0, 1:2 57.9, 1:3 58.0 -- primitives first: a lane parked at a leaf holds a shorter tmax for its own later box
 // tests and returns to the (much more frequent) node phase, so the node phase runs with more lanes.
@@ -44,7 +48,7 @@ constexpr int kPvRefillIdle = PB_REFILL;         // refill when at least this ma
 #define PB_W_TRI 2
 #endif
 #ifndef PB_W_CURVE
-#define PB_W_CURVE 1
+#define PB_W_CURVE 2  // (round 3, Q tree: 1 -> 216.6 ms per C4 frame, 2 -> 213.5; together with the refill at 24 idle lanes 210.2)
 #endif
 
 // kStDone / kStDoneOccluded: the ray is finished, its result still sits in the lane's registers.  Results are delivered
@@ -152,7 +156,7 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
     int n_idle = __popcll(idle_mask);
     // (a walking sink has work for its finished lanes even when the queue is empty: their walks go on)
     // (a walking sink's step is ~3x the work of tracing a ray: it waits for more lanes to be ready for theirs)
-    constexpr int kRefillAt = Sink::kWalk ? PB_WALK_REFILL : kPvRefillIdle;
+    constexpr int kRefillAt = Sink::kWalk ? PB_WALK_REFILL : (CURVES ? kPvRefillIdleCurves : kPvRefillIdle);
     const int n_busy_now = 64 - n_idle;
     if ((n_idle >= kRefillAt || (Sink::kWalk && n_busy_now == 0)) && (!exhausted || (Sink::kWalk && __ballot(state >= kStDone) != 0ull))) {
       // ---- refill idle lanes from the queue

@@ -657,8 +657,11 @@ __device__ __forceinline__ uint32_t shade_principled_path(const PathState& P, co
 #define PB_LDS_MATS 64
 #endif
 constexpr uint32_t kLdsMats = PB_LDS_MATS;  // closure sets staged in LDS by the plain shading kernel (96 B each)
+#ifndef PB_SHADE_WAVES_FULL
+#define PB_SHADE_WAVES_FULL 3  // the same for the general kernel (media, textured materials)
+#endif
 template <bool PLAIN>
-__global__ __launch_bounds__(kBlock, PB_SHADE_WAVES) void k_shade_principled(PathState P, DScene sc, uint64_t rng_inc) {
+__global__ __launch_bounds__(kBlock, PLAIN ? PB_SHADE_WAVES : PB_SHADE_WAVES_FULL) void k_shade_principled(PathState P, DScene sc, uint64_t rng_inc) {
   __shared__ PrincipledBsdf lds_bsdf[kLdsMats ? kLdsMats : 1];
   __shared__ float lds_lights[kLdsMats ? kLdsLightWords : 1];
   const bool lights_staged = kLdsMats && stage_light_tables(sc, lds_lights);

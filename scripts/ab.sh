@@ -7,7 +7,8 @@ for lib in "$@"; do
   PBRHIP_LIB=$(realpath $lib) python bench.py --no-cpu-baseline "${args[@]}" 2>&1 | tail -1 | python -c "
 import sys, json
 d = json.loads(sys.stdin.read())
-r = d['roofline']
-print('$lib', 'Msamples/s %.1f' % d['value'], 'ms/step %.1f' % d['ms_per_step'], 'frac %.3f' % r['frac'], 'launches %d' % r['launches_per_step'], 'depth', d['config'].get('bvh_depth'), {k: round(v,1) for k,v in r['kernel_ms_per_step'].items()})
+r = d.get('roofline') or {}
+k = {k: round(v, 1) for k, v in (r.get('kernel_ms_per_step') or {}).items() if v}
+print('%-28s' % '$lib', 'Msamples/s %.1f' % d['value'], 'ms/step %.2f' % d['ms_per_step'], k)
 "
 done

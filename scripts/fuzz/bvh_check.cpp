@@ -133,7 +133,7 @@ int main() {
             }
             if (g >= n || prim_seen[g]++) return printf("FAIL: primitive in two wide leaves\n"), 1;
             if ((kinds[g] != 0) != ((nd.c[c] & kCurveBit) != 0)) return printf("FAIL: wide leaf kind\n"), 1;
-            if (!check_prim(g)) return printf("FAIL: quantised box does not contain its primitive (case %d)\n", it), 1;
+            if (!check_prim(g)) return printf("FAIL: quantised box does not contain its primitive\n"), 1;
           }
           wide_prims += cnt;
         } else {
