@@ -10,26 +10,25 @@
 int main() {
   try {
     pbrlab::Scene scene;
-    // one quad `light` above one quad floor, shared attribute buffer like LoadTriangleMeshFromObj
-    std::vector<float> v = {-1, 0, -1, 1, 1, 0, -1, 1, 1, 0, 1, 1, -1, 0, 1, 1,
-                            -.5f, 1, -.5f, 1, .5f, 1, -.5f, 1, .5f, 1, .5f, 1, -.5f, 1, .5f, 1};
-    pbrlab::CyclesPrincipledBsdfParameter white = {};
-    white.base_color[0] = white.base_color[1] = white.base_color[2] = 0.8f;
-    white.subsurface_radius[0] = white.subsurface_radius[1] = white.subsurface_radius[2] = 1.f;
-    white.roughness = 0.5f, white.sheen_tint = 0.5f, white.clearcoat_roughness = 0.03f, white.ior = 1.45f;
-    white.base_color_tex_id = white.subsurface_color_tex_id = PBRHIP_NONE;
+    // one quad `light` above one quad floor, shared attribute buffer like LoadTriangleMeshFromObj (io/triangle-mesh-io.cc:238-262)
+    auto attr = std::make_shared<pbrlab::Attribute>();
+    attr->vertices = {-1, 0, -1, 1, 1, 0, -1, 1, 1, 0, 1, 1, -1, 0, 1, 1,
+                      -.5f, 1, -.5f, 1, .5f, 1, -.5f, 1, .5f, 1, .5f, 1, -.5f, 1, .5f, 1};
+    pbrlab::CyclesPrincipledBsdfParameter white;  // the defaults of material-param.h:24-49
     const uint32_t mat = scene.AddMaterialParam(white);
     const float I[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
-    auto floor = scene.AddTriangleMesh("floor", v, {}, {}, {0, 2, 1, 0, 3, 2}, {}, {}, {mat, mat});
+    const pbrlab::MeshPtr floor = scene.AddTriangleMesh("floor", attr, std::vector<uint32_t>{0, 2, 1, 0, 3, 2}, std::vector<uint32_t>{},
+                                                        std::vector<uint32_t>{}, std::vector<uint32_t>{mat, mat});
     uint32_t ls = scene.CreateLocalScene();
     scene.AddMeshToLocalScene(ls, floor);
     scene.CreateInstance(ls, I);
-    auto light = scene.AddTriangleMesh("light", v, {}, {}, {4, 5, 6, 4, 6, 7}, {}, {}, {mat, mat});
+    const pbrlab::MeshPtr light = scene.AddTriangleMesh("light", attr, std::vector<uint32_t>{4, 5, 6, 4, 6, 7}, std::vector<uint32_t>{},
+                                                        std::vector<uint32_t>{}, std::vector<uint32_t>{mat, mat});
     ls = scene.CreateLocalScene();
     scene.AddMeshToLocalScene(ls, light);
     const uint32_t inst = scene.CreateInstance(ls, I);
     pbrlab::AreaLightParameter lp;
-    lp.emission[0] = lp.emission[1] = lp.emission[2] = 3.0f;  // pc/pc-common.cc:174
+    lp.emission = pbrlab::float3(3.0f);  // pc/pc-common.cc:174
     const uint32_t lid = scene.AddLightParam(lp);
     scene.AttachLightParamIdsToInstance(inst, {{lid, lid}});
     bool threw = false;

@@ -7,6 +7,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "tests", "cpp", "shim_smoke")
+EXE_TYPES = os.path.join(ROOT, "tests", "cpp", "shim_types")
 
 
 def build():
@@ -14,9 +15,10 @@ def build():
     if not os.path.exists(os.path.join(ROOT, "pbrlab_amd", "libpbrhip.so")):
         g.build()
     lib = os.path.join(ROOT, "pbrlab_amd")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "tests", "cpp", "shim_smoke.cc"), "-L" + lib, "-lpbrhip",
-                           "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-lpthread", "-o", EXE])
+    for src, exe in (("shim_smoke.cc", EXE), ("shim_types.cc", EXE_TYPES)):
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I" + os.path.join(ROOT, "include"),
+                               os.path.join(ROOT, "tests", "cpp", src), "-L" + lib, "-lpbrhip",
+                               "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-lpthread", "-o", exe])
 
 
 def test_shim_compiles_and_fails_loudly_on_cpu():
@@ -34,3 +36,12 @@ def test_shim_renders_on_gpu():
     build()
     r = subprocess.run([EXE], capture_output=True, text=True)
     assert r.returncode == 0 and "shim ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_shim_value_types_walk_the_reference_callers_sequences():
+    """tests/cpp/shim_types.cc: pc/pc-common.cc:100-233 + the GUI's material edit loop with pbrlab's own value types
+    (TriangleMesh, Attribute, Texture, MaterialParameter, MeshPtr, float3, FetchMeshMaterialParameters)"""
+    build()
+    r = subprocess.run([EXE_TYPES], capture_output=True, text=True)
+    assert r.returncode == 0 and "shim types ok" in r.stdout, (r.returncode, r.stdout + r.stderr)
