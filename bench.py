@@ -65,11 +65,11 @@ def csrc_hash():
 
 
 def pmc_record(workload, spp, world, kernel):
-    """Counters cannot be read live, so they come from the committed PMC passes of this round (profiles/r2_<workload>_pmc.json,
+    """Counters cannot be read live, so they come from the committed PMC passes of this round (profiles/r3_<workload>_pmc.json,
     written by scripts/profile_round.py: FETCH_SIZE, WRITE_SIZE and SQ counters in separate --pmc passes over one render of
     the same workload, per kernel).  They are only used when that file was collected on the very kernel sources that are
     running (csrc_hash) and on the same configuration; otherwise the counter-based fields are null."""
-    path = os.path.join(ROOT, "profiles", f"r2_{workload}_pmc.json")
+    path = os.path.join(ROOT, "profiles", f"r3_{workload}_pmc.json")
     if world != 1 or not os.path.exists(path):
         return None, "no PMC record for this configuration"
     rec = json.load(open(path))

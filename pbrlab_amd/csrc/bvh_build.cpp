@@ -354,41 +354,74 @@ uint32_t build_qtree(const std::vector<BvhNode>& N2, const std::function<int(uin
     const float a = dx * dy + dy * dz + dz * dx;
     return a >= 0.f && std::isfinite(a) ? (double)a : 0.0;
   };
-  // Which descendants become the (up to four) children of a Q node is chosen by dynamic programming over the surface-area
-  // cost (a node visit costs kCostNode, a primitive test kCostPrim, each weighted with the area of its box):
-  //   f[v][1] = cost of the subtree of v with v a child of its Q node (v a leaf: its tests; else a Q node of its own)
-  //   f[v][k] = cheapest way to present the subtree of v as k children of the Q node above (k = 2..4)
-  // The greedy rule (expand the largest child while it fits) left 2.6 children per node on the hair scene.
-  // (every leaf is tested below exactly one frontier whatever the choice, so only the sum of the areas of the vertices that
-  // become Q nodes is being minimised: the result does not depend on the two cost constants)
-  constexpr double kCostNode = 1.0, kCostPrim = 1.0, kInfCost = 1e300;
+  // Which descendants become the (up to four) children of the Q node of a vertex v is chosen bottom-up over the surface-area
+  // cost, with the box a child really presents to a ray: its box rounded outwards on the 8-bit grid of v (step = extent of v /
+  // 253 rounded up to a power of two).  That looseness is what matters for thin primitives in big nodes -- a wall triangle of
+  // the Cornell box as a child of a node two units wide is a slab 0.016 thick, and every ray that starts on the wall tests it:
+  // with plain areas the collapse put such leaves high up and a shadow ray tested 2.7 triangles instead of 0.9.
+  //   below[v] = min over the frontiers F below v, |F| <= 4, of  sum_{u in F} qarea(u | v) * (u leaf ? prims : 1) + below[u]
+  // A vertex has at most a dozen frontiers (each inner member may be replaced by its two children while there is room).
+  constexpr double kCostNode = 1.0, kCostPrim = 1.0;
   const size_t nv = T.size();
-  std::vector<double> f(nv * 4, kInfCost);          // f[v * 4 + (k - 1)]
-  std::vector<uint8_t> split(nv * 4, 0), own(nv, 0);  // split[v][k]: children handed to the left subtree; own[v]: k of v's own Q node
-  for (size_t v = nv; v-- > 0;) {
-    const V& t = T[v];
-    if (t.l < 0) {
-      f[v * 4] = area(t) * kCostPrim * t.prims;
+  std::vector<double> below(nv, 0.0);
+  std::vector<int32_t> choice(nv * 4, -1);  // the chosen frontier of v
+  auto qarea = [&](const V& u, const V& v) {
+    double e[3];
+    for (int a = 0; a < 3; a++) {
+      const double ext = (double)v.hi[a] - (double)v.lo[a];
+      int ex;
+      frexp(std::max(ext / 253.0, 1e-37), &ex);
+      const double st = ldexp(1.0, ex);
+      const double ql = floor(((double)u.lo[a] - (double)v.lo[a]) / st), qh = ceil(((double)u.hi[a] - (double)v.lo[a]) / st);
+      e[a] = std::max(qh - ql, 0.0) * st;
+    }
+    const double a = e[0] * e[1] + e[1] * e[2] + e[2] * e[0];
+    return std::isfinite(a) ? a : 0.0;
+  };
+  for (size_t vi = nv; vi-- > 0;) {
+    const V& v = T[vi];
+    if (v.l < 0) continue;  // leaf: nothing below
+    if (v.r < 0) {          // pass-through (the root of a scene with one leaf or one subtree)
+      choice[vi * 4] = v.l;
+      below[vi] = T[v.l].l < 0 ? area(T[v.l]) * kCostPrim * T[v.l].prims : area(T[v.l]) * kCostNode + below[v.l];
       continue;
     }
-    if (t.r < 0) {  // pass-through (one child)
-      for (int k = 0; k < 4; k++) f[v * 4 + k] = f[(size_t)t.l * 4 + k], split[v * 4 + k] = (uint8_t)(k + 1);
-      own[v] = 1;
-      continue;
-    }
-    double best = kInfCost;
-    for (int k = 2; k <= 4; k++) {
-      double g = kInfCost;
-      for (int i = 1; i < k; i++) {
-        const double c = f[(size_t)t.l * 4 + (i - 1)] + f[(size_t)t.r * 4 + (k - i - 1)];
-        if (c < g) g = c, split[v * 4 + (k - 1)] = (uint8_t)i;
+    // enumerate the frontiers: start from {l, r}; replace inner members by their children while the size stays <= 4
+    int32_t fronts[16][4];
+    int sizes[16], nf = 0;
+    fronts[0][0] = v.l, fronts[0][1] = v.r, sizes[0] = 2, nf = 1;
+    for (int i = 0; i < nf && nf < 16; i++) {
+      if (sizes[i] >= 4) continue;
+      for (int m = 0; m < sizes[i] && nf < 16; m++) {
+        const V& u = T[fronts[i][m]];
+        if (u.l < 0 || u.r < 0) continue;
+        int32_t g[4];
+        int n = 0;
+        for (int j = 0; j < sizes[i]; j++) {
+          if (j == m) g[n++] = u.l, g[n++] = u.r;
+          else g[n++] = fronts[i][j];
+        }
+        std::sort(g, g + n);
+        bool dup = false;
+        for (int q = 0; q < nf && !dup; q++) dup = sizes[q] == n && std::equal(g, g + n, fronts[q]);
+        if (dup) continue;
+        std::copy(g, g + n, fronts[nf]), sizes[nf] = n, nf++;
       }
-      f[v * 4 + (k - 1)] = g;
-      if (g < best) best = g, own[v] = (uint8_t)k;
     }
-    f[v * 4] = area(t) * kCostNode + best;
+    double best = 1e300;
+    int bi = 0;
+    for (int i = 0; i < nf; i++) {
+      double c = 0.0;
+      for (int m = 0; m < sizes[i]; m++) {
+        const V& u = T[fronts[i][m]];
+        c += u.l < 0 ? qarea(u, v) * kCostPrim * u.prims : qarea(u, v) * kCostNode + below[fronts[i][m]];
+      }
+      if (c < best) best = c, bi = i;
+    }
+    below[vi] = best;
+    for (int m = 0; m < sizes[bi]; m++) choice[vi * 4 + m] = fronts[bi][m];
   }
-  // emit: the Q node of vertex v has the frontier of size own[v] below v as its children
+  // emit: the Q node of vertex v has its chosen frontier as children
   struct Item {
     int32_t v;
     uint32_t out;
@@ -402,34 +435,12 @@ uint32_t build_qtree(const std::vector<BvhNode>& N2, const std::function<int(uin
     work.pop_back();
     int32_t fr[4];
     int n = 0;
-    {
-      struct Part {
-        int32_t v;
-        int k;
-      };
-      Part st[8];
-      int sp = 0;
-      const V& t = T[it.v];
-      if (t.l < 0) {
-        fr[n++] = it.v;  // (a scene of one leaf: the root node holds it)
-      } else if (t.r < 0) {
-        st[sp++] = {t.l, 1};
-      } else {
-        const int k = own[it.v], i = split[(size_t)it.v * 4 + (k - 1)];
-        st[sp++] = {t.r, k - i}, st[sp++] = {t.l, i};
-      }
-      while (sp > 0) {
-        const Part p = st[--sp];
-        const V& u = T[p.v];
-        if (p.k == 1 || u.l < 0) {
-          fr[n++] = p.v;
-        } else if (u.r < 0) {
-          st[sp++] = {u.l, p.k};
-        } else {
-          const int i = split[(size_t)p.v * 4 + (p.k - 1)];
-          st[sp++] = {u.r, p.k - i}, st[sp++] = {u.l, i};
-        }
-      }
+    if (T[it.v].l < 0) {
+      fr[n++] = it.v;  // (a scene of one leaf: the root node holds it)
+    } else {
+      for (int m = 0; m < 4; m++)
+        if (choice[(size_t)it.v * 4 + m] >= 0) fr[n++] = choice[(size_t)it.v * 4 + m];
+      // (a pass-through vertex hands on its only child; if that child is inner it gets a node of its own below)
     }
     QChild c[4];
     for (int i = 0; i < n; i++) {

@@ -63,7 +63,7 @@ static_assert(sizeof(BvhNode) == 64, "node must be 64 B");
 // binary tree's (already widened) box.  The traversal rebuilds the bounds the same way and then runs the binary tree's slab
 // arithmetic on them, so the quantised test inherits its properties (monotone in the box, correct for axis-parallel rays).
 // Child references: an inner child = its item index; a triangle leaf = kLeafBit | first << 3 | (count - 1) with `first` the
-// index into the tree's own compact triangle slots (DScene::q_tri0); a curve leaf = kLeafBit | kCurveBit | first << 3 |
+// index into the tree's own compact triangle slots (DScene::q_tri0; 48 B each); a curve leaf = kLeafBit | kCurveBit | first << 3 |
 // (count - 1) with `first` a POINT index (DScene::q_pt0): the linear pieces of a strand are stored as a chain of points
 // (xyz + radius, 16 B), piece p = points p, p + 1, piece-in-cubic index = p & 3 (every cubic starts at a multiple of 4).
 // An unused child has reference kEmptyChild.
@@ -186,7 +186,7 @@ struct DScene {
   const float* tex_pixels;
   const TexDesc* textures;
   uint32_t num_nodes, num_slots, num_lights, num_materials, num_curves, num_textures, num_lrecs;
-  const float4* wide;           // Q tree (4-wide, quantised): wide_nodes x QNode, its compact triangle slots (64 B: corners, .w of the third
+  const float4* wide;           // Q tree (4-wide, quantised): wide_nodes x QNode, its compact triangle slots (48 B: corners, .w of the third
                                 // word = the hit code slot | routing bits), the points of the curve pieces (16 B); or null
   uint32_t wide_nodes;
   uint32_t q_tri0, q_pt0;       // 16-byte index of triangle slot 0 / point 0 in `wide`

@@ -233,7 +233,7 @@ __device__ __forceinline__ bool leaf_test(const DScene& sc, uint32_t leaf, V3 o,
     uint32_t code;
     if (WIDE) {  // Q tree: compact triangle slots / chains of curve points (dscene.h)
       if (!CURVES || !is_curve) {
-        const float4* g = sc.wide + sc.q_tri0 + (size_t)s * 4;
+        const float4* g = sc.wide + sc.q_tri0 + (size_t)s * 3;
         float4 a = g[0], b = g[1], c = g[2];
         if (STATS) st.tris++;
         ok = tri_test(ld3(a), ld3(b), ld3(c), o, d, inv, tmin, t, u, v) && (t <= best_t);

@@ -27,6 +27,14 @@ constexpr uint32_t kPvGuide = PB_GUIDE;   // a grab takes 1 / (kPvGuide x waves)
 #define PB_LDS_STACK 16
 #endif
 constexpr int kPvLdsStack = PB_LDS_STACK;  // stack entries per lane kept in LDS
+#ifndef PB_LDS_STACK_DEEP
+#define PB_LDS_STACK_DEEP 16
+#endif
+// ... and for the Q tree of scenes with curves (hair: trees 14-16 levels deep, up to three entries per level): a wave whose
+// lanes are on both sides of the LDS / spill boundary runs both push paths every node turn
+constexpr int kPvLdsStackDeep = PB_LDS_STACK_DEEP;
+template <bool CURVES, bool WIDE>
+__host__ __device__ constexpr int pv_lds_stack() { return (CURVES && WIDE) ? kPvLdsStackDeep : kPvLdsStack; }
 #ifndef PB_REFILL
 #define PB_REFILL 32
 #endif
@@ -87,6 +95,7 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
                                          uint32_t ntop = 0) {
   // top / ntop: LDS copy of nodes 0 .. ntop-1 (the breadth-first top of the tree, 64 bytes each), or none
   // frame (CURVES): 10 words per lane in LDS (frame[k * stride]), the ray's RayFrame, written when the ray is fetched
+  constexpr int kLds = pv_lds_stack<CURVES, WIDE>();  // stack entries of this lane that live in LDS
   const uint32_t lane = __lane_id();
   // number of set bits of a wave mask below this lane (v_mbcnt: no per-lane mask has to stay in registers)
   auto rank_in = [](unsigned long long m) {
@@ -281,7 +290,7 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
           have_next = k[0] != kWideMiss;
           next = ref_of(k[0]);
           if (k[1] != kWideMiss) {  // the other hit children go on the stack, farthest first
-            if (sp + 3 <= kPvLdsStack) {
+            if (sp + 3 <= kLds) {
               // (an entry written for a child that was not hit lies above the new top or is overwritten by the next one)
               uint32_t p = (uint32_t)sp;
               stk_base[p * stride] = ref_of(k[3]);
@@ -295,11 +304,11 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
               for (int j = 3; j >= 1; j--) {
                 if (k[j] == kWideMiss) continue;
                 const uint32_t farc = ref_of(k[j]);
-                if (sp < kPvLdsStack) {
+                if (sp < kLds) {
                   stk_base[(uint32_t)sp * stride] = farc;
                   sp++;
                 } else if (sp < kStackDepth) {
-                  spill[(uint32_t)(sp - kPvLdsStack) * spill_stride] = farc;
+                  spill[(uint32_t)(sp - kLds) * spill_stride] = farc;
                   sp++;
                 } else {
                   *overflow = 1u;
@@ -319,11 +328,11 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
           have_next = h0 || h1;
           next = nearc;
           if (h0 && h1) {
-            if (sp < kPvLdsStack) {
+            if (sp < kLds) {
               stk_base[(uint32_t)sp * stride] = farc;
               sp++;
             } else if (sp < kStackDepth) {
-              spill[(uint32_t)(sp - kPvLdsStack) * spill_stride] = farc;
+              spill[(uint32_t)(sp - kLds) * spill_stride] = farc;
               sp++;
             } else {
               *overflow = 1u;
@@ -361,7 +370,7 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
             state = kStDoneOccluded;
             if (STATS) st.ahist[steps <= 16u ? 0 : (28 - __clz(steps - 1u) > 7 ? 7 : 28 - __clz(steps - 1u))]++, st.amax_steps = steps > st.amax_steps ? steps : st.amax_steps;
           } else if (rem != 0u) {  // next primitive of the same leaf
-            rem--, cur += WIDE ? ((CURVES && is_curve) ? 1u : 4u) : 1u;
+            rem--, cur += WIDE ? ((CURVES && is_curve) ? 1u : 3u) : 1u;
             need_load = true;
           } else {
             advance = true;  // leaf done: pop
@@ -384,8 +393,8 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
           sp--;
           // the LDS read is unconditional (a clamped index), the spill read the rare exception: one ds_read instead of a
           // flat load behind an address select
-          next = stk_base[(uint32_t)(sp < kPvLdsStack ? sp : kPvLdsStack - 1) * stride];
-          if (sp >= kPvLdsStack) next = spill[(uint32_t)(sp - kPvLdsStack) * spill_stride];
+          next = stk_base[(uint32_t)(sp < kLds ? sp : kLds - 1) * stride];
+          if (sp >= kLds) next = spill[(uint32_t)(sp - kLds) * spill_stride];
         }
       }
       if (advance) {
@@ -394,7 +403,7 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
           const uint32_t first = (next & 0x3FFFFFFFu) >> 3;
           rem = next & 7u;
           state = (CURVES && (next & kCurveBit)) ? kStCurve : kStTri;
-          if (WIDE) cur = (CURVES && (next & kCurveBit)) ? sc.q_pt0 + first : sc.q_tri0 + 4u * first;
+          if (WIDE) cur = (CURVES && (next & kCurveBit)) ? sc.q_pt0 + first : sc.q_tri0 + 3u * first;
           else cur = first + slot0;  // slots follow the nodes in one array of 64-byte items
         } else {
           cur = WIDE ? 4u * next : next;

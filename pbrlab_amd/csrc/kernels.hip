@@ -154,7 +154,7 @@ using TraceSink = TraceSinkT<false>;
 
 template <bool STATS, bool CURVES, bool WIDE = false>
 __global__ __launch_bounds__(kBlock, trace_blocks_per_cu(CURVES, WIDE)) void k_trace(PathState P, DScene sc) {
-  __shared__ uint32_t stk[kPvLdsStack * kBlock];
+  __shared__ uint32_t stk[pv_lds_stack<CURVES, WIDE>() * kBlock];
   __shared__ float frm[CURVES ? 10 * kBlock : 1];
   // the top of the tree in LDS (triangle-only scenes: with the ribbon frames of curve scenes it would cost a block per CU)
   constexpr bool kStageTop = !CURVES && !WIDE && kTopNodes > 0;
@@ -1018,7 +1018,7 @@ struct WalkSink {
 #endif
 template <bool STATS, bool CURVES, bool WIDE = false>
 __global__ __launch_bounds__(kBlock, PB_WALK_WAVES) void k_sss_walk(PathState P, DScene sc, uint64_t rng_inc) {
-  __shared__ uint32_t stk[kPvLdsStack * kBlock];
+  __shared__ uint32_t stk[pv_lds_stack<CURVES, WIDE>() * kBlock];
   __shared__ float frm[CURVES ? 10 * kBlock : 1];
   __shared__ float walk[9 * kBlock];
   const uint32_t n = P.counts[kCntSss];
@@ -1239,7 +1239,7 @@ struct HookSink {
 template <bool ANY, bool CURVES, bool WIDE>  // CURVES / WIDE: the variant k_trace runs for this scene (the Q tree, with or without curves)
 __global__ __launch_bounds__(kBlock) void k_hook_pv(DScene sc, const float4* __restrict__ rays, uint32_t n, HookHit* hits,
                                                     uint8_t* occ, uint32_t* counts, uint32_t* spill) {
-  __shared__ uint32_t stk[kPvLdsStack * kBlock];
+  __shared__ uint32_t stk[pv_lds_stack<CURVES, WIDE>() * kBlock];
   __shared__ float frm[CURVES ? 10 * kBlock : 1];
   TravStats st = {};
   uint32_t overflow = 0u;
@@ -1328,7 +1328,17 @@ void launch_trace(hipStream_t s, const PathState& P, const DScene& sc, uint32_t 
   uint32_t blocks = (n_upper + 4u * rays_per_wave - 1u) / (4u * rays_per_wave);
   const bool curves = sc.num_curves != 0 || getenv("PBRHIP_FORCE_CURVES") != nullptr;
   const bool wide = use_wide(sc);
-  const uint32_t cap = 256u * trace_blocks_per_cu(curves, wide);
+  uint32_t cap = 256u * trace_blocks_per_cu(curves, wide);
+  if (const char* b = getenv("PBRHIP_TRACE_BLOCKS")) {  // (tuning knob, read per launch: resident blocks per CU, at most the kernel's)
+    const uint32_t k = (uint32_t)strtoul(b, nullptr, 10);
+    if (k >= 1u && 256u * k < cap) cap = 256u * k;
+  }
+  if (const char* b = getenv("PBRHIP_TRACE_BLOCKS_SMALL")) {  // "k,n": k blocks per CU for launches of at most n rays
+    char* end = nullptr;
+    const uint32_t k = (uint32_t)strtoul(b, &end, 10);
+    const uint32_t lim = (end && *end == ',') ? (uint32_t)strtoul(end + 1, nullptr, 10) : 0u;
+    if (k >= 1u && n_upper <= lim && 256u * k < cap) cap = 256u * k;
+  }
   dim3 g(blocks < 1u ? 1u : (blocks < cap ? blocks : cap));
   if (stats) PB_LAUNCH_TRAV(k_trace, true, curves, wide, g, dim3(kBlock), 0, s, P, sc);
   else PB_LAUNCH_TRAV(k_trace, false, curves, wide, g, dim3(kBlock), 0, s, P, sc);

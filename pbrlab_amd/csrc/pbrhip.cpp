@@ -680,10 +680,9 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
       const uint32_t g = bvh.slot_gid[k];
       const uint32_t code = k | __builtin_bit_cast(uint32_t, slots[4 * (size_t)k + 2].w);
       if (prims[g].kind == 0) {
-        tri_rank[k] = (uint32_t)(qtri.size() / 4);
-        for (int c = 0; c < 4; c++) qtri.push_back(slots[4 * (size_t)k + c]);
-        qtri.back() = make_float4(0.f, 0.f, 0.f, 0.f);
-        qtri[qtri.size() - 2].w = __builtin_bit_cast(float, code);
+        tri_rank[k] = (uint32_t)(qtri.size() / 3);  // 48 bytes per triangle: three corners, the hit code in the third word's .w
+        for (int c = 0; c < 3; c++) qtri.push_back(slots[4 * (size_t)k + c]);
+        qtri.back().w = __builtin_bit_cast(float, code);
       } else {
         qhit[piece_point[g]] = code;
       }
@@ -715,7 +714,7 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
     if (qpts.size() >= (1u << 27) || build_qtree(bvh.nodes, map_leaf, &wide) > (uint32_t)kStackDepth) wide.clear();
   }
   if (wide.empty()) s->d_wide.release(), s->d_qhit.release();
-  if (getenv("PBRHIP_DEBUG")) fprintf(stderr, "pbrhip: commit: %u binary nodes, %zu wide nodes, %zu slots, %zu triangle slots + %zu points in the Q tree\n", num_nodes, wide.size(), (size_t)ns, qtri.size() / 4, qpts.size());
+  if (getenv("PBRHIP_DEBUG")) fprintf(stderr, "pbrhip: commit: %u binary nodes, %zu wide nodes, %zu slots, %zu triangle slots + %zu points in the Q tree\n", num_nodes, wide.size(), (size_t)ns, qtri.size() / 3, qpts.size());
   if (!wide.empty()) {
     HIPCHK(s->d_wide.reserve(wide.size() * 4 + qtri.size() + qpts.size()));
     HIPCHK(hipMemcpyAsync(s->d_wide.p, wide.data(), wide.size() * sizeof(QNode), hipMemcpyHostToDevice, st));
