@@ -289,7 +289,8 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
           advance = true;
           have_next = k[0] != kWideMiss;
           next = ref_of(k[0]);
-          if (k[1] != kWideMiss) {  // the other hit children go on the stack, farthest first
+          if (!CURVES && k[1] != kWideMiss) {  // the other hit children go on the stack, farthest first
+            // (triangle-only scenes: shallow trees, the LDS part of the stack nearly always has room)
             if (sp + 3 <= kLds) {
               // (an entry written for a child that was not hit lies above the new top or is overwritten by the next one)
               uint32_t p = (uint32_t)sp;
@@ -314,6 +315,28 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
                   *overflow = 1u;
                 }
               }
+            }
+          } else if (k[1] != kWideMiss) {
+            const uint32_t r3 = ref_of(k[3]), r2 = ref_of(k[2]), r1 = ref_of(k[1]);
+            const uint32_t p3 = (uint32_t)sp, p2 = p3 + ((k[3] != kWideMiss) ? 1u : 0u), p1 = p2 + ((k[2] != kWideMiss) ? 1u : 0u);
+            // ONE of the two paths per wave: a wave whose lanes sit on both sides of the LDS / spill boundary used to run both
+            // every node turn (hair: trees 14-16 levels deep, up to three entries per level)
+            if (__ballot(p1 >= (uint32_t)kLds) == 0ull) {
+              // (an entry written for a child that was not hit lies above the new top or is overwritten by the next one)
+              stk_base[p3 * stride] = r3;
+              stk_base[p2 * stride] = r2;
+              stk_base[p1 * stride] = r1;
+              sp = (int)p1 + 1;
+            } else {
+              auto put = [&](uint32_t pos, uint32_t ref) {
+                if (pos < (uint32_t)kLds) stk_base[pos * stride] = ref;
+                else if (pos < (uint32_t)kStackDepth) spill[(pos - (uint32_t)kLds) * spill_stride] = ref;
+                else *overflow = 1u;
+              };
+              if (k[3] != kWideMiss) put(p3, r3);
+              if (k[2] != kWideMiss) put(p2, r2);
+              put(p1, r1);
+              sp = (int)(p1 + 1u < (uint32_t)kStackDepth ? p1 + 1u : (uint32_t)kStackDepth);
             }
           }
         } else if (state == kStNode) {

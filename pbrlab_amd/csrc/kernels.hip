@@ -1326,7 +1326,7 @@ void launch_trace(hipStream_t s, const PathState& P, const DScene& sc, uint32_t 
   const char* e = getenv("PBRHIP_RAYS_PER_WAVE");  // (tuning knob; read per launch)
   const uint32_t rays_per_wave = e ? (uint32_t)strtoul(e, nullptr, 10) : 4u;
   uint32_t blocks = (n_upper + 4u * rays_per_wave - 1u) / (4u * rays_per_wave);
-  const bool curves = sc.num_curves != 0 || getenv("PBRHIP_FORCE_CURVES") != nullptr;
+  const bool curves = sc.num_curves != 0;
   const bool wide = use_wide(sc);
   uint32_t cap = 256u * trace_blocks_per_cu(curves, wide);
   if (const char* b = getenv("PBRHIP_TRACE_BLOCKS")) {  // (tuning knob, read per launch: resident blocks per CU, at most the kernel's)

@@ -9,15 +9,33 @@ def table(lib):
     subprocess.run([llvm + "/llvm-objcopy", f"--dump-section=.hip_fatbin={fat}", lib], check=True, capture_output=True)
     subprocess.run([llvm + "/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fat}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True, capture_output=True)
     notes = subprocess.run([llvm + "/llvm-readelf", "--notes", co], check=True, capture_output=True, text=True).stdout
-    tb, cur = {}, {}
+    tb = {}
+    # one YAML map per kernel, keys in alphabetical order (.group_segment_fixed_size comes before .name): collect a block, file it at .symbol
+    cur = {}
     for line in notes.splitlines():
-        m = re.match(r"\s+\.(name|vgpr_count|sgpr_count|private_segment_fixed_size|group_segment_fixed_size):\s+(\S+)", line)
+        m = re.match(r"\s+(?:- )?\.(name|symbol|vgpr_count|sgpr_count|private_segment_fixed_size|group_segment_fixed_size):\s+(\S+)", line)
+        if not m:
+            continue
+        if m.group(1) == "symbol":
+            if "name" in cur:
+                tb[cur.pop("name")] = cur
+            cur = {}
+        elif m.group(1) == "name":
+            cur["name"] = m.group(2)      # (argument names come first and are overwritten by the kernel's own)
+        else:
+            cur[m.group(1)] = int(m.group(2))
+            if m.group(1) == "vgpr_count" and "name" in cur and cur["name"].startswith("_Z"):
+                pass
+    # .vgpr_count / .wavefront_size follow .symbol: second pass for them
+    name = None
+    for line in notes.splitlines():
+        m = re.match(r"\s+(?:- )?\.(name|vgpr_count):\s+(\S+)", line)
         if not m:
             continue
         if m.group(1) == "name":
-            cur = tb.setdefault(m.group(2), {})
-        else:
-            cur[m.group(1)] = int(m.group(2))
+            name = m.group(2)
+        elif name in tb:
+            tb[name]["vgpr_count"] = int(m.group(2))
     dem = subprocess.run(["c++filt"] + list(tb), check=True, capture_output=True, text=True).stdout.split("\n")
     return {d.replace("void pb::", "").replace("pb::", "").split("(")[0]: v for d, v in zip(dem, tb.values())}
 
