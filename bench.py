@@ -81,6 +81,60 @@ def pmc_record(workload, spp, world, kernel):
     return k, rec.get("source", "")
 
 
+PMC_PASSES = ["FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY"]
+
+
+def pmc_live(workload, spp, kernel, budget_s):
+    """The counters of `kernel` measured by THIS run: rocprofv3 --pmc passes (counters only: no trace flag next to --pmc, one
+    pass per counter group as MI355X_MICROARCH.md prescribes; FETCH_SIZE / WRITE_SIZE apart) over one render of the workload as
+    one path group in child processes (scripts/render_once.py: the program itself after `--`), after the timed region.
+    Returns (record like profiles/r3_<workload>_pmc.json's kernel entry, note) or (None, why) -- the caller then falls back
+    to the committed record."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    variant = {"c2": "ggx", "c3": "sss", "c4": "hair"}.get(workload)
+    if variant is None or not os.path.exists(exe):
+        return None, "no live PMC passes (rocprofv3 not found or no single-scene workload)"
+    t0 = time.time()
+    env = dict(os.environ, TMPDIR="/tmp", VARIANT=variant, SPP=str(spp), PBRHIP_STREAMS="1", REPS="1")
+    agg, disp = collections.defaultdict(float), set()
+    tmp = tempfile.mkdtemp(prefix="pbr_pmc_", dir="/tmp")
+    try:
+        for i, counters in enumerate(PMC_PASSES):
+            left = budget_s - (time.time() - t0)
+            if left < 20:
+                return None, f"live PMC passes over budget ({budget_s} s)"
+            d = os.path.join(tmp, f"p{i}")
+            cmd = [exe, "--pmc"] + counters.split() + ["-f", "csv", "-d", d, "-o", f"p{i}", "--", sys.executable, os.path.join(ROOT, "scripts", "render_once.py")]
+            try:
+                r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=left)
+            except subprocess.TimeoutExpired:
+                return None, f"live PMC pass {counters.split()[0]} timed out"
+            if r.returncode != 0:
+                return None, f"live PMC pass {counters.split()[0]} failed (rc {r.returncode})"
+            for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if not row["Kernel_Name"].split("(")[0].replace("void ", "").startswith(kernel):
+                        continue
+                    agg[row["Counter_Name"]] += float(row["Counter_Value"])
+                    if i == 0:
+                        disp.add(row["Dispatch_Id"])
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    if not disp or "FETCH_SIZE" not in agg or "SQ_INSTS_VALU" not in agg:
+        return None, "live PMC passes returned no rows for the kernel"
+    rec = dict(agg)
+    rec["dispatches"] = len(disp)
+    rec["hbm_bytes_per_dispatch_fetch_x2"] = (2 * agg["FETCH_SIZE"] + agg.get("WRITE_SIZE", 0.0)) * 1024 / len(disp)
+    return rec, (f"measured by this run: rocprofv3 --pmc passes {[p.split()[0] for p in PMC_PASSES]} over one {spp}-spp render of the workload "
+                 f"(one path group, child processes, after the timed region, {time.time() - t0:.0f} s); FETCH_SIZE / WRITE_SIZE in KiB, FETCH_SIZE x2 on gfx950")
+
+
 def make_desc(w):
     from pbrlab_amd import scenes
     if w["scene"] == "cornell":
@@ -171,6 +225,8 @@ def main():
     ap.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)   # internal: one oracle build, one JSON line
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help=argparse.SUPPRESS)
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-live-pmc", action="store_true", help="take roofline.traffic / valu from the committed PMC record instead of measuring them in this run")
+    ap.add_argument("--pmc-budget", type=float, default=150.0, help="seconds the live rocprofv3 --pmc passes may take in all")
     ap.add_argument("--max-paths", type=int, default=0)
     ap.add_argument("--streams", type=int, default=0, help="concurrent path groups (0 = the library's default)")
     ap.add_argument("--shard-block", type=int, default=16,
@@ -329,7 +385,13 @@ def main():
             solo_launch_s = solo_ms * 1e-3 / max(solo["n_trace_closest"], 1)
             # counter-based ceilings, from this round's committed PMC passes on these very kernel sources (else null)
             default_cfg = not (args.max_paths or args.streams or args.spp)
-            pmc, pmc_note = pmc_record(args.workload, spp, world, "pb::k_trace<false") if default_cfg else (None, "non-default configuration")
+            pmc, pmc_note = (None, "non-default configuration")
+            if default_cfg and world == 1 and not args.no_live_pmc:
+                pmc, pmc_note = pmc_live(args.workload, spp, "pb::k_trace<false", args.pmc_budget)
+            if pmc is None and default_cfg:
+                live_note = pmc_note
+                pmc, pmc_note = pmc_record(args.workload, spp, world, "pb::k_trace<false")
+                pmc_note = f"{pmc_note} [committed record; {live_note}]" if pmc else f"{pmc_note}; {live_note}"
             traffic = frac_hbm_counter = valu = None
             bound = "hbm"
             if pmc:

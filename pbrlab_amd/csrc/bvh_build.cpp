@@ -238,8 +238,8 @@ void build_bvh(const std::vector<float>& lo, const std::vector<float>& hi, const
   out->depth = depth;
 }
 
-// Quantises the boxes of up to four children into a QNode (dscene.h).  Per axis: step s = the smallest power of two with
-// (extent / s) + 2 <= 255, org = the node's lower bound rounded down; a child's bounds are rounded outwards on that grid and
+// Quantises the boxes of up to four children into a QNode (dscene.h).  Per axis: step s = extent / 253, org = the node's
+// lower bound; a child's bounds are rounded outwards on that grid and
 // then checked -- and moved out further if need be -- with the expression the traversal evaluates, fmaf(q, s, org) in single
 // precision; when the grid is too fine for that arithmetic (a step below the resolution of org) the step doubles.
 static bool quantise_node(const QChild* c, int n, QNode* nd) {
@@ -249,9 +249,8 @@ static bool quantise_node(const QChild* c, int n, QNode* nd) {
     float lo = std::numeric_limits<float>::infinity(), hi = -lo;
     for (int i = 0; i < n; i++) lo = std::min(lo, c[i].lo[a]), hi = std::max(hi, c[i].hi[a]);
     if (!(lo <= hi) || !std::isfinite(lo) || !std::isfinite(hi)) return false;
-    int e;
-    frexpf(std::max((hi - lo) / 253.0f, 1.1754944e-38f), &e);  // 2^(e-1) <= x < 2^e
-    float sc = ldexpf(1.0f, e);
+    // (the step need not be a power of two: fmaf(q, s, org) rounds once whatever s is, and the result is checked below)
+    float sc = std::max(nextafterf((hi - lo) / 253.0f, std::numeric_limits<float>::infinity()), 1.1754944e-38f);
     for (int tries = 0;; tries++) {
       if (tries > 40 || !std::isfinite(sc)) return false;
       const float org = lo;
@@ -276,7 +275,7 @@ static bool quantise_node(const QChild* c, int n, QNode* nd) {
         *qw[a] = wl, *qw[3 + a] = wh;
         break;
       }
-      sc *= 2.0f;
+      sc *= tries < 8 ? 1.03125f : 2.0f;
     }
   }
   return true;
@@ -356,7 +355,7 @@ uint32_t build_qtree(const std::vector<BvhNode>& N2, const std::function<int(uin
   };
   // Which descendants become the (up to four) children of the Q node of a vertex v is chosen bottom-up over the surface-area
   // cost, with the box a child really presents to a ray: its box rounded outwards on the 8-bit grid of v (step = extent of v /
-  // 253 rounded up to a power of two).  That looseness is what matters for thin primitives in big nodes -- a wall triangle of
+  // 253 ).  That looseness is what matters for thin primitives in big nodes -- a wall triangle of
   // the Cornell box as a child of a node two units wide is a slab 0.016 thick, and every ray that starts on the wall tests it:
   // with plain areas the collapse put such leaves high up and a shadow ray tested 2.7 triangles instead of 0.9.
   //   below[v] = min over the frontiers F below v, |F| <= 4, of  sum_{u in F} qarea(u | v) * (u leaf ? prims : 1) + below[u]
@@ -369,9 +368,7 @@ uint32_t build_qtree(const std::vector<BvhNode>& N2, const std::function<int(uin
     double e[3];
     for (int a = 0; a < 3; a++) {
       const double ext = (double)v.hi[a] - (double)v.lo[a];
-      int ex;
-      frexp(std::max(ext / 253.0, 1e-37), &ex);
-      const double st = ldexp(1.0, ex);
+      const double st = std::max(ext / 253.0, 1e-37);
       const double ql = floor(((double)u.lo[a] - (double)v.lo[a]) / st), qh = ceil(((double)u.hi[a] - (double)v.lo[a]) / st);
       e[a] = std::max(qh - ql, 0.0) * st;
     }

@@ -4,7 +4,7 @@ args=()
 while [ "$1" != "--" ] && [ $# -gt 0 ]; do args+=("$1"); shift; done
 shift
 for lib in "$@"; do
-  PBRHIP_LIB=$(realpath $lib) python bench.py --no-cpu-baseline "${args[@]}" 2>&1 | tail -1 | python -c "
+  PBRHIP_LIB=$(realpath $lib) python bench.py --no-cpu-baseline --no-live-pmc "${args[@]}" 2>&1 | tail -1 | python -c "
 import sys, json
 d = json.loads(sys.stdin.read())
 r = d.get('roofline') or {}

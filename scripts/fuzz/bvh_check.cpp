@@ -113,8 +113,7 @@ int main() {
         if (nd.c[c] == kEmptyChild) continue;
         float bl[3], bh[3];
         for (int a = 0; a < 3; a++) {
-          int e;
-          if (frexpf(sc[a], &e) != 0.5f) return printf("FAIL: step is not a power of two\n"), 1;
+          if (!(sc[a] > 0.f) || !std::isfinite(sc[a])) return printf("FAIL: step\n"), 1;
           bl[a] = fmaf((float)((ql[a] >> (8 * c)) & 255u), sc[a], nd.org[a]), bh[a] = fmaf((float)((qh[a] >> (8 * c)) & 255u), sc[a], nd.org[a]);
         }
         auto check_prim = [&](uint32_t g) {

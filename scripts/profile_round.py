@@ -76,7 +76,7 @@ def main():
         d = os.path.join(tmp, "stats")
         shutil.rmtree(d, ignore_errors=True)
         cmd = ["rocprofv3", "--kernel-trace", "--stats", "-f", "csv", "-d", d, "-o", "ks", "--", "python3", os.path.join(ROOT, "bench.py"),
-               "--workload", wl, "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+               "--workload", wl, "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-live-pmc"]  # (no profiler inside the profiler)
         r = subprocess.run(cmd, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp", capture_output=True, text=True, timeout=1500)
         print("kernel-trace: rc", r.returncode, r.stdout.strip().splitlines()[-1][:300] if r.stdout.strip() else r.stderr[-500:])
         for f in glob.glob(d + "/**/*kernel_stats.csv", recursive=True):

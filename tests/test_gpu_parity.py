@@ -658,6 +658,38 @@ def test_curve_soup(pa, seed):
         assert np.array_equal(sg.trace_any(short), so.trace_any(short, brute_force=True))
 
 
+def test_curves_only_scene_on_both_trees(pa):
+    """a scene without a single triangle (the Q tree then has no triangle slots, only chains of points): hits equal the
+    oracle's brute force on both trees and both traversals; the frame (no emitter: black, but every path is traced) too"""
+    from pbrlab_amd import scenes
+    d = scenes.hair_scene(n_strands=300, n_segments=6, head_subdiv=1)
+    desc = scenes.SceneDesc(np.zeros((0, 4), np.float32), np.zeros((0, 4), np.float32), d.materials, [], d.curves)
+    so, sg = O.oracle_scene_from_desc(desc), pa.scene_from_desc(desc)
+    lo, hi = so.FetchSceneAABB()
+    glo, ghi = sg.FetchSceneAABB()
+    assert np.array_equal(lo, glo) and np.array_equal(hi, ghi)
+    rays = scenes.random_rays((lo, hi), 20000, seed=3)
+    hb = so.trace_closest(rays, brute_force=True)
+    assert (hb["instance_id"] != 0xFFFFFFFF).sum() > 2000
+    for wide in ("1", "0"):
+        os.environ["PBRHIP_WIDE"] = wide
+        try:
+            for simple in (False, True):
+                if simple:
+                    os.environ["PBRHIP_SIMPLE_TRAVERSAL"] = "1"
+                assert_hits_equal(sg.trace_closest(rays), hb)
+                assert np.array_equal(sg.trace_any(rays), so.trace_any(rays, brute_force=True))
+            os.environ.pop("PBRHIP_SIMPLE_TRAVERSAL", None)
+            lay = pa.RenderLayer()
+            ok, st = pa.Render(sg, 64, 48, 3, layer=lay, flags=pa.api.RENDER_STATS)
+            rgba, cnt, ost = so.render(64, 48, 3, threads=4, math_mode=O.MATH_F64R)
+            assert lay.rgba.tobytes() == rgba.tobytes() and np.array_equal(lay.count, cnt)
+            assert st["closest_rays"] + st["tail_closest_rays"] + st["pruned_rays"] == ost["closest_rays"] and st["closest_tris"] == 0
+        finally:
+            os.environ.pop("PBRHIP_WIDE", None)
+            os.environ.pop("PBRHIP_SIMPLE_TRAVERSAL", None)
+
+
 def _mini_scene(shapes_spec, materials):
     """shapes_spec: list of (name, verts (n,3), faces (m,3), material index)"""
     from pbrlab_amd import scenes
