@@ -423,13 +423,16 @@ uint32_t build_qtree(const std::vector<BvhNode>& N2, const std::function<int(uin
     int32_t v;
     uint32_t out;
   };
-  std::vector<Item> work;
+  // numbering: breadth first for the first kTopNodes nodes (the top of the tree is one contiguous block that the traversal
+  // kernel of triangle-only scenes copies into LDS: dscene.h), depth first below; a node's inner children get consecutive numbers
+  std::deque<Item> work;
   out->emplace_back();
   work.push_back({0, 0u});
   uint32_t levels = 0;
   while (!work.empty()) {
-    const Item it = work.back();
-    work.pop_back();
+    Item it;
+    if (out->size() < (size_t)kTopNodes) it = work.front(), work.pop_front();
+    else it = work.back(), work.pop_back();
     int32_t fr[4];
     int n = 0;
     if (T[it.v].l < 0) {

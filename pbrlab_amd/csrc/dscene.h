@@ -192,6 +192,7 @@ struct DScene {
   uint32_t q_tri0, q_pt0;       // 16-byte index of triangle slot 0 / point 0 in `wide`
   const uint32_t* q_hitcode;    // per point p: the hit code of piece p (slot | routing bits)
   uint32_t top_nodes;           // nodes 0 .. top_nodes-1 are the breadth-first top of the tree (<= kTopNodes; 0: not numbered that way)
+  uint32_t wide_top_nodes;      // the same for the Q tree
   uint32_t lights_transformed;  // an emissive instance has a transform: lrecs / light_boxes are not what the raytracer sees
 };
 

@@ -435,10 +435,15 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
       }
     }
     if (WIDE && need_load) {
-      const float4* g = items + cur;
-      D0 = g[0], D1 = g[1];
-      if (!CURVES || state != kStCurve) D2 = g[2];
-      if (state == kStNode) D3w = g[3];
+      if (!CURVES && kTopNodes > 0 && cur < 4u * ntop) {  // the top of the Q tree (triangle-only scenes): every ray passes through it
+        const float4* g = top + cur;
+        D0 = g[0], D1 = g[1], D2 = g[2], D3w = g[3];
+      } else {
+        const float4* g = items + cur;
+        D0 = g[0], D1 = g[1];
+        if (!CURVES || state != kStCurve) D2 = g[2];
+        if (state == kStNode) D3w = g[3];
+      }
     } else if (need_load) {
       if (kTopNodes > 0 && cur < ntop) {  // the top of the tree: every ray passes through it
         const float4* g = top + cur * 4u;

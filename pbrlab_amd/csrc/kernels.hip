@@ -157,11 +157,11 @@ __global__ __launch_bounds__(kBlock, trace_blocks_per_cu(CURVES, WIDE)) void k_t
   __shared__ uint32_t stk[pv_lds_stack<CURVES, WIDE>() * kBlock];
   __shared__ float frm[CURVES ? 10 * kBlock : 1];
   // the top of the tree in LDS (triangle-only scenes: with the ribbon frames of curve scenes it would cost a block per CU)
-  constexpr bool kStageTop = !CURVES && !WIDE && kTopNodes > 0;
+  constexpr bool kStageTop = !CURVES && kTopNodes > 0;
   __shared__ float4 top[kStageTop ? kTopNodes * 4 : 1];
-  const uint32_t ntop = kStageTop ? sc.top_nodes : 0u;
+  const uint32_t ntop = kStageTop ? (WIDE ? sc.wide_top_nodes : sc.top_nodes) : 0u;
   if (kStageTop) {
-    const float4* src = reinterpret_cast<const float4*>(sc.nodes);
+    const float4* src = WIDE ? sc.wide : reinterpret_cast<const float4*>(sc.nodes);  // (binary node and Q node: 64 bytes each)
     for (uint32_t i = threadIdx.x; i < ntop * 4u; i += kBlock) top[i] = src[i];
     __syncthreads();
   }

@@ -755,6 +755,7 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
   d.wide = wide.empty() ? nullptr : s->d_wide.p, d.wide_nodes = (uint32_t)wide.size();
   d.q_tri0 = (uint32_t)wide.size() * 4u, d.q_pt0 = d.q_tri0 + (uint32_t)qtri.size(), d.q_hitcode = wide.empty() ? nullptr : s->d_qhit.p;
   d.top_nodes = gpu_built ? 0u : std::min<uint32_t>(num_nodes, (uint32_t)kTopNodes);
+  d.wide_top_nodes = std::min<uint32_t>((uint32_t)wide.size(), (uint32_t)kTopNodes);
   // light sampling works on the meshes' local positions (light-manager.h:128-136 "TODO transform"), the raytracer on the
   // transformed ones: the doomed-path pretest against the light primitives (kernels.hip::misses_all_lights) is only the
   // traversal's own test when the two coincide
