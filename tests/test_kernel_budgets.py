@@ -26,6 +26,15 @@ BUDGETS = {
     "k_sss_walk<false, true, false>": (168, 0),
     "k_sss_walk<false, true, true>": (168, 0),
     "k_shade_principled<true>": (168, 0),
+    # the kernels below keep scratch at three waves per SIMD, measured against two waves without it (profiles/README.md: the
+    # general shading kernel alone is 9 % faster at two, the C3 frame 2 % slower; k_tail likewise in round 2): pinned as they are
+    "k_shade_principled<false>": (168, 120),
+    "k_tail<false, false, true>": (168, 176),
+    "k_tail<false, true, true>": (168, 176),
+    "k_tail<false, false, false>": (168, 176),
+    "k_tail<false, true, false>": (168, 176),
+    "k_shade_hair": (136, 0),
+    "k_sss_step": (160, 0),
     "k_classify": (64, 0),
     "k_compact": (96, 0),
 }
