@@ -155,7 +155,12 @@ struct alignas(16) Material {
   PrincipledBsdf bsdf;  // kMatPrincipled without textures: ParamToBsdf hoisted to commit time
   HairBsdf hair;        // kMatHair: everything except h (= hit v), hair-shader.cc:100-151
   PrincipledParam param;  // raw parameters (used when textured)
+  // kMatPrincipled without textures: the medium of the random walk, from the closure set at commit (dshade.h::medium_coefficients;
+  // host and device evaluate the same f64r exp): sigma_t, sigma_s, first walk throughput -- nine consecutive words
+  V3 sss_sigt, sss_sigs, sss_wthr;
+  uint32_t pad2[3];
 };
+static_assert(sizeof(Material) % 16 == 0, "material records are read with 16-byte loads");
 
 struct TexDesc {  // pbrlab::Texture (src/texture.h:13-44): float pixels, row-major, interleaved channels
   uint32_t offset, width, height, channels;

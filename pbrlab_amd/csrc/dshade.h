@@ -376,6 +376,13 @@ PB_HD void scattering_from_albedo(float A, float d, float& sigma_t, float& sigma
   sigma_t = 1.0f / smax(d * s, 1e-16f);
   sigma_s = sigma_t * a;
 }
+// the medium a closure set describes and the walk's first throughput (random-walk-sss.h:111-122, 243-258)
+PB_HD void medium_coefficients(const PrincipledBsdf& b, V3& sigt, V3& sigs, V3& wthr) {
+  scattering_from_albedo(b.subsurface_albedo.x, b.subsurface_radius.x, sigt.x, sigs.x);
+  scattering_from_albedo(b.subsurface_albedo.y, b.subsurface_radius.y, sigt.y, sigs.y);
+  scattering_from_albedo(b.subsurface_albedo.z, b.subsurface_radius.z, sigt.z, sigs.z);
+  wthr = safe_divide_spectrum(b.subsurface_weight, b.subsurface_albedo);
+}
 // SampleScatterDistance + SampleChannel (:141-188)
 // the channel pdf is a function of (walk throughput, sigma_s, sigma_t) alone: the step that consumes it recomputes it from the
 // stored throughput instead of keeping it in the path state

@@ -96,7 +96,7 @@ bool trace_uses_wide(const DScene& sc);  // the traversal kernels walk the 4-wid
 void launch_tail(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc, bool stats);
 void launch_classify(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper);
 void launch_compact(hipStream_t s, const PathState& P, uint32_t n_upper);
-void launch_shade_principled(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc, bool plain);
+void launch_shade_principled(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc, bool media, bool textured);
 void launch_shade_hair(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc);
 void launch_sss_step(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc);
 void launch_sss_walk(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc, bool stats);

@@ -496,10 +496,11 @@ __device__ __forceinline__ bool stage_light_tables(const DScene& sc, float* lds)
 // ------------------------------------------------------------------ k_shade_principled
 // CyclesPrincipledShader (cycles-principled-shader.cc:414-484) + the tail of GetRadiance (render.cc:76-87).
 // One path; returns the result bits (kRShadow | kRAlive | kQSssBit | kQDoomed) its caller stores or acts on.
-// PLAIN: the scene has no material that can enter a medium and no textured material (neither branch can be taken), so that
-// code -- and the registers it holds -- is compiled out of the wavefront kernel.
-// lds_bsdf: the scene's closure sets staged in LDS by the caller (k_shade_principled<PLAIN> when they fit), or null
-template <bool PLAIN = false>
+// lds_bsdf: the scene's closure sets staged in LDS by the caller (k_shade_principled when they fit), or null
+// MODE (what the scene's materials can do, so that code no hit can reach -- and the registers it holds -- is compiled out of the
+// wavefront kernel): kShadePlain: no medium, no texture; kShadeMedia: media (random-walk subsurface), no texture; kShadeFull.
+enum : int { kShadePlain = 0, kShadeMedia = 1, kShadeFull = 2 };
+template <int MODE = kShadeFull>
 __device__ __forceinline__ uint32_t shade_principled_path(const PathState& P, const DScene& sc, uint32_t p, uint64_t rng_inc, bool first,
                                                           const PrincipledBsdf* lds_bsdf = nullptr, const float* lds_lights = nullptr) {
   {
@@ -534,7 +535,8 @@ __device__ __forceinline__ uint32_t shade_principled_path(const PathState& P, co
         } else {
           b = sc.materials[s.material].bsdf;
         }
-        if (!PLAIN && sc.materials[s.material].textured) {  // ParamToBsdf per hit (cycles-principled-shader.cc:281-301)
+        const bool per_hit = MODE == kShadeFull && sc.materials[s.material].textured != 0u;
+        if (per_hit) {  // ParamToBsdf per hit (cycles-principled-shader.cc:281-301)
           const PrincipledParam mp = sc.materials[s.material].param;
           V3 bc(mp.base_color[0], mp.base_color[1], mp.base_color[2]);
           V3 ssc(mp.subsurface_color[0], mp.subsurface_color[1], mp.subsurface_color[2]);
@@ -571,7 +573,7 @@ __device__ __forceinline__ uint32_t shade_principled_path(const PathState& P, co
           float u0 = draw(rng);
           float u1 = draw(rng);
           ggx_sample(wo, b.clearcoat_alpha_x, b.clearcoat_alpha_y, u0, u1, wi);
-        } else if (PLAIN) {
+        } else if (MODE == kShadePlain) {
           sampled = false;  // unreachable: no material has a subsurface weight
         } else {
           // RandomWalkSubsurface entry (random-walk-sss.h:236-287)
@@ -587,11 +589,17 @@ __device__ __forceinline__ uint32_t shade_principled_path(const PathState& P, co
             V3 gdir = to_global(fr, tmp);
             ok = !(dot(-s.n_g, gdir) <= 0.0f);
             if (ok) {
-              V3 sigt, sigs;
-              scattering_from_albedo(b.subsurface_albedo.x, b.subsurface_radius.x, sigt.x, sigs.x);
-              scattering_from_albedo(b.subsurface_albedo.y, b.subsurface_radius.y, sigt.y, sigs.y);
-              scattering_from_albedo(b.subsurface_albedo.z, b.subsurface_radius.z, sigt.z, sigs.z);
-              V3 wthr = safe_divide_spectrum(b.subsurface_weight, b.subsurface_albedo);
+              // the medium's coefficients and the walk's first throughput (random-walk-sss.h:111-122, 243-258) depend on the
+              // closure set alone: for a material without textures they were computed at commit with these very functions
+              // (host and device share the f64r exp), otherwise they follow from this hit's closure set
+              V3 sigt, sigs, wthr;
+              if (per_hit) {
+                medium_coefficients(b, sigt, sigs, wthr);
+              } else {
+                const float4* mc = reinterpret_cast<const float4*>(&sc.materials[s.material].sss_sigt);
+                const float4 m0 = mc[0], m1 = mc[1], m2 = mc[2];
+                sigt = V3(m0.x, m0.y, m0.z), sigs = V3(m0.w, m1.x, m1.y), wthr = V3(m1.z, m1.w, m2.x);
+              }
               float e0 = draw(rng);
               float e1 = draw(rng);
               V3 chpdf;
@@ -660,8 +668,8 @@ constexpr uint32_t kLdsMats = PB_LDS_MATS;  // closure sets staged in LDS by the
 #ifndef PB_SHADE_WAVES_FULL
 #define PB_SHADE_WAVES_FULL 3  // the same for the general kernel (media, textured materials)
 #endif
-template <bool PLAIN>
-__global__ __launch_bounds__(kBlock, PLAIN ? PB_SHADE_WAVES : PB_SHADE_WAVES_FULL) void k_shade_principled(PathState P, DScene sc, uint64_t rng_inc) {
+template <int MODE>
+__global__ __launch_bounds__(kBlock, MODE == kShadePlain ? PB_SHADE_WAVES : PB_SHADE_WAVES_FULL) void k_shade_principled(PathState P, DScene sc, uint64_t rng_inc) {
   __shared__ PrincipledBsdf lds_bsdf[kLdsMats ? kLdsMats : 1];
   __shared__ float lds_lights[kLdsMats ? kLdsLightWords : 1];
   const bool lights_staged = kLdsMats && stage_light_tables(sc, lds_lights);
@@ -677,7 +685,7 @@ __global__ __launch_bounds__(kBlock, PLAIN ? PB_SHADE_WAVES : PB_SHADE_WAVES_FUL
   const uint32_t n = P.counts[kCntPrincipled];
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
     const uint32_t p = P.q_principled[i];
-    P.q_principled[i] = p | shade_principled_path<PLAIN>(P, sc, p, rng_inc, P.first != 0u, staged ? lds_bsdf : nullptr,
+    P.q_principled[i] = p | shade_principled_path<MODE>(P, sc, p, rng_inc, P.first != 0u, staged ? lds_bsdf : nullptr,
                                                          lights_staged ? lds_lights : nullptr);
   }
 }
@@ -1354,9 +1362,11 @@ void launch_classify(hipStream_t s, const PathState& P, const DScene& sc, uint32
 void launch_compact(hipStream_t s, const PathState& P, uint32_t n_upper) {
   hipLaunchKernelGGL(k_compact, dim3(tiles_grid(n_upper, kCompactItems)), dim3(kBlock), 0, s, P);
 }
-void launch_shade_principled(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc, bool plain) {
-  if (plain) hipLaunchKernelGGL(k_shade_principled<true>, dim3(grid_for(n_upper, kShadeGridCap)), dim3(kBlock), 0, s, P, sc, rng_inc);
-  else hipLaunchKernelGGL(k_shade_principled<false>, dim3(grid_for(n_upper, kShadeGridCap)), dim3(kBlock), 0, s, P, sc, rng_inc);
+void launch_shade_principled(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc, bool media, bool textured) {
+  const dim3 g(grid_for(n_upper, kShadeGridCap));
+  if (textured) hipLaunchKernelGGL(k_shade_principled<kShadeFull>, g, dim3(kBlock), 0, s, P, sc, rng_inc);
+  else if (media) hipLaunchKernelGGL(k_shade_principled<kShadeMedia>, g, dim3(kBlock), 0, s, P, sc, rng_inc);
+  else hipLaunchKernelGGL(k_shade_principled<kShadePlain>, g, dim3(kBlock), 0, s, P, sc, rng_inc);
 }
 void launch_shade_hair(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc) {
   hipLaunchKernelGGL(k_shade_hair, dim3(grid_for(n_upper, kShadeGridCap)), dim3(kBlock), 0, s, P, sc, rng_inc);

@@ -258,7 +258,7 @@ extern "C" int pbrhip_scene_replicate(const pbrhip_scene* src, int device, pbrhi
     // host side: what a committed scene still needs (material edits, bounds, flags); geometry stays with `src`
     s->materials = src->materials, s->light_params = src->light_params, s->tex_descs = src->tex_descs;
     s->lights = src->lights, s->light_cdf = src->light_cdf;
-    s->has_hair = src->has_hair, s->has_sss = src->has_sss;
+    s->has_hair = src->has_hair, s->has_sss = src->has_sss, s->has_textured = src->has_textured;
     memcpy(s->bmin, src->bmin, sizeof(s->bmin)), memcpy(s->bmax, src->bmax, sizeof(s->bmax));
     s->bvh_depth = src->bvh_depth, s->bvh_builder = src->bvh_builder, s->bvh_built_on_gpu = src->bvh_built_on_gpu;
     HIPCHK(hipSetDevice(device));

@@ -382,6 +382,7 @@ static Material make_material(const HostMaterial& hm) {
   if (hm.kind == kMatPrincipled) {
     m.bsdf = param_to_bsdf(hm.pr);
     m.param = hm.pr;
+    medium_coefficients(m.bsdf, m.sss_sigt, m.sss_sigs, m.sss_wthr);  // (only read when the subsurface closure is picked)
     m.textured = (hm.pr.base_color_tex_id != kNone || hm.pr.subsurface_color_tex_id != kNone) ? 1u : 0u;
   } else {
     m.hair = hair_param_to_bsdf(hm.hr);
@@ -619,14 +620,14 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
     sr.instance_id = pr.instance_id, sr.geom_id = pr.geom_id, sr.prim_id = pr.prim_id;
   }
   std::vector<Material> mats(s->materials.size());
-  s->has_hair = s->has_sss = false;
+  s->has_hair = s->has_sss = s->has_textured = false;
   for (size_t i = 0; i < mats.size(); i++) {
     const HostMaterial& hm = s->materials[i];
     if (hm.kind == kMatPrincipled)
       for (uint32_t t : {hm.pr.base_color_tex_id, hm.pr.subsurface_color_tex_id})
         if (t != kNone && t >= s->tex_descs.size()) return fail(PBRHIP_EINVAL, "material %zu: texture id %u out of range", i, t);
     mats[i] = make_material(s->materials[i]);
-    if (mats[i].textured) s->has_sss = true;  // a subsurface_color / base_color map can switch the SSS closure on per hit
+    if (mats[i].textured) s->has_sss = s->has_textured = true;  // a subsurface_color / base_color map can switch the SSS closure on per hit
     s->has_hair = s->has_hair || mats[i].kind == kMatHair;
     s->has_sss = s->has_sss || (mats[i].kind == kMatPrincipled && mats[i].bsdf.enable_subsurface);
   }
@@ -809,6 +810,7 @@ static int update_material(pbrhip_scene* s, uint32_t id, const HostMaterial& hm)
     HIPCHK(hipMemcpyAsync(s->d_materials.p + id, &m, sizeof(m), hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
     s->has_sss = s->has_sss || (m.kind == kMatPrincipled && (m.bsdf.enable_subsurface || m.textured));
+    s->has_textured = s->has_textured || (m.kind == kMatPrincipled && m.textured);
   }
   s->materials[id] = hm;
   return PBRHIP_OK;
@@ -1173,7 +1175,7 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
           launch_classify(gst, gr.P, sc, n);
           HIPCHK(gr.tm.end());
           HIPCHK(gr.tm.begin(&S.ms_shade_principled));
-          launch_shade_principled(gst, gr.P, sc, n, rng_inc, !s->has_sss);
+          launch_shade_principled(gst, gr.P, sc, n, rng_inc, s->has_sss, s->has_textured);
           HIPCHK(gr.tm.end());
           if (s->has_hair) {
             HIPCHK(gr.tm.begin(&S.ms_shade_hair));

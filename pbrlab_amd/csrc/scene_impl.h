@@ -86,7 +86,7 @@ struct pbrhip_scene {
   std::vector<float> tex_pixels;
   std::vector<pb::HostLight> lights;
   std::vector<float> light_cdf;
-  bool committed = false, has_hair = false, has_sss = false;
+  bool committed = false, has_hair = false, has_sss = false, has_textured = false;  // has_sss: a material can enter a medium (or is textured)
   float bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0};
   uint32_t bvh_depth = 0;
   int bvh_builder = PBRHIP_BVH_HOST_SAH;

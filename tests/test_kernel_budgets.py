@@ -25,10 +25,11 @@ BUDGETS = {
     "k_sss_walk<false, false, false>": (168, 0),
     "k_sss_walk<false, true, false>": (168, 0),
     "k_sss_walk<false, true, true>": (168, 0),
-    "k_shade_principled<true>": (168, 0),
+    "k_shade_principled<0>": (168, 0),           # no medium, no texture (C2, C4)
     # the kernels below keep scratch at three waves per SIMD, measured against two waves without it (profiles/README.md: the
     # general shading kernel alone is 9 % faster at two, the C3 frame 2 % slower; k_tail likewise in round 2): pinned as they are
-    "k_shade_principled<false>": (168, 120),
+    "k_shade_principled<1>": (168, 44),          # media, no texture (C3, C5): the medium's coefficients come from the material record
+    "k_shade_principled<2>": (168, 128),         # textured materials: ParamToBsdf and the medium per hit
     "k_tail<false, false, true>": (168, 176),
     "k_tail<false, true, true>": (168, 176),
     "k_tail<false, false, false>": (168, 176),
