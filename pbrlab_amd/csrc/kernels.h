@@ -93,7 +93,7 @@ void launch_generate(hipStream_t s, const PathState& P, const Camera& cam, const
                      uint32_t npaths, uint32_t slot0, uint32_t width, uint32_t first_pass, uint64_t seed_seq);
 void launch_trace(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, bool stats);
 bool trace_uses_wide(const DScene& sc);  // the traversal kernels walk the 4-wide tree of this scene (now: PBRHIP_WIDE is read per launch)
-void launch_tail(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc, bool stats);
+void launch_tail(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc, bool stats, bool media, bool textured);
 void launch_classify(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper);
 void launch_compact(hipStream_t s, const PathState& P, uint32_t n_upper);
 void launch_shade_principled(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc, bool media, bool textured);

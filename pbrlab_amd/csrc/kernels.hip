@@ -1065,7 +1065,8 @@ __global__ __launch_bounds__(kBlock, PB_WALK_WAVES) void k_sss_walk(PathState P,
 #define PB_TAIL_WAVES 3  // min waves per SIMD of k_tail (<= 168 VGPRs: three blocks per CU hold 196 k lanes, so every path of a 256 Ki tail starts at once;
                          // A/B on C2: 2 -> 59.1 ms per frame / 12.1 ms for an eighth, 3 -> 58.6 / 11.8)
 #endif
-template <bool STATS, bool CURVES, bool WIDE = false>
+// MODE: what the scene's materials can do (shade_principled_path): the branches no path can take are compiled out
+template <int MODE, bool STATS, bool CURVES, bool WIDE = false>
 __global__ __launch_bounds__(kBlock, PB_TAIL_WAVES) void k_tail(PathState P, DScene sc, uint64_t rng_inc) {
   __shared__ uint32_t stk[kSimpleLdsStack * kBlock];
   uint32_t* const spill = P.spill + blockIdx.x * kBlock + threadIdx.x;  // stack entries beyond the LDS part (the group's spill area: this grid is smaller than k_trace's)
@@ -1104,13 +1105,13 @@ __global__ __launch_bounds__(kBlock, PB_TAIL_WAVES) void k_tail(PathState P, DSc
       const uint32_t p = state & kQPathMask;
       uint32_t r = 0u;
       if (state & kHave) {
-        if (state & kMedium) {
+        if (MODE != kShadePlain && (state & kMedium)) {
           r = sss_step_path(P, sc, p, rng_inc);
         } else {
           const uint32_t slot = __float_as_uint(P.hit[p].w);
           if (slot != kNone)  // a miss ends the path (render.cc:34)
             r = (slot & kHitHair) ? shade_hair_path(P, sc, p, rng_inc, (state & kFirst) != 0u)
-                                  : shade_principled_path(P, sc, p, rng_inc, (state & kFirst) != 0u);
+                                  : shade_principled_path<MODE>(P, sc, p, rng_inc, (state & kFirst) != 0u);
         }
         state &= ~kFirst;
       }
@@ -1391,13 +1392,16 @@ void launch_accumulate(hipStream_t s, const PathState& P, const uint32_t* pix_in
 #ifndef PB_TAIL_BLOCKS
 #define PB_TAIL_BLOCKS 768u  // 3 blocks per CU (40 KB LDS stack each); A/B on C2: 256 -> 6.4 ms, 512 -> 5.4, 768 -> 4.8, 1024 -> 5.5
 #endif
-void launch_tail(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc, bool stats) {
+#define PB_COMMA ,
+void launch_tail(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc, bool stats, bool media, bool textured) {
   uint32_t blocks = (n_upper + 3u) / 4u;  // one path per wave while that fits, at most 2 blocks per CU
   dim3 g(blocks < 1u ? 1u : (blocks < PB_TAIL_BLOCKS ? blocks : PB_TAIL_BLOCKS));
   const bool curves = sc.num_curves != 0;
   const bool wide = use_wide(sc);
-  if (stats) PB_LAUNCH_TRAV(k_tail, true, curves, wide, g, dim3(kBlock), 0, s, P, sc, rng_inc);
-  else PB_LAUNCH_TRAV(k_tail, false, curves, wide, g, dim3(kBlock), 0, s, P, sc, rng_inc);
+  if (stats) PB_LAUNCH_TRAV(k_tail, kShadeFull PB_COMMA true, curves, wide, g, dim3(kBlock), 0, s, P, sc, rng_inc);
+  else if (textured) PB_LAUNCH_TRAV(k_tail, kShadeFull PB_COMMA false, curves, wide, g, dim3(kBlock), 0, s, P, sc, rng_inc);
+  else if (media) PB_LAUNCH_TRAV(k_tail, kShadeMedia PB_COMMA false, curves, wide, g, dim3(kBlock), 0, s, P, sc, rng_inc);
+  else PB_LAUNCH_TRAV(k_tail, kShadePlain PB_COMMA false, curves, wide, g, dim3(kBlock), 0, s, P, sc, rng_inc);
 }
 void launch_layer_pack(hipStream_t s, const uint32_t* pix, uint32_t npix, const float* rgba, const uint32_t* count, float* shard) {
   if (!npix) return;

@@ -1158,7 +1158,7 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
           launch_trace(gst, gr.P, sc, 2 * n, want_stats);
           HIPCHK(gr.tm.end());
           HIPCHK(gr.tm.begin(&S.ms_tail));
-          launch_tail(gst, gr.P, sc, n, rng_inc, want_stats);
+          launch_tail(gst, gr.P, sc, n, rng_inc, want_stats, s->has_sss, s->has_textured);
           HIPCHK(gr.tm.end());
           launch_advance(gst, gr.P);  // nothing was queued: both "in" counts become 0
           S.n_trace_closest++, S.n_tail++, S.iterations++;

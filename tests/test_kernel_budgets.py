@@ -30,10 +30,11 @@ BUDGETS = {
     # general shading kernel alone is 9 % faster at two, the C3 frame 2 % slower; k_tail likewise in round 2): pinned as they are
     "k_shade_principled<1>": (168, 44),          # media, no texture (C3, C5): the medium's coefficients come from the material record
     "k_shade_principled<2>": (168, 128),         # textured materials: ParamToBsdf and the medium per hit
-    "k_tail<false, false, true>": (168, 176),
-    "k_tail<false, true, true>": (168, 176),
-    "k_tail<false, false, false>": (168, 176),
-    "k_tail<false, true, false>": (168, 176),
+    "k_tail<0, false, false, true>": (168, 20),    # no medium, no texture (C2)
+    "k_tail<0, false, true, true>": (168, 20),     # ... with curves (C4)
+    "k_tail<1, false, false, true>": (168, 168),   # media (C3)
+    "k_tail<1, false, true, true>": (168, 168),    # media + curves (C5)
+    "k_tail<2, false, false, true>": (168, 176),   # textured materials
     "k_shade_hair": (136, 0),
     "k_sss_step": (160, 0),
     "k_classify": (64, 0),
