@@ -785,8 +785,11 @@ struct WalkState {
 // update, Russian roulette, the step bound, then the next isotropic direction and scatter distance.  Returns false when
 // the walk FAILS here (roulette, or more than 8192 steps); then `w` is left untouched.  Shared by the wavefront's step
 // (sss_step_path) and by the fast-forward kernel (k_sss_walk), so both compute the very same values.
-__device__ __forceinline__ bool sss_scatter(WalkState& w, uint64_t rng_inc) {
-  const V3 chpdf = scatter_channel_pdf(w.wthr, w.sigs, w.sigt);  // what sample_scatter_distance computed when it drew this step's distance
+// chpdf_io: null, or the channel pdf of the pending step as the previous call left it (in: *have_chpdf says whether it holds
+// one; out: the next step's) -- the same function of the same operands, so carrying it changes no bit.
+__device__ __forceinline__ bool sss_scatter(WalkState& w, uint64_t rng_inc, V3* chpdf_io = nullptr, bool have_chpdf = false) {
+  // what sample_scatter_distance computed when it drew this step's distance
+  const V3 chpdf = (chpdf_io && have_chpdf) ? *chpdf_io : scatter_channel_pdf(w.wthr, w.sigs, w.sigt);
   const V3 trans = attenuate_transmission(w.sigt, w.t_scatter);
   float pdf = dot(chpdf, w.sigt * trans);
   V3 wthr = w.wthr * (w.sigs * trans) / pdf;
@@ -808,6 +811,7 @@ __device__ __forceinline__ bool sss_scatter(WalkState& w, uint64_t rng_inc) {
   V3 chpdf_next;
   float t_scatter = sample_scatter_distance(wthr, w.sigs, w.sigt, e0, e1, chpdf_next);
   w.org = org, w.dir = wi, w.wthr = wthr, w.t_scatter = t_scatter, w.bounce = bounce, w.rng_state = rng.state;
+  if (chpdf_io) *chpdf_io = chpdf_next;
   return true;
 }
 
@@ -966,13 +970,15 @@ __global__ __launch_bounds__(kBlock) void k_sss_step(PathState P, DScene sc, uin
 #define PB_WALK_CAP 24u  // A/B on C3 (walk + step kernels, ms per frame): no cap 230, 128: 183, 64: 164, 32: 149, 24: 140, 16: 139, 12: 134 (but more iterations), 8: 138
 #endif
 constexpr uint32_t kWalkCap = PB_WALK_CAP;
+constexpr uint32_t kWalkWords = 18;  // words of walk state per lane in LDS (WalkSink)
 struct WalkSink {
   static constexpr bool kWalk = true;
   const PathState& P;
   uint64_t rng_inc;
-  // What a walk carries besides its ray (which the traversal holds in registers anyway) lives in LDS, 9 words per lane
-  // (wl[k * kBlock]): throughput, scatter distance, step index, generator state, scatterings applied, path slot.  sigma_t /
-  // sigma_s are re-read from the path state each step.  This keeps the kernel's registers at the traversal's.
+  // What a walk carries besides its ray (which the traversal holds in registers anyway) lives in LDS, kWalkWords words per
+  // lane (wl[k * kBlock]): throughput, scatter distance, step index, generator state, scatterings applied, path slot; the
+  // medium's sigma_t / sigma_s (fetched once per launch instead of two gathers in front of every scattering) and the channel
+  // pdf of the pending step as the previous scattering computed it.  This keeps the kernel's registers at the traversal's.
   float* wl;
   uint32_t n_rays;  // rays traced by this lane (STATS)
   __device__ __forceinline__ void start(uint32_t idx, uint32_t& tag, Hit& h, V3& o, V3& d) {
@@ -987,6 +993,9 @@ struct WalkSink {
       o = ld3(o4), d = ld3(d4);
       wl[0] = wt4.x, wl[kBlock] = wt4.y, wl[2 * kBlock] = wt4.z, wl[3 * kBlock] = d4.w, wl[4 * kBlock] = wt4.w;
       wl[5 * kBlock] = __uint_as_float((uint32_t)r), wl[6 * kBlock] = __uint_as_float((uint32_t)(r >> 32));
+      const float4 st4 = P.sss_sigt[p], ss4 = P.sss_sigs[p];
+      wl[9 * kBlock] = st4.x, wl[10 * kBlock] = st4.y, wl[11 * kBlock] = st4.z;
+      wl[12 * kBlock] = ss4.x, wl[13 * kBlock] = ss4.y, wl[14 * kBlock] = ss4.z;
     }
   }
   __device__ __forceinline__ bool next(uint32_t tag, const Hit& h, V3& o, V3& d, float& tmin, float& tmax) {
@@ -995,11 +1004,15 @@ struct WalkSink {
     // one is handed back (k_sss_step applies its pending scattering) and goes on in the next iteration's launch.
     if (h.slot == kNone && __float_as_uint(wl[7 * kBlock]) < kWalkCap) {
       WalkState w;
-      w.org = o, w.dir = d, w.sigt = ld3(P.sss_sigt[p]), w.sigs = ld3(P.sss_sigs[p]);
+      w.org = o, w.dir = d;
+      w.sigt = V3(wl[9 * kBlock], wl[10 * kBlock], wl[11 * kBlock]), w.sigs = V3(wl[12 * kBlock], wl[13 * kBlock], wl[14 * kBlock]);
+      const bool carried = __float_as_uint(wl[7 * kBlock]) != 0u;  // a scattering of this launch left the pending step's channel pdf
+      V3 chpdf(wl[15 * kBlock], wl[16 * kBlock], wl[17 * kBlock]);
       w.wthr = V3(wl[0], wl[kBlock], wl[2 * kBlock]), w.t_scatter = wl[3 * kBlock], w.bounce = __float_as_uint(wl[4 * kBlock]);
       w.rng_state = (uint64_t)__float_as_uint(wl[5 * kBlock]) | ((uint64_t)__float_as_uint(wl[6 * kBlock]) << 32);
-      if (sss_scatter(w, rng_inc)) {
+      if (sss_scatter(w, rng_inc, &chpdf, carried)) {
         o = w.org, d = w.dir, tmin = 0.f, tmax = w.t_scatter;
+        wl[15 * kBlock] = chpdf.x, wl[16 * kBlock] = chpdf.y, wl[17 * kBlock] = chpdf.z;
         wl[0] = w.wthr.x, wl[kBlock] = w.wthr.y, wl[2 * kBlock] = w.wthr.z, wl[3 * kBlock] = w.t_scatter;
         wl[4 * kBlock] = __uint_as_float(w.bounce);
         wl[5 * kBlock] = __uint_as_float((uint32_t)w.rng_state), wl[6 * kBlock] = __uint_as_float((uint32_t)(w.rng_state >> 32));
@@ -1028,7 +1041,7 @@ template <bool STATS, bool CURVES, bool WIDE = false>
 __global__ __launch_bounds__(kBlock, PB_WALK_WAVES) void k_sss_walk(PathState P, DScene sc, uint64_t rng_inc) {
   __shared__ uint32_t stk[pv_lds_stack<CURVES, WIDE>() * kBlock];
   __shared__ float frm[CURVES ? 10 * kBlock : 1];
-  __shared__ float walk[9 * kBlock];
+  __shared__ float walk[kWalkWords * kBlock];
   const uint32_t n = P.counts[kCntSss];
   TravStats st = {};
   uint32_t overflow = 0u;
