@@ -386,15 +386,16 @@ PB_HD void medium_coefficients(const PrincipledBsdf& b, V3& sigt, V3& sigs, V3& 
 // SampleScatterDistance + SampleChannel (:141-188)
 // the channel pdf is a function of (walk throughput, sigma_s, sigma_t) alone: the step that consumes it recomputes it from the
 // stored throughput instead of keeping it in the path state
-PB_HD V3 scatter_channel_pdf(V3 throughput, V3 sigma_s, V3 sigma_t) {
-  V3 albedo = safe_divide_spectrum(sigma_s, sigma_t);
+// albedo: null, or safe_divide_spectrum(sigma_s, sigma_t) computed before (a constant of the walk)
+PB_HD V3 scatter_channel_pdf(V3 throughput, V3 sigma_s, V3 sigma_t, const V3* albedo_in = nullptr) {
+  V3 albedo = albedo_in ? *albedo_in : safe_divide_spectrum(sigma_s, sigma_t);
   V3 w(fabsf(throughput.x * albedo.x), fabsf(throughput.y * albedo.y), fabsf(throughput.z * albedo.z));
   float sum = w.x + w.y + w.z;
   if (sum > 0.0f) return V3(w.x / sum, w.y / sum, w.z / sum);
   return V3(1.0f / 3.0f, 1.0f / 3.0f, 1.0f / 3.0f);
 }
-PB_HD float sample_scatter_distance(V3 throughput, V3 sigma_s, V3 sigma_t, float u0, float u1, V3& channel_pdf) {
-  channel_pdf = scatter_channel_pdf(throughput, sigma_s, sigma_t);
+PB_HD float sample_scatter_distance(V3 throughput, V3 sigma_s, V3 sigma_t, float u0, float u1, V3& channel_pdf, const V3* albedo_in = nullptr) {
+  channel_pdf = scatter_channel_pdf(throughput, sigma_s, sigma_t, albedo_in);
   float st = (u0 < channel_pdf.x) ? sigma_t.x : ((u0 < channel_pdf.x + channel_pdf.y) ? sigma_t.y : sigma_t.z);
   return -f_log(1.0f - u1) / st;
 }

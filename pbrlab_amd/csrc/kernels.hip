@@ -787,9 +787,10 @@ struct WalkState {
 // (sss_step_path) and by the fast-forward kernel (k_sss_walk), so both compute the very same values.
 // chpdf_io: null, or the channel pdf of the pending step as the previous call left it (in: *have_chpdf says whether it holds
 // one; out: the next step's) -- the same function of the same operands, so carrying it changes no bit.
-__device__ __forceinline__ bool sss_scatter(WalkState& w, uint64_t rng_inc, V3* chpdf_io = nullptr, bool have_chpdf = false) {
+// albedo: null, or sigma_s / sigma_t (safe_divide_spectrum) computed once for the walk.
+__device__ __forceinline__ bool sss_scatter(WalkState& w, uint64_t rng_inc, V3* chpdf_io = nullptr, bool have_chpdf = false, const V3* albedo = nullptr) {
   // what sample_scatter_distance computed when it drew this step's distance
-  const V3 chpdf = (chpdf_io && have_chpdf) ? *chpdf_io : scatter_channel_pdf(w.wthr, w.sigs, w.sigt);
+  const V3 chpdf = (chpdf_io && have_chpdf) ? *chpdf_io : scatter_channel_pdf(w.wthr, w.sigs, w.sigt, albedo);
   const V3 trans = attenuate_transmission(w.sigt, w.t_scatter);
   float pdf = dot(chpdf, w.sigt * trans);
   V3 wthr = w.wthr * (w.sigs * trans) / pdf;
@@ -809,7 +810,7 @@ __device__ __forceinline__ bool sss_scatter(WalkState& w, uint64_t rng_inc, V3* 
   float e0 = draw(rng);
   float e1 = draw(rng);
   V3 chpdf_next;
-  float t_scatter = sample_scatter_distance(wthr, w.sigs, w.sigt, e0, e1, chpdf_next);
+  float t_scatter = sample_scatter_distance(wthr, w.sigs, w.sigt, e0, e1, chpdf_next, albedo);
   w.org = org, w.dir = wi, w.wthr = wthr, w.t_scatter = t_scatter, w.bounce = bounce, w.rng_state = rng.state;
   if (chpdf_io) *chpdf_io = chpdf_next;
   return true;
@@ -970,7 +971,7 @@ __global__ __launch_bounds__(kBlock) void k_sss_step(PathState P, DScene sc, uin
 #define PB_WALK_CAP 24u  // A/B on C3 (walk + step kernels, ms per frame): no cap 230, 128: 183, 64: 164, 32: 149, 24: 140, 16: 139, 12: 134 (but more iterations), 8: 138
 #endif
 constexpr uint32_t kWalkCap = PB_WALK_CAP;
-constexpr uint32_t kWalkWords = 18;  // words of walk state per lane in LDS (WalkSink)
+constexpr uint32_t kWalkWords = 21;  // words of walk state per lane in LDS (WalkSink)
 struct WalkSink {
   static constexpr bool kWalk = true;
   const PathState& P;
@@ -996,6 +997,8 @@ struct WalkSink {
       const float4 st4 = P.sss_sigt[p], ss4 = P.sss_sigs[p];
       wl[9 * kBlock] = st4.x, wl[10 * kBlock] = st4.y, wl[11 * kBlock] = st4.z;
       wl[12 * kBlock] = ss4.x, wl[13 * kBlock] = ss4.y, wl[14 * kBlock] = ss4.z;
+      const V3 albedo = safe_divide_spectrum(ld3(ss4), ld3(st4));  // what scatter_channel_pdf derives from them every time
+      wl[18 * kBlock] = albedo.x, wl[19 * kBlock] = albedo.y, wl[20 * kBlock] = albedo.z;
     }
   }
   __device__ __forceinline__ bool next(uint32_t tag, const Hit& h, V3& o, V3& d, float& tmin, float& tmax) {
@@ -1008,9 +1011,10 @@ struct WalkSink {
       w.sigt = V3(wl[9 * kBlock], wl[10 * kBlock], wl[11 * kBlock]), w.sigs = V3(wl[12 * kBlock], wl[13 * kBlock], wl[14 * kBlock]);
       const bool carried = __float_as_uint(wl[7 * kBlock]) != 0u;  // a scattering of this launch left the pending step's channel pdf
       V3 chpdf(wl[15 * kBlock], wl[16 * kBlock], wl[17 * kBlock]);
+      const V3 albedo(wl[18 * kBlock], wl[19 * kBlock], wl[20 * kBlock]);
       w.wthr = V3(wl[0], wl[kBlock], wl[2 * kBlock]), w.t_scatter = wl[3 * kBlock], w.bounce = __float_as_uint(wl[4 * kBlock]);
       w.rng_state = (uint64_t)__float_as_uint(wl[5 * kBlock]) | ((uint64_t)__float_as_uint(wl[6 * kBlock]) << 32);
-      if (sss_scatter(w, rng_inc, &chpdf, carried)) {
+      if (sss_scatter(w, rng_inc, &chpdf, carried, &albedo)) {
         o = w.org, d = w.dir, tmin = 0.f, tmax = w.t_scatter;
         wl[15 * kBlock] = chpdf.x, wl[16 * kBlock] = chpdf.y, wl[17 * kBlock] = chpdf.z;
         wl[0] = w.wthr.x, wl[kBlock] = w.wthr.y, wl[2 * kBlock] = w.wthr.z, wl[3 * kBlock] = w.t_scatter;
