@@ -11,7 +11,9 @@ W, H = 3840, 2160
 SPP = int(os.environ.get("SPP", "1024"))
 rgba = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda"); cnt = torch.zeros((H, W), dtype=torch.int32, device="cuda")
 torch.cuda.synchronize()
-api.Render(s, W, H, 32, tile_rank=0, tile_world=8, device_out=(rgba.data_ptr(), cnt.data_ptr()), shard_block=16)  # (working set allocated, pixel list built)
+# warm-up: pixel lists built and the working set allocated at its final size (a chunk of the eighth holds 258 passes = 267.5 M
+# paths, one of the whole frame 32 passes = 265.4 M: the first render that needs the larger one re-allocates 65 GB of path state)
+api.Render(s, W, H, min(SPP, 300), tile_rank=0, tile_world=8, device_out=(rgba.data_ptr(), cnt.data_ptr()), shard_block=16)
 api.Render(s, W, H, 32, device_out=(rgba.data_ptr(), cnt.data_ptr()))
 res = {}
 for world in (8, 1):
