@@ -1631,7 +1631,7 @@ bool DecodeExr(const uint8_t* file, size_t n, std::vector<float>* pixels, size_t
     return *err = "OpenEXR header lacks a required attribute", false;
   if (compression > 4) return *err = "OpenEXR compression PXR24 / B44 / DWA is not decoded by this build (use ZIP or PIZ)", false;
   if (dw[2] < dw[0] || dw[3] < dw[1]) return *err = "bad OpenEXR data window", false;
-  const size_t w = size_t(dw[2] - dw[0]) + 1, h = size_t(dw[3] - dw[1]) + 1;
+  const size_t w = size_t(int64_t(dw[2]) - int64_t(dw[0])) + 1, h = size_t(int64_t(dw[3]) - int64_t(dw[1])) + 1;  // (64-bit: the corners are arbitrary int32)
   if (w > (1u << 24) || h > (1u << 24) || uint64_t(w) * h > (1ull << 28)) return *err = "bad OpenEXR data window", false;
   size_t pixel_bytes = 0;
   for (ExrChannel& c : ch) {
