@@ -61,6 +61,9 @@ def csrc_hash():
         if name.endswith((".h", ".hip", ".cpp")) or name == "Makefile":
             h.update(name.encode())
             h.update(open(os.path.join(base, name), "rb").read())
+    for name in ("pbr_f64r.h", "pbrhip.h"):  # headers outside csrc the kernels are compiled from
+        h.update(name.encode())
+        h.update(open(os.path.join(ROOT, "include", name), "rb").read())
     return h.hexdigest()[:16]
 
 
@@ -155,9 +158,11 @@ def cpu_model():
 
 
 def cpu_baseline_run(workload, spp_override, seconds_budget):
-    """Oracle (reference algorithm restated in C, oracle/) on the host cores, bounded sample of the same
-    workload: the full frame at as many spp as fit ~seconds_budget (cost per sample is spp-independent).
-    Which build of the oracle is loaded is decided by PBR_ORACLE_SO (tests/_oracle.py)."""
+    """Oracle (reference algorithm restated in C, oracle/) on the host cores, bounded sample of the same workload, with
+    the reference's own worker pool: job = (tile, pass), job id -> (id % tiles, id / tiles) from one atomic counter
+    (render.cc:210-233; oracle/pbr_oracle.c ORC_JOBS_TILE_PASS).  Three timings: one thread on every 6th tile at 1 spp
+    (per-thread speed), all threads on 1/16 of the tiles (calibration), all threads on the full frame at as many spp as
+    fit ~seconds_budget.  Which build of the oracle is loaded is decided by PBR_ORACLE_SO (tests/_oracle.py)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _oracle as O
     w = dict(WORKLOADS[workload])
@@ -165,8 +170,13 @@ def cpu_baseline_run(workload, spp_override, seconds_budget):
     so = O.oracle_scene_from_desc(desc)
     cores = os.cpu_count() or 1
     W, H = w["width"], w["height"]
-    t0 = time.time()                               # calibrate on 1/16 of the tiles
-    _, _, st = so.render(W, H, 1, tile_rank=0, tile_world=16, threads=cores)
+    t0 = time.time()                               # one thread: every 6th tile (a representative ~1/6 of the frame is too
+    one_world = max(6, int(round(W * H / 400000)))  # long for big frames: about 0.4 M samples)
+    _, _, st1 = so.render(W, H, 1, tile_rank=0, tile_world=one_world, threads=1, job_mode=O.JOBS_TILE_PASS)
+    dt1 = max(time.time() - t0, 1e-3)
+    rate1 = st1["samples"] / dt1
+    t0 = time.time()                               # calibrate the pool on 1/16 of the tiles
+    _, _, st = so.render(W, H, 1, tile_rank=0, tile_world=16, threads=cores, job_mode=O.JOBS_TILE_PASS)
     rate = st["samples"] / max(time.time() - t0, 1e-3)
     spp, world = 1, 1
     if rate * seconds_budget >= W * H:
@@ -174,10 +184,16 @@ def cpu_baseline_run(workload, spp_override, seconds_budget):
     else:
         world = int(min(64, max(1, round(W * H / (rate * seconds_budget)))))
     t0 = time.time()
-    _, _, st = so.render(W, H, spp, tile_rank=0, tile_world=world, threads=cores)
+    _, _, st = so.render(W, H, spp, tile_rank=0, tile_world=world, threads=cores, job_mode=O.JOBS_TILE_PASS)
     dt = time.time() - t0
-    return {"value": st["samples"] / dt / 1e6, "unit": "Msamples/s", "cores": cores,
-            "sample": f"{W}x{H} x {spp} spp, tiles i%{world}==0: {st['samples']} samples in {dt:.1f} s on {cores} threads"}
+    busy = float(so.L.orc_last_render_busy())
+    valn = st["samples"] / dt / 1e6
+    return {"value": valn, "unit": "Msamples/s", "cores": cores,
+            "one_thread": {"value": rate1 / 1e6, "sample": f"{W}x{H} x 1 spp, tiles i%{one_world}==0: {st1['samples']} samples in {dt1:.1f} s on 1 thread"},
+            "speedup_over_one_thread": valn / (rate1 / 1e6),
+            "parallel_efficiency": valn / (rate1 / 1e6) / cores,
+            "schedule_efficiency": busy / (cores * dt),
+            "sample": f"{W}x{H} x {spp} spp, tiles i%{world}==0, jobs = (tile, pass) as render.cc:210-219: {st['samples']} samples in {dt:.1f} s on {cores} threads"}
 
 
 def cpu_baseline(workload):
@@ -209,9 +225,16 @@ def cpu_baseline(workload):
         return None
     best = max(runs, key=lambda r: r["value"])
     return {"value": best["value"], "unit": "Msamples/s", "cores": best["cores"], "kind": "port", "cpu": cpu_model(),
-            "sample": "oracle (C restatement of the reference integrator, own binned-SAH BVH2, pthread tile pool like render.cc:203-238; "
-                      "Embree is not available here, so the reference cannot run), " + best["sample"] + "; build: " + best["build"],
-            "builds": [{"build": r["build"], "value": r["value"], "sample": r["sample"]} for r in runs]}
+            "one_thread": best["one_thread"], "speedup_over_one_thread": best["speedup_over_one_thread"],
+            "parallel_efficiency": best["parallel_efficiency"], "schedule_efficiency": best["schedule_efficiency"],
+            "sample": "oracle = a SCALAR C restatement of the reference integrator over its own binned-SAH BVH2 (NOT Embree: Embree 4 is "
+                      "not available here, so the reference itself cannot run; Embree's SSE/AVX BVH4 kernels are typically several "
+                      "times faster per ray than a scalar BVH2, so the GPU / CPU ratio is over this port, not over the reference); "
+                      "worker pool as render.cc:203-238 with the reference's job = (tile, pass); " + best["sample"] + "; build: " + best["build"]
+                      + "; parallel_efficiency = value / (one-thread value x threads) -- the threads are SMT siblings, two per core -- "
+                      "schedule_efficiency = sum of the workers' busy time / (threads x wall time)",
+            "builds": [{"build": r["build"], "value": r["value"], "one_thread": r["one_thread"]["value"],
+                        "schedule_efficiency": r["schedule_efficiency"], "sample": r["sample"]} for r in runs]}
 
 
 def main():

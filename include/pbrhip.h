@@ -114,6 +114,14 @@ typedef struct {
   uint64_t curve_bytes; /* bytes fetched per curve-piece test: 32 (Q tree: two 16-byte points of a chain) or 64 (binary tree: one slot) */
 } pbrhip_render_stats;
 
+/* Layout version of the structs of this header (pbrhip_render_desc, pbrhip_render_stats, pbrhip_*_param, pbrhip_hit): it
+ * changes whenever one of them changes (3 -> 4: pbrhip_render_stats grew by curve_bytes).  The library writes whole structs
+ * (n of them for pbrhip_render_multi), so a caller compiled against another version must not call it: check
+ * pbrhip_abi_version() == PBRHIP_ABI_VERSION once after loading (include/pbrlab_hip.hpp and pbrlab_amd/api.py do). */
+#define PBRHIP_ABI_VERSION 4u
+uint32_t pbrhip_abi_version(void);
+size_t pbrhip_sizeof_render_stats(void); /* == sizeof(pbrhip_render_stats) of the library's build */
+
 const char* pbrhip_last_error(void);
 int pbrhip_device_count(int* count);
 /* selects the HIP device used by subsequently created scenes (one process per GPU: LOCAL_RANK) */

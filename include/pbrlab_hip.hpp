@@ -261,6 +261,8 @@ inline Pushed Flatten(const MaterialParameter& m) {
 class Scene {
 public:
   Scene() {
+    if (pbrhip_abi_version() != PBRHIP_ABI_VERSION)  // (the library writes whole structs of ITS layout)
+      throw std::runtime_error("libpbrhip.so was built from another version of pbrhip.h (struct layouts differ): rebuild");
     if (pbrhip_scene_create(&h_) != PBRHIP_OK) throw std::runtime_error(pbrhip_last_error());
   }
   ~Scene() { pbrhip_scene_destroy(h_); }
@@ -311,14 +313,16 @@ public:
   // scene.h:39-44: a MaterialParameter, or either of its alternatives
   template <class... Args>
   uint32_t AddMaterialParam(Args&&... args) {
+    // the library first: if it refuses the material nothing is appended and the two lists stay in step
     const uint32_t id = uint32_t(material_params_.size());
-    material_params_.emplace_back(args...);
-    const detail::Pushed f = detail::Flatten(material_params_.back());
-    uint32_t lib_id;
+    MaterialParameter param(args...);
+    const detail::Pushed f = detail::Flatten(param);
+    uint32_t lib_id = uint32_t(-1);
     if (f.kind == kCyclesPrincipledBsdfParameter) Check(pbrhip_scene_add_principled_material(h_, &f.pr, &lib_id));
     else Check(pbrhip_scene_add_hair_material(h_, &f.hr, &lib_id));
+    if (lib_id != id) throw std::runtime_error("pbrlab::Scene::AddMaterialParam: material ids of the library and of the shim differ");
+    material_params_.emplace_back(std::move(param));
     pushed_.push_back(f);
-    assert(lib_id == id);
     return id;
   }
   // scene.h:46-51: a Texture, or its constructor arguments (pixels, width, height, channels, name)

@@ -9,6 +9,7 @@
 #include "pbr_oracle.h"
 
 #include <pthread.h>
+#include <time.h>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -1921,8 +1922,10 @@ typedef struct {
   uint32_t* count;
   uint32_t* tiles;
   uint32_t ntiles;
-  volatile uint32_t next_tile;
+  uint32_t job_mode;
+  volatile uint64_t next_job;
   pthread_mutex_t mtx;
+  pthread_mutex_t* tile_mtx; /* ORC_JOBS_TILE_PASS: RenderTile::mtx (render.cc:176) */
   orc_stats total;
 } orc_job;
 
@@ -1932,38 +1935,76 @@ static void stats_add(orc_stats* a, const orc_stats* b, const orc_trav_stats* t)
   a->nodes_visited += t->nodes, a->tris_tested += t->tris, a->curves_tested += t->curves;
 }
 
-/* One worker: pulls tiles (render.cc:215-233 job loop, but tile-major so that each pixel's passes
- * are accumulated in ascending order by a single thread: Q13). */
+/* the samples of passes [p0, p1) of the pixels [x0, x1) x [y0, y1): render.cc:160-183 */
+static void render_rect(orc_job* job, orc_ctx* c, const orc_camera* cam, uint32_t x0, uint32_t x1, uint32_t y0, uint32_t y1,
+                        uint32_t p0, uint32_t p1, pthread_mutex_t* mtx) {
+  for (uint32_t pass = p0; pass < p1; pass++)
+    for (uint32_t y = y0; y < y1; y++)
+      for (uint32_t x = x0; x < x1; x++) {
+        orc_rng rng;
+        seed_sample(&rng, job->width, x, y, pass, job->seed_seq);
+        orc_rayf r = camera_ray(cam, x, y, &rng);
+        f3 L = get_radiance(c, &r, &rng);
+        size_t p = (size_t)y * job->width + x;
+        /* render.cc:175-183 */
+        if (mtx) pthread_mutex_lock(mtx);
+        job->rgba[p * 4 + 0] += L.x;
+        job->rgba[p * 4 + 1] += L.y;
+        job->rgba[p * 4 + 2] += L.z;
+        job->rgba[p * 4 + 3] += 1.0f;
+        job->count[p]++;
+        if (mtx) pthread_mutex_unlock(mtx);
+        c->stats.samples++;
+        c->stats.rng_draws += rng.draws;
+      }
+}
+
+/* One worker of the pool (render.cc:210-233: every thread pulls job ids from one atomic counter).
+ * ORC_JOBS_BLOCKS (the checker's mode): a job = one 16x16 block of a tile x ALL passes, so that each pixel's passes are
+ *   accumulated in ascending order by a single thread (Q13: the image does not depend on the schedule or the thread count);
+ *   blocks instead of whole tiles because the heaviest tile of a frame costs ~10x the mean and 510 tiles cannot keep 256
+ *   threads busy (parallel efficiency 0.20).
+ * ORC_JOBS_TILE_PASS (timing mode, the reference's own granularity): job id -> (tile = id % ntiles, pass = id / ntiles),
+ *   pixels accumulated under the tile's mutex as in render.cc:175-183; the float sums then depend on the schedule, exactly
+ *   like the reference's, so this mode is for the CPU baseline's clock, not for parity. */
+static double g_last_busy = 0.0; /* sum over the workers of the last orc_render_jobs call: seconds from its start to the end of the worker's last job */
+static double now_seconds(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+double orc_last_render_busy(void) { return g_last_busy; }
+
 static void* render_worker(void* arg) {
   orc_job* job = (orc_job*)arg;
   orc_ctx c;
   memset(&c, 0, sizeof(c));
   c.scene = job->scene;
+  const double t_start = now_seconds();
+  double t_last = t_start;
   orc_camera cam = make_camera(job->scene, job->width, job->height);
+  const uint64_t njobs = job->job_mode == ORC_JOBS_TILE_PASS ? (uint64_t)job->ntiles * job->spp : (uint64_t)job->ntiles * 16u;
   for (;;) {
-    uint32_t tile = __sync_fetch_and_add(&job->next_tile, 1u);
-    if (tile >= job->ntiles) break;
-    if (tile % job->tile_world != job->tile_rank) continue;
-    const uint32_t* tl = job->tiles + tile * 4;
-    for (uint32_t pass = job->first_pass; pass < job->first_pass + job->spp; pass++)
-      for (uint32_t y = tl[2]; y < tl[3]; y++)
-        for (uint32_t x = tl[0]; x < tl[1]; x++) {
-          orc_rng rng;
-          seed_sample(&rng, job->width, x, y, pass, job->seed_seq);
-          orc_rayf r = camera_ray(&cam, x, y, &rng);
-          f3 L = get_radiance(&c, &r, &rng);
-          size_t p = (size_t)y * job->width + x;
-          /* render.cc:175-183 */
-          job->rgba[p * 4 + 0] += L.x;
-          job->rgba[p * 4 + 1] += L.y;
-          job->rgba[p * 4 + 2] += L.z;
-          job->rgba[p * 4 + 3] += 1.0f;
-          job->count[p]++;
-          c.stats.samples++;
-          c.stats.rng_draws += rng.draws;
-        }
+    const uint64_t id = __sync_fetch_and_add(&job->next_job, 1ull);
+    if (id >= njobs) break;
+    if (job->job_mode == ORC_JOBS_TILE_PASS) {
+      const uint32_t tile = (uint32_t)(id % job->ntiles), pass = job->first_pass + (uint32_t)(id / job->ntiles);
+      if (tile % job->tile_world != job->tile_rank) continue;
+      const uint32_t* tl = job->tiles + tile * 4;
+      render_rect(job, &c, &cam, tl[0], tl[1], tl[2], tl[3], pass, pass + 1u, &job->tile_mtx[tile]);
+    } else {
+      const uint32_t tile = (uint32_t)(id / 16u), sub = (uint32_t)(id % 16u);
+      if (tile % job->tile_world != job->tile_rank) continue;
+      const uint32_t* tl = job->tiles + tile * 4;
+      const uint32_t x0 = tl[0] + 16u * (sub % 4u), y0 = tl[2] + 16u * (sub / 4u);
+      if (x0 >= tl[1] || y0 >= tl[3]) continue;
+      render_rect(job, &c, &cam, x0, x0 + 16u < tl[1] ? x0 + 16u : tl[1], y0, y0 + 16u < tl[3] ? y0 + 16u : tl[3], job->first_pass,
+                  job->first_pass + job->spp, NULL);
+    }
+    t_last = now_seconds();
   }
   pthread_mutex_lock(&job->mtx);
+  g_last_busy += t_last - t_start;
   stats_add(&job->total, &c.stats, &c.trav);
   pthread_mutex_unlock(&job->mtx);
   return NULL;
@@ -1972,8 +2013,16 @@ static void* render_worker(void* arg) {
 void orc_render(const orc_scene* s, uint32_t width, uint32_t height, uint32_t spp, uint32_t first_pass, uint64_t seed_seq,
                 uint32_t tile_rank, uint32_t tile_world, uint32_t num_threads, float* rgba, uint32_t* count,
                 orc_stats* stats) {
+  orc_render_jobs(s, width, height, spp, first_pass, seed_seq, tile_rank, tile_world, num_threads, ORC_JOBS_BLOCKS, rgba, count, stats);
+}
+
+void orc_render_jobs(const orc_scene* s, uint32_t width, uint32_t height, uint32_t spp, uint32_t first_pass, uint64_t seed_seq,
+                     uint32_t tile_rank, uint32_t tile_world, uint32_t num_threads, uint32_t job_mode, float* rgba,
+                     uint32_t* count, orc_stats* stats) {
   orc_job job;
   memset(&job, 0, sizeof(job));
+  g_last_busy = 0.0;
+  job.job_mode = job_mode;
   job.scene = s, job.width = width, job.height = height, job.spp = spp, job.first_pass = first_pass;
   job.tile_rank = tile_rank, job.tile_world = tile_world ? tile_world : 1, job.seed_seq = seed_seq;
   job.rgba = rgba, job.count = count;
@@ -1984,6 +2033,10 @@ void orc_render(const orc_scene* s, uint32_t width, uint32_t height, uint32_t sp
   job.tiles = (uint32_t*)xrealloc(NULL, sizeof(uint32_t) * 4 * job.ntiles);
   orc_create_tiles(width, height, job.tiles, &job.ntiles);
   pthread_mutex_init(&job.mtx, NULL);
+  if (job_mode == ORC_JOBS_TILE_PASS) {
+    job.tile_mtx = (pthread_mutex_t*)xrealloc(NULL, sizeof(pthread_mutex_t) * job.ntiles);
+    for (uint32_t i = 0; i < job.ntiles; i++) pthread_mutex_init(&job.tile_mtx[i], NULL);
+  }
   if (num_threads < 1) num_threads = 1;
   if (num_threads == 1) {
     render_worker(&job);
@@ -1994,6 +2047,10 @@ void orc_render(const orc_scene* s, uint32_t width, uint32_t height, uint32_t sp
     free(th);
   }
   pthread_mutex_destroy(&job.mtx);
+  if (job.tile_mtx) {
+    for (uint32_t i = 0; i < job.ntiles; i++) pthread_mutex_destroy(&job.tile_mtx[i]);
+    free(job.tile_mtx);
+  }
   free(job.tiles);
   if (stats) *stats = job.total;
 }

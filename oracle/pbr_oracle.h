@@ -106,6 +106,21 @@ void orc_render(const orc_scene*, uint32_t width, uint32_t height, uint32_t spp,
                 uint64_t seed_seq, uint32_t tile_rank, uint32_t tile_world, uint32_t num_threads,
                 float* rgba, uint32_t* count, orc_stats* stats);
 
+/* The same with the job granularity of the worker pool chosen by the caller:
+ *   ORC_JOBS_BLOCKS     a job = a 16x16 block of a tile x all passes (what orc_render does: per-pixel ascending-pass sums
+ *                       by one thread -- the image is independent of the schedule; the checker's mode)
+ *   ORC_JOBS_TILE_PASS  a job = (tile, pass), id -> (id % ntiles, id / ntiles), pixel sums under the tile's mutex: the
+ *                       reference's own pool (render.cc:210-233, 175-183); float sums depend on the schedule like the
+ *                       reference's, so it is used for the CPU baseline's clock only */
+enum { ORC_JOBS_BLOCKS = 0, ORC_JOBS_TILE_PASS = 1 };
+void orc_render_jobs(const orc_scene*, uint32_t width, uint32_t height, uint32_t spp, uint32_t first_pass,
+                     uint64_t seed_seq, uint32_t tile_rank, uint32_t tile_world, uint32_t num_threads, uint32_t job_mode,
+                     float* rgba, uint32_t* count, orc_stats* stats);
+
+/* timing aid: the sum over the worker threads of the last orc_render / orc_render_jobs call of (end of the worker's last job -
+ * start of the call), in seconds; divided by threads x wall time it is the pool's scheduling efficiency */
+double orc_last_render_busy(void);
+
 /* one sample, with a trace of the hit sequence: returns number of closest-hit records written
  * (<= max_hits; the path may be longer), radiance[3], draws consumed. */
 uint32_t orc_sample_trace(const orc_scene*, uint32_t width, uint32_t height, uint32_t x, uint32_t y,

@@ -56,8 +56,8 @@ struct alignas(16) BvhNode {
 };
 static_assert(sizeof(BvhNode) == 64, "node must be 64 B");
 
-// The same tree with four children per node and quantised boxes (bvh_build.cpp::build_qtree: every node of the binary tree
-// absorbs the children of its largest children): 64 B = ONE item.  Per axis the node has an origin `org` and a
+// The same tree with four children per node and quantised boxes (bvh_build.cpp::build_qtree: the children of a Q node are a
+// frontier of <= 4 subtrees below a binary node, chosen by dynamic programming over the area of the quantised boxes): 64 B = ONE item.  Per axis the node has an origin `org` and a
 // step `s` (extent / 253); child i's box is [fma(qlo[i], s, org), fma(qhi[i], s, org)] in single precision with 8-bit qlo / qhi (byte i of the
 // word), rounded outwards: the builder evaluates that very expression and moves a bound out until the result encloses the
 // binary tree's (already widened) box.  The traversal rebuilds the bounds the same way and then runs the binary tree's slab

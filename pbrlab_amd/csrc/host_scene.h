@@ -72,12 +72,18 @@ struct FlatBvh {
 void build_bvh(const std::vector<float>& lo, const std::vector<float>& hi, const std::vector<uint8_t>& kinds,
                FlatBvh* out);
 
-// The binary tree collapsed to four children per node with quantised boxes (dscene.h::QNode): a node takes its two
-// children and, while it has room, replaces the inner child of largest surface area by that child's two children.
+// The binary tree collapsed to four children per node with quantised boxes (dscene.h::QNode).  Which descendants of a
+// binary node become the children of its Q node -- a frontier of at most four subtrees below it -- is chosen bottom-up by
+// dynamic programming over the surface-area cost WITH THE BOX A CHILD REALLY PRESENTS: its box rounded outwards on the node's
+// 8-bit grid (a thin primitive in a big node is a thick slab).
 // map_leaf turns a leaf reference of the binary tree into one or two children of the Q tree (its references use the Q
 // tree's own triangle slots and curve points; a curve leaf whose two pieces are not neighbours in a chain becomes two):
-// it fills ref / lo / hi (boxes as stored in the binary tree: already widened) and returns the count.
-// Returns the stack depth a near-first traversal of the Q tree can need (three pushes per level).
+// it fills ref / lo / hi and returns the count.  PRECONDITION on lo / hi (QChild): they are boxes as the binary tree stores
+// them, i.e. already widened with BvhNode::widen_lo / widen_hi -- for a curve leaf that map_leaf splits, the box of each piece
+// (end points +- the larger radius) widened the same way; quantise_node only rounds outwards from there, and the
+// traversal's exactness argument needs every stored box to contain the validation boxes below it.
+// Returns the EXACT stack need of a near-first traversal of the Q tree: the maximum over root-to-leaf paths of the sum of
+// (children - 1) of the nodes on the path (a node pushes all hit children but the nearest).
 struct QChild {
   uint32_t ref;
   float lo[3], hi[3];

@@ -79,6 +79,26 @@ constexpr uint32_t trace_blocks_per_cu(bool curves, bool wide) {
   return wide ? (curves ? kTraceBlocksPerCUWideCurves : kTraceBlocksPerCUWide) : (curves ? kTraceBlocksPerCUCurves : kTraceBlocksPerCU);
 }
 constexpr uint32_t kTraceGridCap = 256 * (kTraceBlocksPerCU > kTraceBlocksPerCUCurves ? kTraceBlocksPerCU : kTraceBlocksPerCUCurves);  // persistent traversal: at most the resident blocks (sizes the spill area)
+// The two-rays-per-lane traversal (dtrace_pv2.h, Q tree): blocks per CU (each wave carries 128 rays) and the LDS part of a ray's stack
+#ifndef PB_TRACE2_BLOCKS
+#define PB_TRACE2_BLOCKS 5
+#endif
+#ifndef PB_TRACE2_BLOCKS_CURVES
+#define PB_TRACE2_BLOCKS_CURVES 3
+#endif
+#ifndef PB_LDS_STACK2
+#define PB_LDS_STACK2 12
+#endif
+constexpr int kPv2LdsStack = PB_LDS_STACK2;  // stack entries per RAY kept in LDS
+constexpr uint32_t trace2_blocks_per_cu(bool curves) { return curves ? PB_TRACE2_BLOCKS_CURVES : PB_TRACE2_BLOCKS; }
+constexpr uint32_t kTrace2GridCap = 256 * (PB_TRACE2_BLOCKS > PB_TRACE2_BLOCKS_CURVES ? PB_TRACE2_BLOCKS : PB_TRACE2_BLOCKS_CURVES);
+// words of traversal-stack spill area one path group (or one hook call) needs: every resident thread of the largest traversal
+// grid x the entries of its stack(s) that do not live in LDS (the one-ray-per-lane kernels -- k_tail, the simple hooks -- run
+// smaller grids: (kStackDepth - kSimpleLdsStack) x 4096 x 256 and x PB_TAIL_BLOCKS x 256)
+constexpr size_t kSpillWordsPv = (size_t)kStackDepth * kTraceGridCap * 256;
+constexpr size_t kSpillWordsPv2 = (size_t)2 * (kStackDepth - kPv2LdsStack) * kTrace2GridCap * 256;
+constexpr size_t kSpillWords = kSpillWordsPv > kSpillWordsPv2 ? kSpillWordsPv : kSpillWordsPv2;
+static_assert((size_t)(kStackDepth - kSimpleLdsStack) * 4096 * 256 <= kSpillWords, "spill area of the one-ray-per-lane hook grids (grid_for(n, 4096))");
 constexpr uint32_t kShadeGridCap = 256 * 8;
 constexpr int kMaxGroups = 8;
 constexpr uint32_t kWaveLogWaves = 8192, kWaveLogLaunches = 64;  // PBRHIP_WAVE_LOG buffer: launches x waves x 4 words  // concurrent path groups (one HIP stream each)

@@ -17,8 +17,10 @@
 // k_tail runs the same per-path functions in a loop once few paths are left; k_generate (render.cc:160-171) and
 // k_accumulate (render.cc:175-183) bracket a chunk of passes.
 #include "dshade.h"
-#include "dtrace_pv.h"
 #include "kernels.h"
+#include "dtrace_pv.h"
+#include "dtrace_pv2.h"
+#include "dtrace_q.h"
 
 namespace pb {
 
@@ -152,6 +154,33 @@ struct TraceSinkT {
 
 using TraceSink = TraceSinkT<false>;
 
+__device__ __forceinline__ void trace_stats_out(const PathState& P, const TravStats& st, uint32_t n_closest, uint32_t n_shadow) {
+    uint32_t v[13] = {st.nodes, st.tris, st.curves, st.anodes, st.atris, st.acurves, st.it_node, st.it_tri, st.it_curve,
+                      st.it_refill, st.ln_node, st.ln_tri, st.ln_curve};
+    const uint32_t idx[13] = {kStatClosestNodes, kStatClosestTris, kStatClosestCurves, kStatShadowNodes, kStatShadowTris,
+                              kStatShadowCurves, kStatPvItNode, kStatPvItTri, kStatPvItCurve, kStatPvItRefill,
+                              kStatPvLnNode, kStatPvLnTri, kStatPvLnCurve};
+    for (int i = 0; i < 13; i++) {
+      uint32_t s = wave_sum(v[i]);
+      if (__lane_id() == 0 && s) atomicAdd(&P.stats[idx[i]], (unsigned long long)s);
+    }
+    for (int i = 0; i < 8; i++) {
+      uint32_t s = wave_sum(st.hist[i]);
+      if (__lane_id() == 0 && s) atomicAdd(&P.stats[kStatStepHist0 + i], (unsigned long long)s);
+    }
+    for (int i = 0; i < 8; i++) {
+      uint32_t s = wave_sum(st.ahist[i]);
+      if (__lane_id() == 0 && s) atomicAdd(&P.stats[kStatAnyHist0 + i], (unsigned long long)s);
+    }
+    atomicMax(&P.stats[kStatAnyMaxSteps], (unsigned long long)st.amax_steps);
+    atomicMax(&P.stats[kStatMaxSteps], (unsigned long long)st.max_steps);
+    if (__lane_id() == 0) atomicMax(&P.stats[kStatMaxWaveIters], (unsigned long long)(st.it_node + st.it_tri + st.it_curve + st.it_refill));
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+      atomicAdd(&P.stats[kStatClosestRays], (unsigned long long)n_closest);
+      atomicAdd(&P.stats[kStatShadowRays], (unsigned long long)n_shadow);
+    }
+}
+
 template <bool STATS, bool CURVES, bool WIDE = false>
 __global__ __launch_bounds__(kBlock, trace_blocks_per_cu(CURVES, WIDE)) void k_trace(PathState P, DScene sc) {
   __shared__ uint32_t stk[pv_lds_stack<CURVES, WIDE>() * kBlock];
@@ -181,32 +210,46 @@ __global__ __launch_bounds__(kBlock, trace_blocks_per_cu(CURVES, WIDE)) void k_t
       o[0] = t_start, o[1] = wall_clock64(), o[2] = st.it_refill | ((unsigned long long)st.refill_ticks << 32), o[3] = st.it_node + st.it_tri + st.it_curve;
     }
   }
-  if (STATS) {
-    uint32_t v[13] = {st.nodes, st.tris, st.curves, st.anodes, st.atris, st.acurves, st.it_node, st.it_tri, st.it_curve,
-                      st.it_refill, st.ln_node, st.ln_tri, st.ln_curve};
-    const uint32_t idx[13] = {kStatClosestNodes, kStatClosestTris, kStatClosestCurves, kStatShadowNodes, kStatShadowTris,
-                              kStatShadowCurves, kStatPvItNode, kStatPvItTri, kStatPvItCurve, kStatPvItRefill,
-                              kStatPvLnNode, kStatPvLnTri, kStatPvLnCurve};
-    for (int i = 0; i < 13; i++) {
-      uint32_t s = wave_sum(v[i]);
-      if (__lane_id() == 0 && s) atomicAdd(&P.stats[idx[i]], (unsigned long long)s);
-    }
-    for (int i = 0; i < 8; i++) {
-      uint32_t s = wave_sum(st.hist[i]);
-      if (__lane_id() == 0 && s) atomicAdd(&P.stats[kStatStepHist0 + i], (unsigned long long)s);
-    }
-    for (int i = 0; i < 8; i++) {
-      uint32_t s = wave_sum(st.ahist[i]);
-      if (__lane_id() == 0 && s) atomicAdd(&P.stats[kStatAnyHist0 + i], (unsigned long long)s);
-    }
-    atomicMax(&P.stats[kStatAnyMaxSteps], (unsigned long long)st.amax_steps);
-    atomicMax(&P.stats[kStatMaxSteps], (unsigned long long)st.max_steps);
-    if (__lane_id() == 0) atomicMax(&P.stats[kStatMaxWaveIters], (unsigned long long)(st.it_node + st.it_tri + st.it_curve + st.it_refill));
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-      atomicAdd(&P.stats[kStatClosestRays], (unsigned long long)n_closest);
-      atomicAdd(&P.stats[kStatShadowRays], (unsigned long long)n_shadow);
-    }
+  if (STATS) trace_stats_out(P, st, n_closest, n_shadow);
+}
+
+// The same launch on the two-rays-per-lane traversal (dtrace_pv2.h; Q tree only): fewer waves per SIMD, each carrying 128 rays.
+template <bool STATS, bool CURVES>
+__global__ __launch_bounds__(kBlock, trace2_blocks_per_cu(CURVES)) void k_trace2(PathState P, DScene sc) {
+  __shared__ uint32_t stk[2 * kPv2LdsStack * kBlock];
+  __shared__ float frm[CURVES ? 20 * kBlock : 1];
+  constexpr bool kStageTop = !CURVES && kTopNodes > 0;
+  __shared__ float4 top[kStageTop ? kTopNodes * 4 : 1];
+  const uint32_t ntop = kStageTop ? sc.wide_top_nodes : 0u;
+  if (kStageTop) {
+    for (uint32_t i = threadIdx.x; i < ntop * 4u; i += kBlock) top[i] = sc.wide[i];
+    __syncthreads();
   }
+  const uint32_t n_closest = P.counts[kCntIn], n_shadow = P.counts[kCntShadowIn];
+  TravStats st = {};
+  uint32_t overflow = 0u;
+  TraceSinkT<CURVES> sink = {P, n_closest};
+  trace_pv2<2, STATS, CURVES>(sc, n_closest + n_shadow, &P.counts[kCntHead], sink, stk + threadIdx.x, kBlock,
+                              P.spill + blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, st, &overflow,
+                              CURVES ? frm + threadIdx.x : nullptr, top, ntop);
+  if (overflow) P.counts[kCntOverflow] = 1u;
+  if (STATS) trace_stats_out(P, st, n_closest, n_shadow);
+}
+
+// The same launch on the pooled traversal (dtrace_q.h; Q tree, triangle-only scenes): one block of 16 waves per CU, the rays
+// of a block in LDS, full batches of same-phase work.
+static_assert((size_t)(kStackDepth - kQStack) * 256 * kQRays <= kSpillWords, "spill area of the pooled traversal (256 blocks)");
+__global__ __launch_bounds__(kQBlock, 1) void k_trace_q(PathState P, DScene sc) {
+  __shared__ QPool pool;
+  const uint32_t n_closest = P.counts[kCntIn], n_shadow = P.counts[kCntShadowIn];
+  uint32_t overflow = 0u;
+  TraceSinkT<false> sink = {P, n_closest};
+  trace_pool<2>(sc, n_closest + n_shadow, &P.counts[kCntHead], sink, pool, P.spill + blockIdx.x * kQRays, gridDim.x * kQRays, &overflow, P.stats);
+  if (P.stats && threadIdx.x == 0 && blockIdx.x == 0) {
+    atomicAdd(&P.stats[kStatClosestRays], (unsigned long long)n_closest);
+    atomicAdd(&P.stats[kStatShadowRays], (unsigned long long)n_shadow);
+  }
+  if (overflow) P.counts[kCntOverflow] = overflow;
 }
 
 // ------------------------------------------------------------------ ordered stream compaction, few atomics
@@ -1274,6 +1317,15 @@ __global__ __launch_bounds__(kBlock) void k_hook_pv(DScene sc, const float4* __r
                              spill + blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, st, &overflow, CURVES ? frm + threadIdx.x : nullptr);
   if (overflow) counts[kCntOverflow] = 1u;
 }
+template <bool ANY>
+__global__ __launch_bounds__(kQBlock, 1) void k_hook_q(DScene sc, const float4* __restrict__ rays, uint32_t n, HookHit* hits, uint8_t* occ,
+                                                      uint32_t* counts, uint32_t* spill) {
+  __shared__ QPool pool;
+  uint32_t overflow = 0u;
+  HookSink sink = {sc, rays, hits, occ};
+  trace_pool<ANY ? 1 : 0>(sc, n, &counts[kCntHead], sink, pool, spill + blockIdx.x * kQRays, gridDim.x * kQRays, &overflow);
+  if (overflow) counts[kCntOverflow] = overflow;
+}
 // One ray per thread, plain stack traversal (dtrace.h): an independent second implementation, selected with
 // PBRHIP_SIMPLE_TRAVERSAL=1, that must agree with the production traversal bit for bit.
 template <bool CURVES, bool WIDE>
@@ -1333,6 +1385,25 @@ static inline bool use_wide(const DScene& sc) {
     else hipLaunchKernelGGL((KERNEL<PRE, false, false>), __VA_ARGS__);                          \
   } while (0)
 bool trace_uses_wide(const DScene& sc) { return use_wide(sc); }
+// the two-rays-per-lane traversal (dtrace_pv2.h) serves the Q tree; PBRHIP_TRACE2=0: one ray per lane (read per launch)
+#ifndef PB_TRACE2_DEFAULT
+#define PB_TRACE2_DEFAULT 0
+#endif
+#ifndef PB_TRACE2_DEFAULT_CURVES
+#define PB_TRACE2_DEFAULT_CURVES 0
+#endif
+// the pooled traversal (dtrace_q.h) serves the Q tree of triangle-only scenes; PBRHIP_TRACEQ=0/1 (read per launch)
+#ifndef PB_TRACEQ_DEFAULT
+#define PB_TRACEQ_DEFAULT 0
+#endif
+static inline bool use_pool() {
+  const char* e = getenv("PBRHIP_TRACEQ");
+  return e ? atoi(e) != 0 : PB_TRACEQ_DEFAULT != 0;
+}
+static inline bool use_two_rays(bool curves) {
+  const char* e = getenv("PBRHIP_TRACE2");
+  return e ? atoi(e) != 0 : (curves ? PB_TRACE2_DEFAULT_CURVES != 0 : PB_TRACE2_DEFAULT != 0);
+}
 static inline uint32_t grid_for(uint32_t n, uint32_t cap) {
   uint32_t g = (n + kBlock - 1) / kBlock;
   if (g < 1) g = 1;
@@ -1364,6 +1435,26 @@ void launch_trace(hipStream_t s, const PathState& P, const DScene& sc, uint32_t 
     const uint32_t k = (uint32_t)strtoul(b, &end, 10);
     const uint32_t lim = (end && *end == ',') ? (uint32_t)strtoul(end + 1, nullptr, 10) : 0u;
     if (k >= 1u && n_upper <= lim && 256u * k < cap) cap = 256u * k;
+  }
+  if (wide && !curves && use_pool()) {
+    const uint32_t nb = (n_upper + 63u) / 64u;
+    hipLaunchKernelGGL(k_trace_q, dim3(nb < 1u ? 1u : (nb < 256u ? nb : 256u)), dim3(kQBlock), 0, s, P, sc);
+    return;
+  }
+  if (wide && use_two_rays(curves)) {
+    // two rays per lane: a wave carries 128 rays (dtrace_pv2.h)
+    blocks = (n_upper + 8u * rays_per_wave - 1u) / (8u * rays_per_wave);
+    cap = 256u * trace2_blocks_per_cu(curves);
+    if (const char* b = getenv("PBRHIP_TRACE2_BLOCKS")) {
+      const uint32_t k = (uint32_t)strtoul(b, nullptr, 10);
+      if (k >= 1u && 256u * k < cap) cap = 256u * k;
+    }
+    dim3 g2(blocks < 1u ? 1u : (blocks < cap ? blocks : cap));
+    if (stats && curves) hipLaunchKernelGGL((k_trace2<true, true>), g2, dim3(kBlock), 0, s, P, sc);
+    else if (stats) hipLaunchKernelGGL((k_trace2<true, false>), g2, dim3(kBlock), 0, s, P, sc);
+    else if (curves) hipLaunchKernelGGL((k_trace2<false, true>), g2, dim3(kBlock), 0, s, P, sc);
+    else hipLaunchKernelGGL((k_trace2<false, false>), g2, dim3(kBlock), 0, s, P, sc);
+    return;
   }
   dim3 g(blocks < 1u ? 1u : (blocks < cap ? blocks : cap));
   if (stats) PB_LAUNCH_TRAV(k_trace, true, curves, wide, g, dim3(kBlock), 0, s, P, sc);
@@ -1409,6 +1500,9 @@ void launch_accumulate(hipStream_t s, const PathState& P, const uint32_t* pix_in
 #ifndef PB_TAIL_BLOCKS
 #define PB_TAIL_BLOCKS 768u  // 3 blocks per CU (40 KB LDS stack each); A/B on C2: 256 -> 6.4 ms, 512 -> 5.4, 768 -> 4.8, 1024 -> 5.5
 #endif
+static_assert((size_t)(kStackDepth - kSimpleLdsStack) * PB_TAIL_BLOCKS * 256 <= kSpillWords, "k_tail's spill area (one stack per thread of its grid)");
+static_assert(trace_blocks_per_cu(false, true) * 256u <= kTraceGridCap && trace_blocks_per_cu(true, true) * 256u <= kTraceGridCap,
+              "the Q tree's k_trace grids fit the spill area sized by kTraceGridCap");
 #define PB_COMMA ,
 void launch_tail(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc, bool stats, bool media, bool textured) {
   uint32_t blocks = (n_upper + 3u) / 4u;  // one path per wave while that fits, at most 2 blocks per CU
@@ -1443,6 +1537,11 @@ void launch_hook_closest(hipStream_t s, const DScene& sc, const float4* rays, ui
     else hipLaunchKernelGGL((k_hook_closest<true, false>), dim3(grid_for(n, 4096)), dim3(kBlock), 0, s, sc, rays, n, out, counts + kCntOverflow, spill);
     return;
   }
+  if (wide && !curves && use_pool()) {
+    const uint32_t nb = (n + 63u) / 64u;
+    hipLaunchKernelGGL((k_hook_q<false>), dim3(nb < 1u ? 1u : (nb < 256u ? nb : 256u)), dim3(kQBlock), 0, s, sc, rays, n, out, (uint8_t*)nullptr, counts, spill);
+    return;
+  }
   const dim3 g(grid_for(n, kTraceGridCap));
   if (wide && curves) hipLaunchKernelGGL((k_hook_pv<false, true, true>), g, dim3(kBlock), 0, s, sc, rays, n, out, (uint8_t*)nullptr, counts, spill);
   else if (wide) hipLaunchKernelGGL((k_hook_pv<false, false, true>), g, dim3(kBlock), 0, s, sc, rays, n, out, (uint8_t*)nullptr, counts, spill);
@@ -1455,6 +1554,11 @@ void launch_hook_any(hipStream_t s, const DScene& sc, const float4* rays, uint32
     if (wide && curves) hipLaunchKernelGGL((k_hook_any<true, true>), dim3(grid_for(n, 4096)), dim3(kBlock), 0, s, sc, rays, n, out, counts + kCntOverflow, spill);
     else if (wide) hipLaunchKernelGGL((k_hook_any<false, true>), dim3(grid_for(n, 4096)), dim3(kBlock), 0, s, sc, rays, n, out, counts + kCntOverflow, spill);
     else hipLaunchKernelGGL((k_hook_any<true, false>), dim3(grid_for(n, 4096)), dim3(kBlock), 0, s, sc, rays, n, out, counts + kCntOverflow, spill);
+    return;
+  }
+  if (wide && !curves && use_pool()) {
+    const uint32_t nb = (n + 63u) / 64u;
+    hipLaunchKernelGGL((k_hook_q<true>), dim3(nb < 1u ? 1u : (nb < 256u ? nb : 256u)), dim3(kQBlock), 0, s, sc, rays, n, (HookHit*)nullptr, out, counts, spill);
     return;
   }
   const dim3 g(grid_for(n, kTraceGridCap));

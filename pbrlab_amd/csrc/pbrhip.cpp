@@ -41,6 +41,8 @@ int pb::fail(int code, const char* fmt, ...) {
 int pb::current_device() { return g_device; }
 
 extern "C" const char* pbrhip_last_error(void) { return g_err.c_str(); }
+extern "C" uint32_t pbrhip_abi_version(void) { return PBRHIP_ABI_VERSION; }
+extern "C" size_t pbrhip_sizeof_render_stats(void) { return sizeof(pbrhip_render_stats); }
 
 extern "C" int pbrhip_device_count(int* count) {
   if (!count) return fail(PBRHIP_EINVAL, "count is NULL");
@@ -963,7 +965,7 @@ static int ensure_groups(pbrhip_scene* s, uint32_t groups) {
     s->group_streams.push_back(g);
   }
   HIPCHK(s->counts.reserve(kCntNum * kMaxGroups));
-  HIPCHK(s->spill.reserve((size_t)groups * kStackDepth * kTraceGridCap * 256));
+  HIPCHK(s->spill.reserve((size_t)groups * kSpillWords));
   return PBRHIP_OK;
 }
 
@@ -1212,7 +1214,7 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
         hipStream_t gst = lane_stream(lane);
         gr.tm.stream = gst;
         gr.P.counts = s->counts.p + lane * kCntNum;
-        gr.P.spill = s->spill.p + (size_t)lane * kStackDepth * kTraceGridCap * 256;
+        gr.P.spill = s->spill.p + (size_t)lane * kSpillWords;
         uint32_t* hc = lane_hcounts(lane);
         memset(hc, 0, sizeof(uint32_t) * kCntNum);
         hc[kCntIn] = gr.n0;
@@ -1383,7 +1385,7 @@ extern "C" int pbrhip_trace_closest(pbrhip_scene* s, const pbrhip_ray* rays, siz
   HIPCHK(s->counts.reserve(kCntNum * kMaxGroups));
   HIPCHK(hipMemsetAsync(s->counts.p, 0, sizeof(uint32_t) * kCntNum, s->stream));
   HIPCHK(hipMemcpyAsync(s->hook_rays.p, rays, n * sizeof(pbrhip_ray), hipMemcpyHostToDevice, s->stream));
-  HIPCHK(s->spill.reserve((size_t)kStackDepth * kTraceGridCap * 256));
+  HIPCHK(s->spill.reserve(kSpillWords));
   launch_hook_closest(s->stream, s->dscene, s->hook_rays.p, (uint32_t)n, s->hook_hits.p, s->counts.p, s->spill.p,
                       getenv("PBRHIP_SIMPLE_TRAVERSAL") != nullptr);
   HIPCHK(hipGetLastError());
@@ -1406,7 +1408,7 @@ extern "C" int pbrhip_trace_any(pbrhip_scene* s, const pbrhip_ray* rays, size_t 
   HIPCHK(s->counts.reserve(kCntNum * kMaxGroups));
   HIPCHK(hipMemsetAsync(s->counts.p, 0, sizeof(uint32_t) * kCntNum, s->stream));
   HIPCHK(hipMemcpyAsync(s->hook_rays.p, rays, n * sizeof(pbrhip_ray), hipMemcpyHostToDevice, s->stream));
-  HIPCHK(s->spill.reserve((size_t)kStackDepth * kTraceGridCap * 256));
+  HIPCHK(s->spill.reserve(kSpillWords));
   launch_hook_any(s->stream, s->dscene, s->hook_rays.p, (uint32_t)n, s->hook_occ.p, s->counts.p, s->spill.p,
                   getenv("PBRHIP_SIMPLE_TRAVERSAL") != nullptr);
   HIPCHK(hipGetLastError());

@@ -1,0 +1,20 @@
+mkdir -p gpurun_out/r4d
+{
+PBRHIP_TRACEQ=1 timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "soup or hooks or trace or render" 2>&1 | tail -4
+PBRHIP_TRACEQ=1 PBRHIP_PV_STATS=1 SPP=8 timeout 300 python - <<'PY'
+import os, sys
+sys.path.insert(0, os.getcwd())
+import pbrlab_amd as pa
+from pbrlab_amd import scenes
+s = pa.scene_from_desc(scenes.cornell_scene("ggx", seed=1))
+layer = pa.RenderLayer()
+pa.Render(s, 1920, 1080, 8, layer=layer)
+for t in ("0", "1"):
+    os.environ["PBRHIP_TRACEQ"] = t
+    ok, tm = pa.Render(s, 1920, 1080, 8, layer=layer, flags=pa.api.RENDER_TIMING, num_streams=1)
+    print("TRACEQ=%s 8 spp: frame %.1f ms k_trace %.2f" % (t, tm["ms_total"], tm["ms_trace_closest"]), flush=True)
+ok, st = pa.Render(s, 1920, 1080, 8, layer=layer, flags=pa.api.RENDER_STATS, num_streams=1)
+PY
+SPP=8 PBRHIP_TRACEQ=1 PASS_TIMEOUT=200 timeout 900 python scripts/pmc_adhoc.py c2 "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU" 2>&1 | grep -v "^$" | grep "pass\|k_trace"
+} > gpurun_out/r4d/pool.log 2>&1
+cat gpurun_out/r4d/pool.log

@@ -13,6 +13,7 @@ ORACLE_SO = os.environ.get("PBR_ORACLE_SO") or os.path.join(ORACLE_DIR, "libpbr_
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libref_leaf.so")
 
 MATH_LIBM, MATH_F64R = 0, 1
+JOBS_BLOCKS, JOBS_TILE_PASS = 0, 1  # orc_render_jobs: the worker pool's job granularity (pbr_oracle.h)
 
 
 class PrincipledParam(C.Structure):
@@ -88,6 +89,9 @@ def lib():
         L.orc_trace_any.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
         L.orc_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32,
                                  C.c_uint32, C.c_uint32, fp, u32p, C.POINTER(Stats)]
+        L.orc_last_render_busy.restype = C.c_double
+        L.orc_render_jobs.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32,
+                                      C.c_uint32, C.c_uint32, C.c_uint32, fp, u32p, C.POINTER(Stats)]
         L.orc_sample_trace.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                        C.c_uint64, fp, C.POINTER(C.c_uint64), C.c_void_p, C.c_uint32]
         L.orc_sample_trace.restype = C.c_uint32
@@ -258,14 +262,15 @@ class OracleScene:
         return occ
 
     def render(self, width, height, spp, first_pass=0, seed_seq=1234567890, tile_rank=0, tile_world=1, threads=1,
-               math_mode=MATH_LIBM):
+               math_mode=MATH_LIBM, job_mode=JOBS_BLOCKS):
+        """job_mode: JOBS_BLOCKS (schedule-independent image: the checker) or JOBS_TILE_PASS (the reference's pool: timing)"""
         rgba = np.zeros((height, width, 4), np.float32)
         count = np.zeros((height, width), np.uint32)
         st = Stats()
         self.L.orc_set_math_mode(math_mode)
         try:
-            self.L.orc_render(self.h, width, height, spp, first_pass, seed_seq, tile_rank, tile_world, threads,
-                              _ptr(rgba), _ptr(count, u32p), C.byref(st))
+            self.L.orc_render_jobs(self.h, width, height, spp, first_pass, seed_seq, tile_rank, tile_world, threads, job_mode,
+                                   _ptr(rgba), _ptr(count, u32p), C.byref(st))
         finally:
             self.L.orc_set_math_mode(MATH_LIBM)
         return rgba, count, {n: getattr(st, n) for n, _ in Stats._fields_}

@@ -1,0 +1,2 @@
+// forwarding header: the reference's file name -> this repository's drop-in (see include/pbrlab_hip_io.hpp)
+#include "pbrlab_hip_io.hpp"

@@ -39,9 +39,10 @@ def test_shim_renders_on_gpu():
 
 
 @pytest.mark.gpu
-def test_shim_value_types_walk_the_reference_callers_sequences():
-    """tests/cpp/shim_types.cc: pc/pc-common.cc:100-233 + the GUI's material edit loop with pbrlab's own value types
-    (TriangleMesh, Attribute, Texture, MaterialParameter, MeshPtr, float3, FetchMeshMaterialParameters)"""
+def test_shim_value_types_and_material_edits():
+    """tests/cpp/shim_types.cc: a caller written from INTEGRATION.md's API tables with pbrlab's own value types (TriangleMesh,
+    Attribute, Texture, MaterialParameter, MeshPtr, float3, FetchMeshMaterialParameters) and the GUI-style material edit between
+    two Render() calls.  (The reference's own callers are compiled unmodified by tests/test_reference_callers.py.)"""
     build()
     r = subprocess.run([EXE_TYPES], capture_output=True, text=True)
     assert r.returncode == 0 and "shim types ok" in r.stdout, (r.returncode, r.stdout + r.stderr)
