@@ -97,7 +97,27 @@ constexpr uint32_t kTrace2GridCap = 256 * (PB_TRACE2_BLOCKS > PB_TRACE2_BLOCKS_C
 // smaller grids: (kStackDepth - kSimpleLdsStack) x 4096 x 256 and x PB_TAIL_BLOCKS x 256)
 constexpr size_t kSpillWordsPv = (size_t)kStackDepth * kTraceGridCap * 256;
 constexpr size_t kSpillWordsPv2 = (size_t)2 * (kStackDepth - kPv2LdsStack) * kTrace2GridCap * 256;
-constexpr size_t kSpillWords = kSpillWordsPv > kSpillWordsPv2 ? kSpillWordsPv : kSpillWordsPv2;
+// The wave-pooled traversal (dtrace_wp.h): rays per wave, stack entries per ray in LDS, blocks of four waves per CU, and the
+// number of finished / free slots at which a wave delivers and fetches
+#ifndef PB_WP_RAYS
+#define PB_WP_RAYS 152
+#endif
+#ifndef PB_WP_STACK
+#define PB_WP_STACK 8
+#endif
+#ifndef PB_WP_BLOCKS
+#define PB_WP_BLOCKS 3
+#endif
+#ifndef PB_WP_REFILL
+#define PB_WP_REFILL 64
+#endif
+constexpr uint32_t kWpRays = PB_WP_RAYS;        // rays per wave (<= 256: tickets are bytes)
+constexpr int kWpStack = PB_WP_STACK;           // stack entries per ray in LDS (deeper ones: the global spill area)
+constexpr uint32_t kWpRefillAt = PB_WP_REFILL;  // deliver / fetch when this many slots are finished or free
+
+constexpr size_t kSpillWordsWp = (size_t)(kStackDepth - kWpStack) * 256 * PB_WP_BLOCKS * 4 * kWpRays;
+constexpr size_t kSpillWords0 = kSpillWordsPv > kSpillWordsPv2 ? kSpillWordsPv : kSpillWordsPv2;
+constexpr size_t kSpillWords = kSpillWords0 > kSpillWordsWp ? kSpillWords0 : kSpillWordsWp;
 static_assert((size_t)(kStackDepth - kSimpleLdsStack) * 4096 * 256 <= kSpillWords, "spill area of the one-ray-per-lane hook grids (grid_for(n, 4096))");
 constexpr uint32_t kShadeGridCap = 256 * 8;
 constexpr int kMaxGroups = 8;

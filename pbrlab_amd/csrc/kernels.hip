@@ -20,7 +20,7 @@
 #include "kernels.h"
 #include "dtrace_pv.h"
 #include "dtrace_pv2.h"
-#include "dtrace_q.h"
+#include "dtrace_wp.h"
 
 namespace pb {
 
@@ -132,6 +132,22 @@ struct TraceSinkT {
     tag |= 0x80000000u;
     return true;
   }
+  // the wave-pooled traversal (dtrace_wp.h): the direction again, a new nearest hit written through, the end of the ray
+  static constexpr bool kKeepUV = false;
+  __device__ __forceinline__ V3 dir(uint32_t tag) const {
+    const uint32_t p = tag & 0x7FFFFFFFu;
+    return ld3((tag & 0x80000000u) ? P.sh_d[p] : P.ray_d[p]);
+  }
+  __device__ __forceinline__ void accept(uint32_t tag, float t, float u, float v, uint32_t code) const {
+    P.hit[tag & 0x7FFFFFFFu] = make_float4(t, u, v, __uint_as_float(code));
+  }
+  __device__ __forceinline__ void finish(uint32_t tag, const Hit& h, bool occluded) const {
+    if (!(tag & 0x80000000u)) {
+      if (h.slot == kNone) P.hit[tag] = make_float4(h.t, 0.f, 0.f, __uint_as_float(kNone));  // (a hit is in the record already: accept)
+      return;
+    }
+    done(tag, h, occluded);
+  }
   __device__ __forceinline__ void done(uint32_t tag, const Hit& h, bool occluded) const {
     const uint32_t p = tag & 0x7FFFFFFFu;
     if (!(tag & 0x80000000u)) {
@@ -236,20 +252,23 @@ __global__ __launch_bounds__(kBlock, trace2_blocks_per_cu(CURVES)) void k_trace2
   if (STATS) trace_stats_out(P, st, n_closest, n_shadow);
 }
 
-// The same launch on the pooled traversal (dtrace_q.h; Q tree, triangle-only scenes): one block of 16 waves per CU, the rays
-// of a block in LDS, full batches of same-phase work.
-static_assert((size_t)(kStackDepth - kQStack) * 256 * kQRays <= kSpillWords, "spill area of the pooled traversal (256 blocks)");
-__global__ __launch_bounds__(kQBlock, 1) void k_trace_q(PathState P, DScene sc) {
-  __shared__ QPool pool;
+// The same launch on the wave-pooled traversal (dtrace_wp.h; Q tree, triangle-only scenes): every wave owns kWpRays rays in
+// its slice of LDS and steps them in full batches of one phase.
+static_assert((size_t)(kStackDepth - kWpStack) * 256 * PB_WP_BLOCKS * 4 * kWpRays <= kSpillWords, "spill area of the wave-pooled traversal");
+static_assert(sizeof(WavePool<false>) * 4 * PB_WP_BLOCKS <= 160 * 1024, "PB_WP_BLOCKS blocks of four wave pools per CU");
+__global__ __launch_bounds__(kBlock, PB_WP_BLOCKS) void k_trace_wp(PathState P, DScene sc) {
+  __shared__ WavePool<false> pools[kBlock / 64];
   const uint32_t n_closest = P.counts[kCntIn], n_shadow = P.counts[kCntShadowIn];
   uint32_t overflow = 0u;
   TraceSinkT<false> sink = {P, n_closest};
-  trace_pool<2>(sc, n_closest + n_shadow, &P.counts[kCntHead], sink, pool, P.spill + blockIdx.x * kQRays, gridDim.x * kQRays, &overflow, P.stats);
+  const uint32_t wave = threadIdx.x >> 6, gwave = blockIdx.x * (kBlock / 64) + wave, nwaves = gridDim.x * (kBlock / 64);
+  trace_wp<2, false>(sc, n_closest + n_shadow, &P.counts[kCntHead], sink, pools[wave], P.spill + (size_t)gwave * kWpRays, nwaves * kWpRays,
+                     &overflow, P.stats);
+  if (overflow) P.counts[kCntOverflow] = overflow;
   if (P.stats && threadIdx.x == 0 && blockIdx.x == 0) {
     atomicAdd(&P.stats[kStatClosestRays], (unsigned long long)n_closest);
     atomicAdd(&P.stats[kStatShadowRays], (unsigned long long)n_shadow);
   }
-  if (overflow) P.counts[kCntOverflow] = overflow;
 }
 
 // ------------------------------------------------------------------ ordered stream compaction, few atomics
@@ -1304,6 +1323,11 @@ struct HookSink {
     if (occ) occ[i] = occluded ? 1 : 0;
     else hits[i] = hook_result(sc, ld3(rays[2 * i]), ld3(rays[2 * i + 1]), h);
   }
+  // the wave-pooled traversal (dtrace_wp.h) keeps this sink's (u, v) and hands over the whole hit at the end
+  static constexpr bool kKeepUV = true;
+  __device__ __forceinline__ V3 dir(uint32_t i) const { return ld3(rays[2 * i + 1]); }
+  __device__ __forceinline__ void accept(uint32_t, float, float, float, uint32_t) const {}
+  __device__ __forceinline__ void finish(uint32_t i, const Hit& h, bool occluded) const { done(i, h, occluded); }
 };
 template <bool ANY, bool CURVES, bool WIDE>  // CURVES / WIDE: the variant k_trace runs for this scene (the Q tree, with or without curves)
 __global__ __launch_bounds__(kBlock) void k_hook_pv(DScene sc, const float4* __restrict__ rays, uint32_t n, HookHit* hits,
@@ -1318,12 +1342,13 @@ __global__ __launch_bounds__(kBlock) void k_hook_pv(DScene sc, const float4* __r
   if (overflow) counts[kCntOverflow] = 1u;
 }
 template <bool ANY>
-__global__ __launch_bounds__(kQBlock, 1) void k_hook_q(DScene sc, const float4* __restrict__ rays, uint32_t n, HookHit* hits, uint8_t* occ,
+__global__ __launch_bounds__(kBlock, 2) void k_hook_wp(DScene sc, const float4* __restrict__ rays, uint32_t n, HookHit* hits, uint8_t* occ,
                                                       uint32_t* counts, uint32_t* spill) {
-  __shared__ QPool pool;
+  __shared__ WavePool<true> pools[kBlock / 64];
   uint32_t overflow = 0u;
   HookSink sink = {sc, rays, hits, occ};
-  trace_pool<ANY ? 1 : 0>(sc, n, &counts[kCntHead], sink, pool, spill + blockIdx.x * kQRays, gridDim.x * kQRays, &overflow);
+  const uint32_t wave = threadIdx.x >> 6, gwave = blockIdx.x * (kBlock / 64) + wave, nwaves = gridDim.x * (kBlock / 64);
+  trace_wp<ANY ? 1 : 0, true>(sc, n, &counts[kCntHead], sink, pools[wave], spill + (size_t)gwave * kWpRays, nwaves * kWpRays, &overflow);
   if (overflow) counts[kCntOverflow] = overflow;
 }
 // One ray per thread, plain stack traversal (dtrace.h): an independent second implementation, selected with
@@ -1392,13 +1417,13 @@ bool trace_uses_wide(const DScene& sc) { return use_wide(sc); }
 #ifndef PB_TRACE2_DEFAULT_CURVES
 #define PB_TRACE2_DEFAULT_CURVES 0
 #endif
-// the pooled traversal (dtrace_q.h) serves the Q tree of triangle-only scenes; PBRHIP_TRACEQ=0/1 (read per launch)
-#ifndef PB_TRACEQ_DEFAULT
-#define PB_TRACEQ_DEFAULT 0
+// the wave-pooled traversal (dtrace_wp.h): PBRHIP_TRACEWP=0/1 (read per launch)
+#ifndef PB_TRACEWP_DEFAULT
+#define PB_TRACEWP_DEFAULT 0
 #endif
-static inline bool use_pool() {
-  const char* e = getenv("PBRHIP_TRACEQ");
-  return e ? atoi(e) != 0 : PB_TRACEQ_DEFAULT != 0;
+static inline bool use_wave_pool() {
+  const char* e = getenv("PBRHIP_TRACEWP");
+  return e ? atoi(e) != 0 : PB_TRACEWP_DEFAULT != 0;
 }
 static inline bool use_two_rays(bool curves) {
   const char* e = getenv("PBRHIP_TRACE2");
@@ -1436,9 +1461,9 @@ void launch_trace(hipStream_t s, const PathState& P, const DScene& sc, uint32_t 
     const uint32_t lim = (end && *end == ',') ? (uint32_t)strtoul(end + 1, nullptr, 10) : 0u;
     if (k >= 1u && n_upper <= lim && 256u * k < cap) cap = 256u * k;
   }
-  if (wide && !curves && use_pool()) {
-    const uint32_t nb = (n_upper + 63u) / 64u;
-    hipLaunchKernelGGL(k_trace_q, dim3(nb < 1u ? 1u : (nb < 256u ? nb : 256u)), dim3(kQBlock), 0, s, P, sc);
+  if (wide && !curves && use_wave_pool()) {
+    const uint32_t nb = (n_upper + 4u * rays_per_wave - 1u) / (4u * rays_per_wave), capw = 256u * PB_WP_BLOCKS;
+    hipLaunchKernelGGL(k_trace_wp, dim3(nb < 1u ? 1u : (nb < capw ? nb : capw)), dim3(kBlock), 0, s, P, sc);
     return;
   }
   if (wide && use_two_rays(curves)) {
@@ -1537,9 +1562,9 @@ void launch_hook_closest(hipStream_t s, const DScene& sc, const float4* rays, ui
     else hipLaunchKernelGGL((k_hook_closest<true, false>), dim3(grid_for(n, 4096)), dim3(kBlock), 0, s, sc, rays, n, out, counts + kCntOverflow, spill);
     return;
   }
-  if (wide && !curves && use_pool()) {
-    const uint32_t nb = (n + 63u) / 64u;
-    hipLaunchKernelGGL((k_hook_q<false>), dim3(nb < 1u ? 1u : (nb < 256u ? nb : 256u)), dim3(kQBlock), 0, s, sc, rays, n, out, (uint8_t*)nullptr, counts, spill);
+  if (wide && !curves && use_wave_pool()) {
+    const uint32_t nb = (n + 255u) / 256u;
+    hipLaunchKernelGGL((k_hook_wp<false>), dim3(nb < 1u ? 1u : (nb < 512u ? nb : 512u)), dim3(kBlock), 0, s, sc, rays, n, out, (uint8_t*)nullptr, counts, spill);
     return;
   }
   const dim3 g(grid_for(n, kTraceGridCap));
@@ -1556,9 +1581,9 @@ void launch_hook_any(hipStream_t s, const DScene& sc, const float4* rays, uint32
     else hipLaunchKernelGGL((k_hook_any<true, false>), dim3(grid_for(n, 4096)), dim3(kBlock), 0, s, sc, rays, n, out, counts + kCntOverflow, spill);
     return;
   }
-  if (wide && !curves && use_pool()) {
-    const uint32_t nb = (n + 63u) / 64u;
-    hipLaunchKernelGGL((k_hook_q<true>), dim3(nb < 1u ? 1u : (nb < 256u ? nb : 256u)), dim3(kQBlock), 0, s, sc, rays, n, (HookHit*)nullptr, out, counts, spill);
+  if (wide && !curves && use_wave_pool()) {
+    const uint32_t nb = (n + 255u) / 256u;
+    hipLaunchKernelGGL((k_hook_wp<true>), dim3(nb < 1u ? 1u : (nb < 512u ? nb : 512u)), dim3(kBlock), 0, s, sc, rays, n, (HookHit*)nullptr, out, counts, spill);
     return;
   }
   const dim3 g(grid_for(n, kTraceGridCap));

@@ -615,6 +615,33 @@ def test_triangle_soup_and_ties(pa, seed, extra_slivers):
                 os.environ.pop("PBRHIP_SIMPLE_TRAVERSAL", None)
 
 
+@pytest.mark.parametrize("which", ["PBRHIP_TRACE2", "PBRHIP_TRACEWP"])
+def test_alternative_traversals_bit_exact(pa, pairs, which):
+    """The two traversal kernels of round 4 that were measured and not selected -- two rays per lane (dtrace_pv2.h) and the
+    wave-pooled traversal (dtrace_wp.h) -- stay in the library behind PBRHIP_TRACE2 / PBRHIP_TRACEWP (read per launch): hits
+    do not depend on the visiting order, so soups (ties, slivers, tmax == hit distance) and whole renders are bit-identical."""
+    import _soups
+    desc, so, rays = _soups.triangle_soup(2, 30)
+    hb = so.trace_closest(rays, brute_force=True)
+    short = rays.copy()
+    short["tmax"] = np.where(np.isfinite(hb["t"]) & (hb["instance_id"] != 0xFFFFFFFF), hb["t"], 1.0)
+    ob = so.trace_any(short, brute_force=True)
+    sg = pa.scene_from_desc(desc)
+    os.environ[which] = "1"
+    try:
+        assert_hits_equal(sg.trace_closest(rays), hb)
+        assert np.array_equal(sg.trace_any(short), ob)
+        for name in ("ggx", "sss") + (("hair",) if which == "PBRHIP_TRACE2" else ()):
+            _, g, o = pairs[name]
+            rgba, cnt, _ = o.render(96, 64, 4, threads=4, math_mode=O.MATH_F64R)
+            for tail in (0xFFFFFFFF, 3000):
+                layer = pa.RenderLayer()
+                pa.Render(g, 96, 64, 4, layer=layer, tail_paths=tail)
+                assert np.array_equal(layer.count, cnt) and layer.rgba.tobytes() == rgba.tobytes(), (which, name, tail)
+    finally:
+        os.environ.pop(which, None)
+
+
 @pytest.mark.parametrize("seed", range(4))
 def test_curve_soup(pa, seed):
     """Random cubic ribbons incl. duplicates, degenerate (all control points equal), zero-radius and straight ones, with a
