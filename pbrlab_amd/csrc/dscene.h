@@ -36,6 +36,14 @@ constexpr int kSimpleLdsStack = 40;          // of which the one-ray-per-lane tr
 #define PB_TOP_NODES 64
 #endif
 constexpr int kTopNodes = PB_TOP_NODES;
+// ... and the Q tree's kernels.  0 since round 4: with the packed two-triangle leaf test the triangle kernel is at its register
+// budget and the staging branch costs it a spill; same-box A/B on C2 (k_trace ms per frame, two runs each): no staging 33.9 / 33.6,
+// 64 nodes 35.1 / 34.8, 128 nodes 34.9 / 35.0, 256 nodes (12 stack entries in LDS) 34.8 / 35.3 -- the top of the tree is served by
+// the vector L1 either way (profiles/README.md).
+#ifndef PB_TOP_NODES_WIDE
+#define PB_TOP_NODES_WIDE 0
+#endif
+constexpr int kTopNodesWide = PB_TOP_NODES_WIDE;
 
 // Both children's boxes, interleaved [axis][child] so that the two children's values of one bound sit in an aligned
 // register pair after the 16-byte loads: the slab test runs on v_pk_add_f32 / v_pk_mul_f32 (two children per instruction).
@@ -63,7 +71,8 @@ static_assert(sizeof(BvhNode) == 64, "node must be 64 B");
 // binary tree's (already widened) box.  The traversal rebuilds the bounds the same way and then runs the binary tree's slab
 // arithmetic on them, so the quantised test inherits its properties (monotone in the box, correct for axis-parallel rays).
 // Child references: an inner child = its item index; a triangle leaf = kLeafBit | first << 3 | (count - 1) with `first` the
-// index into the tree's own compact triangle slots (DScene::q_tri0; 48 B each); a curve leaf = kLeafBit | kCurveBit | first << 3 |
+// index of the leaf's TriPair among the tree's own triangle records (DScene::q_tri0; 80 B each, below; scenes with curves: of
+// its first 48-byte triangle slot); a curve leaf = kLeafBit | kCurveBit | first << 3 |
 // (count - 1) with `first` a POINT index (DScene::q_pt0): the linear pieces of a strand are stored as a chain of points
 // (xyz + radius, 16 B), piece p = points p, p + 1, piece-in-cubic index = p & 3 (every cubic starts at a multiple of 4).
 // An unused child has reference kEmptyChild.
@@ -75,6 +84,14 @@ struct alignas(16) QNode {
   uint32_t c[4];
 };
 static_assert(sizeof(QNode) == 64, "quantised wide node must be 64 B");
+// A triangle leaf of the Q tree of a TRIANGLE-ONLY scene (scenes with curves keep 48 bytes per triangle -- three corners, the
+// hit code in the third word's .w -- one after the other: their kernels have no registers to spare for the packed test and
+// meet triangles rarely): its one or two triangles (a, b) interleaved coordinate by coordinate, five 16-byte words
+//   (v0x_a v0x_b v0y_a v0y_b) (v0z_a v0z_b v1x_a v1x_b) (v1y_a v1y_b v1z_a v1z_b) (v2x_a v2x_b v2y_a v2y_b) (v2z_a v2z_b code_a code_b)
+// so that the two triangles' values of one coordinate sit in an aligned register pair after the loads and the intersection test
+// runs on packed fp32 for both (dtrace.h::tri_test_pair).  code = the complete hit code (slot | routing bits); a leaf of ONE
+// triangle stores it twice with code_b = kNone.  80 B per leaf instead of 48 B per triangle: -17 % for a pair, +67 % for a single.
+constexpr uint32_t kTriPairWords = 5;
 // during a traversal of the Q tree a curve hit is held as kQPointHit | point index; it becomes the hit code every other
 // stage sees (slot | routing bits, below) through DScene::q_hitcode when the ray is delivered
 constexpr uint32_t kQPointHit = 0x80000000u;
@@ -191,10 +208,10 @@ struct DScene {
   const float* tex_pixels;
   const TexDesc* textures;
   uint32_t num_nodes, num_slots, num_lights, num_materials, num_curves, num_textures, num_lrecs;
-  const float4* wide;           // Q tree (4-wide, quantised): wide_nodes x QNode, its compact triangle slots (48 B: corners, .w of the third
-                                // word = the hit code slot | routing bits), the points of the curve pieces (16 B); or null
+  const float4* wide;           // Q tree (4-wide, quantised): wide_nodes x QNode, its triangle leaves (TriPair, 80 B), the points of the
+                                // curve pieces (16 B); or null
   uint32_t wide_nodes;
-  uint32_t q_tri0, q_pt0;       // 16-byte index of triangle slot 0 / point 0 in `wide`
+  uint32_t q_tri0, q_pt0;       // 16-byte index of triangle leaf record 0 / point 0 in `wide`
   const uint32_t* q_hitcode;    // per point p: the hit code of piece p (slot | routing bits)
   uint32_t top_nodes;           // nodes 0 .. top_nodes-1 are the breadth-first top of the tree (<= kTopNodes; 0: not numbered that way)
   uint32_t wide_top_nodes;      // the same for the Q tree

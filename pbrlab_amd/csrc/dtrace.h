@@ -76,6 +76,77 @@ __device__ __forceinline__ bool tri_test(V3 v0, V3 v1, V3 v2, V3 o, V3 d, V3 inv
   return true;
 }
 
+// Two triangles at once on packed fp32 (v_pk_*): the triangle leaves of the Q tree hold one or two triangles, stored
+// interleaved (TriPair, dscene.h: every pair of words = the same coordinate of triangle a and of triangle b), so that after the
+// 16-byte loads the two values sit in an aligned register pair and every +, -, x of tri_test / hit_inside is ONE instruction for
+// both.  Per triangle the operations and their order are tri_test's, so each half returns tri_test's bits; nothing is skipped on
+// a failed condition (in SIMT an early exit saves nothing unless the whole wave takes it).  ok[i]: triangle i has an accepted hit
+// in (tmin, +inf) -- the caller compares with the ray's tmax.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 f2s(float a) { return f2{a, a}; }
+__device__ __forceinline__ void tri_test_pair(const float4& w0, const float4& w1, const float4& w2, const float4& w3, const float4& w4, V3 o, V3 d,
+                                              V3 inv3, float tmin, bool& ok_a, bool& ok_b, f2& t, f2& u, f2& v) {
+  const f2 v0x = {w0.x, w0.y}, v0y = {w0.z, w0.w}, v0z = {w1.x, w1.y};
+  const f2 v1x = {w1.z, w1.w}, v1y = {w2.x, w2.y}, v1z = {w2.z, w2.w};
+  const f2 v2x = {w3.x, w3.y}, v2y = {w3.z, w3.w}, v2z = {w4.x, w4.y};
+  const f2 dx = f2s(d.x), dy = f2s(d.y), dz = f2s(d.z), ox = f2s(o.x), oy = f2s(o.y), oz = f2s(o.z);
+  const f2 e1x = v1x - v0x, e1y = v1y - v0y, e1z = v1z - v0z;
+  const f2 e2x = v2x - v0x, e2y = v2y - v0y, e2z = v2z - v0z;
+  const f2 px = dy * e2z - dz * e2y, py = dz * e2x - dx * e2z, pz = dx * e2y - dy * e2x;  // cross(d, e2)
+  const f2 det = e1x * px + e1y * py + e1z * pz;
+  const f2 inv = {1.0f / det.x, 1.0f / det.y};
+  const f2 sx = ox - v0x, sy = oy - v0y, sz = oz - v0z;
+  const f2 uu = (sx * px + sy * py + sz * pz) * inv;
+  const f2 qx = sy * e1z - sz * e1y, qy = sz * e1x - sx * e1z, qz = sx * e1y - sy * e1x;  // cross(s, e1)
+  const f2 vv = (dx * qx + dy * qy + dz * qz) * inv;
+  const f2 tt = (e2x * qx + e2y * qy + e2z * qz) * inv;
+  const f2 uv = uu + vv;
+  // hit_inside on the triangles' own boxes
+  const f2 lox = __builtin_elementwise_min(__builtin_elementwise_min(v0x, v1x), v2x), loy = __builtin_elementwise_min(__builtin_elementwise_min(v0y, v1y), v2y),
+           loz = __builtin_elementwise_min(__builtin_elementwise_min(v0z, v1z), v2z);
+  const f2 hix = __builtin_elementwise_max(__builtin_elementwise_max(v0x, v1x), v2x), hiy = __builtin_elementwise_max(__builtin_elementwise_max(v0y, v1y), v2y),
+           hiz = __builtin_elementwise_max(__builtin_elementwise_max(v0z, v1z), v2z);
+  const f2 c = f2s(7.62939453125e-06f), tiny = f2s(1e-31f), e = f2s(1.52587890625e-05f);
+  auto vlo = [&](f2 x) { return __builtin_elementwise_fma(-__builtin_elementwise_abs(x), c, x) - tiny; };
+  auto vhi = [&](f2 x) { return __builtin_elementwise_fma(__builtin_elementwise_abs(x), c, x) + tiny; };
+  f2 t0 = (vlo(lox) - ox) * f2s(inv3.x), t1 = (vhi(hix) - ox) * f2s(inv3.x);
+  f2 a = __builtin_elementwise_min(t0, t1), b = __builtin_elementwise_max(t0, t1);
+  t0 = (vlo(loy) - oy) * f2s(inv3.y), t1 = (vhi(hiy) - oy) * f2s(inv3.y);
+  a = __builtin_elementwise_max(a, __builtin_elementwise_min(t0, t1)), b = __builtin_elementwise_min(b, __builtin_elementwise_max(t0, t1));
+  t0 = (vlo(loz) - oz) * f2s(inv3.z), t1 = (vhi(hiz) - oz) * f2s(inv3.z);
+  a = __builtin_elementwise_max(a, __builtin_elementwise_min(t0, t1)), b = __builtin_elementwise_min(b, __builtin_elementwise_max(t0, t1));
+  a = __builtin_elementwise_fma(-__builtin_elementwise_abs(a), e, a), b = __builtin_elementwise_fma(__builtin_elementwise_abs(b), e, b);
+  ok_a = det.x != 0.0f && uu.x >= 0.0f && uu.x <= 1.0f && vv.x >= 0.0f && uv.x <= 1.0f && tt.x > tmin && a.x <= tt.x && tt.x <= b.x;
+  ok_b = det.y != 0.0f && uu.y >= 0.0f && uu.y <= 1.0f && vv.y >= 0.0f && uv.y <= 1.0f && tt.y > tmin && a.y <= tt.y && tt.y <= b.y;
+  t = tt, u = uu, v = vv;
+}
+// one triangle leaf of the Q tree (the five words of its TriPair) against a ray whose current interval ends at hit.t with hit
+// `hit` (slot == kNone: none yet): the reference order -- triangle a, then triangle b -- of the accept rule "t <= tmax, equal
+// distances go to the smaller canonical id".  Returns true when the ray is an any-hit ray and a triangle was accepted.
+__device__ __forceinline__ uint32_t q_gid(const DScene& sc, uint32_t code);
+template <bool ANY_CT, bool STATS>
+__device__ __forceinline__ bool tri_pair_accept(const DScene& sc, const float4& w0, const float4& w1, const float4& w2, const float4& w3, const float4& w4,
+                                                V3 o, V3 d, V3 inv3, float tmin, bool any_rt, Hit& hit, uint32_t& ntested) {
+  bool ok_a, ok_b;
+  f2 t, u, v;
+  tri_test_pair(w0, w1, w2, w3, w4, o, d, inv3, tmin, ok_a, ok_b, t, u, v);
+  const uint32_t code_a = __float_as_uint(w4.z), code_b = __float_as_uint(w4.w);
+  ok_b = ok_b && code_b != kNone;  // (a leaf of one triangle stores it twice: the second copy is not a candidate)
+  if (STATS) ntested += code_b != kNone ? 2u : 1u;
+  const bool any_ray = ANY_CT || any_rt;
+  bool acc_a = ok_a && t.x <= hit.t;
+  if (!any_ray) {
+    if (acc_a && t.x == hit.t && hit.slot != kNone) acc_a = q_gid(sc, code_a) < q_gid(sc, hit.slot);  // tie: the smaller canonical id wins
+    if (acc_a) hit.t = t.x, hit.u = u.x, hit.v = v.x, hit.slot = code_a;
+  }
+  bool acc_b = ok_b && t.y <= hit.t;
+  if (!any_ray) {
+    if (acc_b && t.y == hit.t && hit.slot != kNone) acc_b = q_gid(sc, code_b) < q_gid(sc, hit.slot);
+    if (acc_b) hit.t = t.y, hit.u = u.y, hit.v = v.y, hit.slot = code_b;
+  }
+  return any_ray && (acc_a || acc_b);
+}
+
 // dP/du of the cubic: what Embree reports as Ng for flat curves (hair-shader.cc:165-166 uses it as tangent)
 __device__ __forceinline__ V3 bezier_tangent(const float4 cp[4], float u) {
   float s = 1.0f - u;
@@ -135,7 +206,6 @@ __device__ __forceinline__ bool segment_test(const float4& a, const float4& b, u
 // first three 16-byte words of a BvhNode: (lo.x pair, lo.y pair), (lo.z pair, hi.x pair), (hi.y pair, hi.z pair), each
 // pair = (child 0, child 1).  The interval is widened by 2^-16 relative; the test only has to be conservative (hits do
 // not depend on which boxes are visited), so the widening may use fma.
-typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void box_test2(const float4& n0, const float4& n1, const float4& n2, V3 o, V3 inv, float tmin,
                                           float tmax, bool& h0, bool& h1, float& t0, float& t1) {
   const f2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
@@ -227,12 +297,21 @@ __device__ __forceinline__ bool leaf_test(const DScene& sc, uint32_t leaf, V3 o,
   const bool ANY = MODE == 2 ? any_rt : (MODE == 1);
   uint32_t first = (leaf & 0x3FFFFFFFu) >> 3, count = (leaf & 7u) + 1u;
   bool is_curve = (leaf & kCurveBit) != 0;
+  if (WIDE && !CURVES) {  // Q tree of a triangle-only scene: one TriPair per leaf (dscene.h), both triangles in one packed test
+    const float4* g = sc.wide + sc.q_tri0 + (size_t)first * kTriPairWords;
+    const float4 w0 = g[0], w1 = g[1], w2 = g[2], w3 = g[3], w4 = g[4];
+    uint32_t nt = 0u;
+    const bool occluded = tri_pair_accept<MODE == 1, STATS>(sc, w0, w1, w2, w3, w4, o, d, inv, tmin, ANY, hit, nt);
+    if (STATS) st.tris += nt;
+    best_t = hit.t;
+    return occluded;
+  }
   for (uint32_t s = first; s < first + count; s++) {
     float t, u, v;
     bool ok;
     uint32_t code;
-    if (WIDE) {  // Q tree: compact triangle slots / chains of curve points (dscene.h)
-      if (!CURVES || !is_curve) {
+    if (WIDE) {  // Q tree of a scene with curves: 48-byte triangle slots / chains of curve points (dscene.h)
+      if (!is_curve) {
         const float4* g = sc.wide + sc.q_tri0 + (size_t)s * 3;
         float4 a = g[0], b = g[1], c = g[2];
         if (STATS) st.tris++;

@@ -153,6 +153,7 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
   float4 D0 = make_float4(0, 0, 0, 0), D1 = D0, D2 = D0;  // prefetched node / primitive slot (a curve piece of the Q tree: its two points in D0, D1)
   float2 D3 = make_float2(0, 0);                           // a node's two child references
   float4 D3w = D0;                                         // WIDE: the four child references of a QNode (D0..D2 = origin, steps, quantised bounds)
+  float4 D4 = D0;                                          // WIDE, triangle-only scenes: the fifth word of a triangle leaf (TriPair, dscene.h: D0..D3w + D4)
   // the array the traversal walks: the binary tree's nodes then the slots (64-byte items), or the Q tree (16-byte words)
   const float4* const items = WIDE ? sc.wide : reinterpret_cast<const float4*>(sc.nodes);
   const uint32_t slot0 = sc.num_nodes;  // binary tree: item index of slot 0
@@ -366,7 +367,19 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
         // ---- TRI / CURVE phase: one primitive per lane
         const bool is_tri = state == kStTri, is_curve = CURVES && state == kStCurve;
         const bool mine = (phase == 1) ? is_tri : is_curve;
-        if (mine) {
+        if (WIDE && !CURVES && mine) {
+          // a triangle leaf of the Q tree of a triangle-only scene: its one or two triangles in ONE packed test (TriPair; dtrace.h::tri_pair_accept)
+          if (STATS) steps++;
+          uint32_t nt = 0u;
+          const bool occ = tri_pair_accept<MODE == 1, STATS>(sc, D0, D1, D2, D3w, D4, o, d, V3(inv4.x, inv4.y, inv4.z), tmin, any_ray, hit, nt);
+          if (STATS) (any_ray ? st.atris : st.tris) += nt;
+          if (occ) {
+            state = kStDoneOccluded;
+            if (STATS) st.ahist[steps <= 16u ? 0 : (28 - __clz(steps - 1u) > 7 ? 7 : 28 - __clz(steps - 1u))]++, st.amax_steps = steps > st.amax_steps ? steps : st.amax_steps;
+          } else {
+            advance = true;  // leaf done: pop
+          }
+        } else if (mine) {
           if (STATS) steps++;
           float t, u, v;
           bool ok;
@@ -426,7 +439,8 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
           const uint32_t first = (next & 0x3FFFFFFFu) >> 3;
           rem = next & 7u;
           state = (CURVES && (next & kCurveBit)) ? kStCurve : kStTri;
-          if (WIDE) cur = (CURVES && (next & kCurveBit)) ? sc.q_pt0 + first : sc.q_tri0 + 3u * first;
+          if (WIDE && !CURVES) rem = 0u;  // (a triangle leaf of a triangle-only scene's Q tree is one item: TriPair)
+          if (WIDE) cur = (CURVES && (next & kCurveBit)) ? sc.q_pt0 + first : sc.q_tri0 + (CURVES ? 3u : kTriPairWords) * first;
           else cur = first + slot0;  // slots follow the nodes in one array of 64-byte items
         } else {
           cur = WIDE ? 4u * next : next;
@@ -435,14 +449,15 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
       }
     }
     if (WIDE && need_load) {
-      if (!CURVES && kTopNodes > 0 && cur < 4u * ntop) {  // the top of the Q tree (triangle-only scenes): every ray passes through it
+      if (!CURVES && kTopNodesWide > 0 && cur < 4u * ntop) {  // the top of the Q tree (triangle-only scenes): every ray passes through it
         const float4* g = top + cur;
         D0 = g[0], D1 = g[1], D2 = g[2], D3w = g[3];
       } else {
         const float4* g = items + cur;
         D0 = g[0], D1 = g[1];
         if (!CURVES || state != kStCurve) D2 = g[2];
-        if (state == kStNode) D3w = g[3];
+        if (!CURVES || state == kStNode) D3w = g[3];
+        if (!CURVES && state == kStTri) D4 = g[4];
       }
     } else if (need_load) {
       if (kTopNodes > 0 && cur < ntop) {  // the top of the tree: every ray passes through it

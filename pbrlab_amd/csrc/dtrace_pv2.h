@@ -195,7 +195,7 @@ __device__ __forceinline__ void trace_pv2(const DScene& sc, uint32_t n, uint32_t
       // ---- NODE turn
       if (mine) {
         float4 D0, D1, D2, D3w;
-        if (!CURVES && kTopNodes > 0 && A.cur < 4u * ntop) {
+        if (!CURVES && kTopNodesWide > 0 && A.cur < 4u * ntop) {
           const float4* g = top + A.cur;
           D0 = g[0], D1 = g[1], D2 = g[2], D3w = g[3];
         } else {
@@ -243,10 +243,20 @@ __device__ __forceinline__ void trace_pv2(const DScene& sc, uint32_t n, uint32_t
         float4 D2 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (!is_curve) D2 = g[2];
         if (STATS) A.steps++;
-        float t, u, v;
-        bool ok;
+        float t = 0.f, u = 0.f, v = 0.f;
+        bool ok = false;
         const V3 o(A.ox, A.oy, A.oz), inv(A.ix, A.iy, A.iz);
-        if (!is_curve) {
+        if (!CURVES) {
+          // a triangle leaf of a triangle-only scene's Q tree: one TriPair, both triangles in one packed test (dtrace.h)
+          const float4 w3 = g[3], w4 = g[4];
+          Hit h = {A.t, A.u, A.v, A.slot};
+          uint32_t nt = 0u;
+          const bool occ = tri_pair_accept<MODE == 1, STATS>(sc, D0, D1, D2, w3, w4, o, V3(A.dx, A.dy, A.dz), inv, A.tmin, any_ray, h, nt);
+          if (STATS) (any_ray ? st.atris : st.tris) += nt;
+          A.t = h.t, A.u = h.u, A.v = h.v, A.slot = h.slot;
+          if (occ) A.pk = (A.pk & ~kPkState) | kStDoneOccluded;
+          else advance = true;
+        } else if (!is_curve) {
           if (STATS) (any_ray ? st.atris : st.tris)++;
           ok = tri_test(ld3(D0), ld3(D1), ld3(D2), o, V3(A.dx, A.dy, A.dz), inv, A.tmin, t, u, v) && (t <= A.t);
         } else {
@@ -261,7 +271,9 @@ __device__ __forceinline__ void trace_pv2(const DScene& sc, uint32_t n, uint32_t
         const uint32_t code = is_curve ? (kQPointHit | (A.cur - sc.q_pt0)) : __float_as_uint(D2.w);
         if (ok && !any_ray && t == A.t && A.slot != kNone) ok = q_gid(sc, code) < q_gid(sc, A.slot);
         if (ok) A.t = t, A.u = u, A.v = v, A.slot = code;
-        if (any_ray && ok) {
+        if (!CURVES) {
+          // (handled above)
+        } else if (any_ray && ok) {
           A.pk = (A.pk & ~kPkState) | kStDoneOccluded;
           if (STATS) st.ahist[A.steps <= 16u ? 0 : (28 - __clz(A.steps - 1u) > 7 ? 7 : 28 - __clz(A.steps - 1u))]++, st.amax_steps = A.steps > st.amax_steps ? A.steps : st.amax_steps;
         } else if (A.pk & kPkRem) {  // next primitive of the same leaf
@@ -294,8 +306,8 @@ __device__ __forceinline__ void trace_pv2(const DScene& sc, uint32_t n, uint32_t
         if (next & kLeafBit) {
           const uint32_t first = (next & 0x3FFFFFFFu) >> 3;
           const bool curve = CURVES && (next & kCurveBit);
-          A.pk = (A.pk & ~(kPkState | kPkRem)) | (curve ? kStCurve : kStTri) | ((next & 7u) << kPkRemShift);
-          A.cur = curve ? sc.q_pt0 + first : sc.q_tri0 + 3u * first;
+          A.pk = (A.pk & ~(kPkState | kPkRem)) | (curve ? kStCurve : kStTri) | (CURVES ? ((next & 7u) << kPkRemShift) : 0u);
+          A.cur = curve ? sc.q_pt0 + first : sc.q_tri0 + (CURVES ? 3u : kTriPairWords) * first;
         } else {
           A.cur = 4u * next;
           A.pk = (A.pk & ~(kPkState | kPkRem)) | kStNode;

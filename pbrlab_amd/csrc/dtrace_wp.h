@@ -106,8 +106,7 @@ __device__ __forceinline__ void trace_wp(const DScene& sc, uint32_t n, uint32_t*
       meta = (meta & ~kWmSp) | sp;
     }
     if (next & kLeafBit) {
-      cur = sc.q_tri0 + 3u * ((next & 0x3FFFFFFFu) >> 3);
-      meta = (meta & ~kWmRem) | ((next & 7u) << kWmRemShift);
+      cur = sc.q_tri0 + kTriPairWords * ((next & 0x3FFFFFFFu) >> 3);
       return kWTri;
     }
     cur = 4u * next;
@@ -165,30 +164,23 @@ __device__ __forceinline__ void trace_wp(const DScene& sc, uint32_t n, uint32_t*
         const uint4 mm = S.m[r];
         uint32_t cur = mm.x, meta = mm.y;
         const V3 d = sink.dir(mm.z);
-        const float4* g = items + cur;
-        const float4 D0 = g[0], D1 = g[1], D2 = g[2];
+        const float4* g = items + cur;  // a triangle leaf of the Q tree: one TriPair, both triangles in one packed test
+        const float4 w0 = g[0], w1 = g[1], w2 = g[2], w3 = g[3], w4 = g[4];
         const bool any_ray = (MODE == 1) || (MODE == 2 && (meta & kWmAny) != 0u);
-        float t, u, v;
-        bool ok = tri_test(ld3(D0), ld3(D1), ld3(D2), V3(o4.x, o4.y, o4.z), d, V3(i4.x, i4.y, i4.z), o4.w, t, u, v) && (t <= i4.w);
-        const uint32_t code = __float_as_uint(D2.w);
-        if (ok && !any_ray && t == i4.w && mm.w != kNone) ok = q_gid(sc, code) < q_gid(sc, mm.w);  // tie: the smaller canonical id wins
-        if (any_ray && ok) {
+        Hit h = {i4.w, 0.f, 0.f, mm.w};
+        uint32_t nt = 0u;
+        const bool occ = tri_pair_accept<MODE == 1, false>(sc, w0, w1, w2, w3, w4, V3(o4.x, o4.y, o4.z), d, V3(i4.x, i4.y, i4.z), o4.w, any_ray, h, nt);
+        if (occ) {
           meta |= kWmOccluded;
           dest = kWDone;
         } else {
-          if (ok) {
-            S.a1[r].w = t;
-            S.m[r].w = code;
-            if (UV) S.uv[UV ? r : 0u] = make_float2(u, v);
-            else sink.accept(mm.z, t, u, v, code);
+          if (h.slot != mm.w || h.t != i4.w) {  // a new nearest hit
+            S.a1[r].w = h.t;
+            S.m[r].w = h.slot;
+            if (UV) S.uv[UV ? r : 0u] = make_float2(h.u, h.v);
+            else sink.accept(mm.z, h.t, h.u, h.v, h.slot);
           }
-          if (meta & kWmRem) {  // next primitive of the same leaf
-            meta -= 1u << kWmRemShift;
-            cur += 3u;
-            dest = kWTri;
-          } else {
-            dest = next_item(r, kEmptyChild, cur, meta);  // leaf done: pop
-          }
+          dest = next_item(r, kEmptyChild, cur, meta);  // leaf done: pop
         }
         *reinterpret_cast<uint2*>(&S.m[r]) = make_uint2(cur, meta);
       }

@@ -202,9 +202,10 @@ __global__ __launch_bounds__(kBlock, trace_blocks_per_cu(CURVES, WIDE)) void k_t
   __shared__ uint32_t stk[pv_lds_stack<CURVES, WIDE>() * kBlock];
   __shared__ float frm[CURVES ? 10 * kBlock : 1];
   // the top of the tree in LDS (triangle-only scenes: with the ribbon frames of curve scenes it would cost a block per CU)
-  constexpr bool kStageTop = !CURVES && kTopNodes > 0;
-  __shared__ float4 top[kStageTop ? kTopNodes * 4 : 1];
-  const uint32_t ntop = kStageTop ? (WIDE ? sc.wide_top_nodes : sc.top_nodes) : 0u;
+  constexpr int kTopHere = WIDE ? kTopNodesWide : kTopNodes;
+  constexpr bool kStageTop = !CURVES && kTopHere > 0;
+  __shared__ float4 top[kStageTop ? kTopHere * 4 : 1];
+  const uint32_t ntop = kStageTop ? (WIDE ? (sc.wide_top_nodes < (uint32_t)kTopHere ? sc.wide_top_nodes : (uint32_t)kTopHere) : sc.top_nodes) : 0u;
   if (kStageTop) {
     const float4* src = WIDE ? sc.wide : reinterpret_cast<const float4*>(sc.nodes);  // (binary node and Q node: 64 bytes each)
     for (uint32_t i = threadIdx.x; i < ntop * 4u; i += kBlock) top[i] = src[i];
@@ -234,9 +235,9 @@ template <bool STATS, bool CURVES>
 __global__ __launch_bounds__(kBlock, trace2_blocks_per_cu(CURVES)) void k_trace2(PathState P, DScene sc) {
   __shared__ uint32_t stk[2 * kPv2LdsStack * kBlock];
   __shared__ float frm[CURVES ? 20 * kBlock : 1];
-  constexpr bool kStageTop = !CURVES && kTopNodes > 0;
-  __shared__ float4 top[kStageTop ? kTopNodes * 4 : 1];
-  const uint32_t ntop = kStageTop ? sc.wide_top_nodes : 0u;
+  constexpr bool kStageTop = !CURVES && kTopNodesWide > 0;
+  __shared__ float4 top[kStageTop ? kTopNodesWide * 4 : 1];
+  const uint32_t ntop = kStageTop ? (sc.wide_top_nodes < (uint32_t)kTopNodesWide ? sc.wide_top_nodes : (uint32_t)kTopNodesWide) : 0u;
   if (kStageTop) {
     for (uint32_t i = threadIdx.x; i < ntop * 4u; i += kBlock) top[i] = sc.wide[i];
     __syncthreads();

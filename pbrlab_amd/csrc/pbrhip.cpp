@@ -676,24 +676,43 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
       }
       for (int k = 0; k < 4; k++) qpts.push_back(make_float4(0.f, 0.f, 0.f, 0.f));  // (the last piece reads point p + 1)
     }
-    // compact triangle slots (.w of the third word = the complete hit code) and the per-point hit codes
-    std::vector<uint32_t> tri_rank(ns, 0);
+    // the complete hit code of every slot (slot | routing bits); curve pieces: per point
+    std::vector<uint32_t> slot_code(ns, kNone);
     qhit.assign(qpts.size(), kNone);
     for (uint32_t k = 0; k < ns; k++) {
       const uint32_t g = bvh.slot_gid[k];
-      const uint32_t code = k | __builtin_bit_cast(uint32_t, slots[4 * (size_t)k + 2].w);
-      if (prims[g].kind == 0) {
-        tri_rank[k] = (uint32_t)(qtri.size() / 3);  // 48 bytes per triangle: three corners, the hit code in the third word's .w
-        for (int c = 0; c < 3; c++) qtri.push_back(slots[4 * (size_t)k + c]);
-        qtri.back().w = __builtin_bit_cast(float, code);
-      } else {
-        qhit[piece_point[g]] = code;
-      }
+      slot_code[k] = k | __builtin_bit_cast(uint32_t, slots[4 * (size_t)k + 2].w);
+      if (prims[g].kind != 0) qhit[piece_point[g]] = slot_code[k];
     }
+    // Triangle leaves.  Triangle-only scenes: one TriPair per leaf (dscene.h): its one or two triangles interleaved coordinate by
+    // coordinate, 80 bytes, both tested at once on packed fp32.  Scenes with curves (their kernels have no registers to spare
+    // and meet triangles rarely): 48 bytes per triangle -- three corners, the hit code in the third word's .w -- one after the other.
+    bool tri_pairs = true;
+    for (uint8_t kd : kinds) tri_pairs = tri_pairs && kd == 0;
+    auto tri_pair = [&](uint32_t first, uint32_t count) -> uint32_t {
+      if (!tri_pairs) {
+        const uint32_t rec = (uint32_t)(qtri.size() / 3);
+        for (uint32_t i = 0; i < count; i++) {
+          for (int c = 0; c < 3; c++) qtri.push_back(slots[4 * (size_t)(first + i) + c]);
+          qtri.back().w = __builtin_bit_cast(float, slot_code[first + i]);
+        }
+        return rec;
+      }
+      const uint32_t rec = (uint32_t)(qtri.size() / kTriPairWords);
+      const float4* a = &slots[4 * (size_t)first];
+      const float4* b = count == 2 ? &slots[4 * (size_t)(first + 1)] : a;  // (one triangle: stored twice, the copy is no candidate)
+      const float ca = __builtin_bit_cast(float, slot_code[first]), cb = __builtin_bit_cast(float, count == 2 ? slot_code[first + 1] : kNone);
+      qtri.push_back(make_float4(a[0].x, b[0].x, a[0].y, b[0].y));
+      qtri.push_back(make_float4(a[0].z, b[0].z, a[1].x, b[1].x));
+      qtri.push_back(make_float4(a[1].y, b[1].y, a[1].z, b[1].z));
+      qtri.push_back(make_float4(a[2].x, b[2].x, a[2].y, b[2].y));
+      qtri.push_back(make_float4(a[2].z, b[2].z, ca, cb));
+      return rec;
+    };
     auto map_leaf = [&](uint32_t ref, const float* blo, const float* bhi, QChild* o) -> int {
       const uint32_t first = (ref & 0x3FFFFFFFu) >> 3, count = (ref & 7u) + 1u;
       if (!(ref & kCurveBit)) {
-        o[0].ref = kLeafBit | (tri_rank[first] << 3) | (count - 1u);
+        o[0].ref = kLeafBit | (tri_pair(first, count) << 3) | (count - 1u);
         for (int a = 0; a < 3; a++) o[0].lo[a] = blo[a], o[0].hi[a] = bhi[a];
         return 1;
       }
@@ -717,7 +736,7 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
     if (qpts.size() >= (1u << 27) || build_qtree(bvh.nodes, map_leaf, &wide) > (uint32_t)kStackDepth) wide.clear();
   }
   if (wide.empty()) s->d_wide.release(), s->d_qhit.release();
-  if (getenv("PBRHIP_DEBUG")) fprintf(stderr, "pbrhip: commit: %u binary nodes, %zu wide nodes, %zu slots, %zu triangle slots + %zu points in the Q tree\n", num_nodes, wide.size(), (size_t)ns, qtri.size() / 3, qpts.size());
+  if (getenv("PBRHIP_DEBUG")) fprintf(stderr, "pbrhip: commit: %u binary nodes, %zu wide nodes, %zu slots, %zu triangle leaves + %zu points in the Q tree\n", num_nodes, wide.size(), (size_t)ns, qtri.size() / kTriPairWords, qpts.size());
   if (!wide.empty()) {
     HIPCHK(s->d_wide.reserve(wide.size() * 4 + qtri.size() + qpts.size()));
     HIPCHK(hipMemcpyAsync(s->d_wide.p, wide.data(), wide.size() * sizeof(QNode), hipMemcpyHostToDevice, st));

@@ -21,7 +21,7 @@ BUDGETS = {
     "k_trace<false, true, false>": (80, 0),     # binary tree, curves: 6 waves
     "k_trace<false, false, true>": (80, 0),     # Q tree, triangles: 6 waves
     "k_trace<false, true, true>": (80, 0),      # Q tree, curves: 6 waves
-    "k_sss_walk<false, false, true>": (168, 0),  # 3 waves per SIMD, nothing spilled
+    "k_sss_walk<false, false, true>": (168, 24),  # 3 waves per SIMD; 24 B since the packed two-triangle leaf test (round 4): measured 31.1 -> 29.6 ms per 64 spp of C3 WITH them
     "k_sss_walk<false, false, false>": (168, 0),
     "k_sss_walk<false, true, false>": (168, 0),
     "k_sss_walk<false, true, true>": (168, 0),
@@ -30,11 +30,11 @@ BUDGETS = {
     # general shading kernel alone is 9 % faster at two, the C3 frame 2 % slower; k_tail likewise in round 2): pinned as they are
     "k_shade_principled<1>": (168, 44),          # media, no texture (C3, C5): the medium's coefficients come from the material record
     "k_shade_principled<2>": (168, 128),         # textured materials: ParamToBsdf and the medium per hit
-    "k_tail<0, false, false, true>": (168, 20),    # no medium, no texture (C2)
+    "k_tail<0, false, false, true>": (168, 52),    # no medium, no texture (C2); 20 -> 52 B with the packed two-triangle leaf test (C2 k_tail 3.7-4.2 -> 3.5-3.8 ms)
     "k_tail<0, false, true, true>": (168, 20),     # ... with curves (C4)
-    "k_tail<1, false, false, true>": (168, 168),   # media (C3)
+    "k_tail<1, false, false, true>": (168, 200),   # media (C3)
     "k_tail<1, false, true, true>": (168, 168),    # media + curves (C5)
-    "k_tail<2, false, false, true>": (168, 176),   # textured materials
+    "k_tail<2, false, false, true>": (168, 216),   # textured materials
     "k_shade_hair": (136, 0),
     "k_sss_step": (160, 0),
     "k_classify": (64, 0),
