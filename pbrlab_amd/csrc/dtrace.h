@@ -84,12 +84,17 @@ __device__ __forceinline__ bool tri_test(V3 v0, V3 v1, V3 v2, V3 o, V3 d, V3 inv
 // in (tmin, +inf) -- the caller compares with the ray's tmax.
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 f2s(float a) { return f2{a, a}; }
-__device__ __forceinline__ void tri_test_pair(const float4& w0, const float4& w1, const float4& w2, const float4& w3, const float4& w4, V3 o, V3 d,
-                                              V3 inv3, float tmin, bool& ok_a, bool& ok_b, f2& t, f2& u, f2& v) {
+__device__ __forceinline__ f2 vbox_lo2(f2 x) { return __builtin_elementwise_fma(-__builtin_elementwise_abs(x), f2s(7.62939453125e-06f), x) - f2s(1e-31f); }  // vbox_lo, two at once
+__device__ __forceinline__ f2 vbox_hi2(f2 x) { return __builtin_elementwise_fma(__builtin_elementwise_abs(x), f2s(7.62939453125e-06f), x) + f2s(1e-31f); }
+// (the ray comes as nine scalars: a V3 handed over by value survives as a 12-byte stack object here -- the splats below defeat
+// its scalar replacement -- which the backend then parks in LDS, 3 KB per block)
+__device__ __forceinline__ void tri_test_pair(const float4& w0, const float4& w1, const float4& w2, const float4& w3, const float4& w4, float o_x,
+                                              float o_y, float o_z, float d_x, float d_y, float d_z, float i_x, float i_y, float i_z, float tmin,
+                                              bool& ok_a, bool& ok_b, f2& t, f2& u, f2& v) {
   const f2 v0x = {w0.x, w0.y}, v0y = {w0.z, w0.w}, v0z = {w1.x, w1.y};
   const f2 v1x = {w1.z, w1.w}, v1y = {w2.x, w2.y}, v1z = {w2.z, w2.w};
   const f2 v2x = {w3.x, w3.y}, v2y = {w3.z, w3.w}, v2z = {w4.x, w4.y};
-  const f2 dx = f2s(d.x), dy = f2s(d.y), dz = f2s(d.z), ox = f2s(o.x), oy = f2s(o.y), oz = f2s(o.z);
+  const f2 dx = f2s(d_x), dy = f2s(d_y), dz = f2s(d_z), ox = f2s(o_x), oy = f2s(o_y), oz = f2s(o_z);
   const f2 e1x = v1x - v0x, e1y = v1y - v0y, e1z = v1z - v0z;
   const f2 e2x = v2x - v0x, e2y = v2y - v0y, e2z = v2z - v0z;
   const f2 px = dy * e2z - dz * e2y, py = dz * e2x - dx * e2z, pz = dx * e2y - dy * e2x;  // cross(d, e2)
@@ -106,14 +111,12 @@ __device__ __forceinline__ void tri_test_pair(const float4& w0, const float4& w1
            loz = __builtin_elementwise_min(__builtin_elementwise_min(v0z, v1z), v2z);
   const f2 hix = __builtin_elementwise_max(__builtin_elementwise_max(v0x, v1x), v2x), hiy = __builtin_elementwise_max(__builtin_elementwise_max(v0y, v1y), v2y),
            hiz = __builtin_elementwise_max(__builtin_elementwise_max(v0z, v1z), v2z);
-  const f2 c = f2s(7.62939453125e-06f), tiny = f2s(1e-31f), e = f2s(1.52587890625e-05f);
-  auto vlo = [&](f2 x) { return __builtin_elementwise_fma(-__builtin_elementwise_abs(x), c, x) - tiny; };
-  auto vhi = [&](f2 x) { return __builtin_elementwise_fma(__builtin_elementwise_abs(x), c, x) + tiny; };
-  f2 t0 = (vlo(lox) - ox) * f2s(inv3.x), t1 = (vhi(hix) - ox) * f2s(inv3.x);
+  const f2 e = f2s(1.52587890625e-05f);
+  f2 t0 = (vbox_lo2(lox) - ox) * f2s(i_x), t1 = (vbox_hi2(hix) - ox) * f2s(i_x);
   f2 a = __builtin_elementwise_min(t0, t1), b = __builtin_elementwise_max(t0, t1);
-  t0 = (vlo(loy) - oy) * f2s(inv3.y), t1 = (vhi(hiy) - oy) * f2s(inv3.y);
+  t0 = (vbox_lo2(loy) - oy) * f2s(i_y), t1 = (vbox_hi2(hiy) - oy) * f2s(i_y);
   a = __builtin_elementwise_max(a, __builtin_elementwise_min(t0, t1)), b = __builtin_elementwise_min(b, __builtin_elementwise_max(t0, t1));
-  t0 = (vlo(loz) - oz) * f2s(inv3.z), t1 = (vhi(hiz) - oz) * f2s(inv3.z);
+  t0 = (vbox_lo2(loz) - oz) * f2s(i_z), t1 = (vbox_hi2(hiz) - oz) * f2s(i_z);
   a = __builtin_elementwise_max(a, __builtin_elementwise_min(t0, t1)), b = __builtin_elementwise_min(b, __builtin_elementwise_max(t0, t1));
   a = __builtin_elementwise_fma(-__builtin_elementwise_abs(a), e, a), b = __builtin_elementwise_fma(__builtin_elementwise_abs(b), e, b);
   ok_a = det.x != 0.0f && uu.x >= 0.0f && uu.x <= 1.0f && vv.x >= 0.0f && uv.x <= 1.0f && tt.x > tmin && a.x <= tt.x && tt.x <= b.x;
@@ -129,7 +132,7 @@ __device__ __forceinline__ bool tri_pair_accept(const DScene& sc, const float4& 
                                                 V3 o, V3 d, V3 inv3, float tmin, bool any_rt, Hit& hit, uint32_t& ntested) {
   bool ok_a, ok_b;
   f2 t, u, v;
-  tri_test_pair(w0, w1, w2, w3, w4, o, d, inv3, tmin, ok_a, ok_b, t, u, v);
+  tri_test_pair(w0, w1, w2, w3, w4, o.x, o.y, o.z, d.x, d.y, d.z, inv3.x, inv3.y, inv3.z, tmin, ok_a, ok_b, t, u, v);
   const uint32_t code_a = __float_as_uint(w4.z), code_b = __float_as_uint(w4.w);
   ok_b = ok_b && code_b != kNone;  // (a leaf of one triangle stores it twice: the second copy is not a candidate)
   if (STATS) ntested += code_b != kNone ? 2u : 1u;

@@ -504,10 +504,18 @@ __device__ __forceinline__ bool misses_all_lights(const DScene& sc, V3 o, V3 d, 
   if (sc.lights_transformed) return false;  // the light records hold local positions, the raytracer tests transformed ones
   if (sc.num_lrecs <= kLightPretest) {
     const V3 inv(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    for (uint32_t i = 0; i < sc.num_lrecs; i++) {
-      const float4* lr = reinterpret_cast<const float4*>(sc.lrecs + i);
-      float t, u, v;
-      if (tri_test(ld3(lr[0]), ld3(lr[1]), ld3(lr[2]), o, d, inv, tmin, t, u, v)) return false;
+    // two light primitives per test on packed fp32 (dtrace.h::tri_test_pair: per triangle tri_test's operations and bits); an odd
+    // last one is tested twice
+    for (uint32_t i = 0; i < sc.num_lrecs; i += 2u) {
+      const float4* la = reinterpret_cast<const float4*>(sc.lrecs + i);
+      const float4* lb = reinterpret_cast<const float4*>(sc.lrecs + (i + 1u < sc.num_lrecs ? i + 1u : i));
+      const float4 a0 = la[0], a1 = la[1], a2 = la[2], b0 = lb[0], b1 = lb[1], b2 = lb[2];
+      bool ok_a, ok_b;
+      f2 t, u, v;
+      tri_test_pair(make_float4(a0.x, b0.x, a0.y, b0.y), make_float4(a0.z, b0.z, a1.x, b1.x), make_float4(a1.y, b1.y, a1.z, b1.z),
+                    make_float4(a2.x, b2.x, a2.y, b2.y), make_float4(a2.z, b2.z, 0.f, 0.f), o.x, o.y, o.z, d.x, d.y, d.z, inv.x, inv.y, inv.z, tmin, ok_a,
+                    ok_b, t, u, v);
+      if (ok_a || ok_b) return false;
     }
     return true;
   }
