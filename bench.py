@@ -49,6 +49,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
 SIMDS, CLOCK_HZ = 1024, 2.4e9   # 256 CUs x 4 SIMDs; MI355X_MICROARCH.md peak engine clock
+GATHER_PEAK_GBS = 256 * 2.4 * 14.6  # per-lane gathers through the vector L1: 14.6 B per clock and CU, measured (scripts/ubench/vmem_quads.hip)
 
 
 def csrc_hash():
@@ -68,11 +69,11 @@ def csrc_hash():
 
 
 def pmc_record(workload, spp, world, kernel):
-    """Counters cannot be read live, so they come from the committed PMC passes of this round (profiles/r3_<workload>_pmc.json,
+    """Counters cannot be read live, so they come from the committed PMC passes of this round (profiles/r4_<workload>_pmc.json,
     written by scripts/profile_round.py: FETCH_SIZE, WRITE_SIZE and SQ counters in separate --pmc passes over one render of
     the same workload, per kernel).  They are only used when that file was collected on the very kernel sources that are
     running (csrc_hash) and on the same configuration; otherwise the counter-based fields are null."""
-    path = os.path.join(ROOT, "profiles", f"r3_{workload}_pmc.json")
+    path = os.path.join(ROOT, "profiles", f"r4_{workload}_pmc.json")
     if world != 1 or not os.path.exists(path):
         return None, "no PMC record for this configuration"
     rec = json.load(open(path))
@@ -91,7 +92,7 @@ def pmc_live(workload, spp, kernel, budget_s):
     """The counters of `kernel` measured by THIS run: rocprofv3 --pmc passes (counters only: no trace flag next to --pmc, one
     pass per counter group as MI355X_MICROARCH.md prescribes; FETCH_SIZE / WRITE_SIZE apart) over one render of the workload as
     one path group in child processes (scripts/render_once.py: the program itself after `--`), after the timed region.
-    Returns (record like profiles/r3_<workload>_pmc.json's kernel entry, note) or (None, why) -- the caller then falls back
+    Returns (record like profiles/r4_<workload>_pmc.json's kernel entry, note) or (None, why) -- the caller then falls back
     to the committed record."""
     import collections
     import csv
@@ -417,6 +418,14 @@ def main():
                 pmc_note = f"{pmc_note} [committed record; {live_note}]" if pmc else f"{pmc_note}; {live_note}"
             traffic = frac_hbm_counter = valu = None
             bound = "hbm"
+            # third ceiling (round 4): the vector-memory GATHER path.  A per-lane 64-byte item fetch (four global_load_dwordx4) is
+            # served at 14.6 bytes per clock and CU whatever the lanes' address pattern (scripts/ubench/vmem_quads.hip: 299 / 274
+            # cycles per 64 x 64 B wave step from L1-resident tables -- own item per lane / four lanes per item -- and 360 / 332 from
+            # L2-resident ones): 256 CUs x 2.4 GHz x 14.6 B = 8.97 TB/s.  Every node, triangle leaf, curve piece and ray record of
+            # k_trace takes that path, so the ALGORITHMIC bytes of a launch over its solo duration are a fraction of THIS peak.
+            gather = {"peak": GATHER_PEAK_GBS, "achieved": bytes_step / (solo_ms * 1e-3) / 1e9, "frac": bytes_step / (solo_ms * 1e-3) / 1e9 / GATHER_PEAK_GBS,
+                      "note": "algorithmic bytes per launch / solo launch duration / the measured per-lane gather throughput of the vector L1 path "
+                              "(14.6 B per clock and CU: scripts/ubench/vmem_quads.hip, profiles/README.md)"}
             if pmc:
                 traffic = pmc["hbm_bytes_per_dispatch_fetch_x2"]
                 # HBM-side bytes per launch / the launch's duration when it has the GPU to itself / the 8 TB/s peak
@@ -432,19 +441,21 @@ def main():
                                     "the VALU pipes are issuing, whatever the EXEC mask; lanes_per_valu = SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU"}
                     if valu["frac"] > frac_hbm_counter:
                         bound = "valu"
+                if gather["frac"] > max(frac_hbm_counter, valu["frac"] if valu else 0.0):
+                    bound = "gather"
             roofline = {"bound": bound, "kernel": "k_trace (closest-hit rays of bounce k + shadow rays of bounce k-1)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                         "note": "achieved / frac = ALGORITHMIC bytes (64 B per node visit -- binary tree or the Q tree's quantised 4-wide node --, 48 B per triangle test, 32 B per curve-piece test on the Q tree (64 on the binary tree), 52 B per ray: SURVEY 8d) / kernel "
                                 "time (HIP events on the launch's own stream, timed region) -- NOT a ceiling: the scene is served from L2 / "
                                 "Infinity Cache, so it can exceed 1.  The ceilings are frac_hbm_counter (HBM-side bytes from the FETCH_SIZE / "
-                                "WRITE_SIZE PMC passes per launch / solo launch duration / 8 TB/s) and valu.frac (VALU issue); `bound` names "
-                                "the larger.  By default the frame runs as two path groups on two HIP streams whose launches overlap, so "
+                                "WRITE_SIZE PMC passes per launch / solo launch duration / 8 TB/s), valu.frac (VALU issue) and gather.frac (the "
+                                "vector-memory gather path, 8.97 TB/s measured); `bound` names the largest.  By default the frame runs as two path groups on two HIP streams whose launches overlap, so "
                                 "per-launch durations of the timed region include shared time; `solo` and kernel_ms_per_step are from an "
                                 "untimed extra render as ONE group, every launch alone on the GPU",
                         "solo": {"launches_per_step": solo["n_trace_closest"], "avg_launch_ms": solo_launch_s * 1e3,
                                  "achieved": bytes_step / (solo_ms * 1e-3) / 1e9,
                                  "frac": bytes_step / (solo_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_frame": solo["ms_total"]},
-                        "traffic": traffic, "frac_hbm_counter": frac_hbm_counter, "valu": valu, "pmc_source": pmc_note,
+                        "traffic": traffic, "frac_hbm_counter": frac_hbm_counter, "valu": valu, "gather": gather, "pmc_source": pmc_note,
                         "algorithmic_bytes_per_launch": bytes_step / max(launches, 1), "node_bytes": node_b, "curve_bytes": curve_b,
                         "avg_launch_ms": ms_step / max(launches, 1), "launches_per_step": launches,
                         "rays_per_step": sst["closest_rays"] + sst["shadow_rays"],

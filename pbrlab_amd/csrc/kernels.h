@@ -34,6 +34,14 @@ struct PathState {
   // ("not the first bounce", MIS weight of emission) is the same bit.
   float cam_org[3];
   uint32_t first;
+  // ... and the camera sample of path slot0 + j itself is a function of j (render.cc:160-171: pixel = pix_index[j % npix], pass =
+  // first_pass + j / npix, two draws of the sample's own generator): the first k_trace and the first shading compute it
+  // (kernels.hip::camera_sample) instead of reading a stored direction, generator state and queue entry (round 4: k_generate only
+  // clears the radiance; 44 -> 16 bytes written and 44 fewer read per path)
+  Camera cam;
+  const uint32_t* pix_index;
+  uint32_t npix, width, first_pass, slot0;
+  uint64_t seed_seq;
   uint32_t no_medium;  // no material of the scene can enter a medium: every shadow ray is an ordinary one (kShNormal), so an occluded one has nothing to deliver
 };
 
@@ -129,8 +137,7 @@ struct HookHit {  // == pbrhip_hit == TraceResult (raytracer.h:9-17)
   uint32_t instance_id, geom_id, prim_id;
 };
 
-void launch_generate(hipStream_t s, const PathState& P, const Camera& cam, const uint32_t* pix_index, uint32_t npix,
-                     uint32_t npaths, uint32_t slot0, uint32_t width, uint32_t first_pass, uint64_t seed_seq);
+void launch_generate(hipStream_t s, const PathState& P, uint32_t npaths);  // clears the radiance of the group's paths (PathState::slot0 ...)
 void launch_trace(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, bool stats);
 bool trace_uses_wide(const DScene& sc);  // the traversal kernels walk the 4-wide tree of this scene (now: PBRHIP_WIDE is read per launch)
 void launch_tail(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc, bool stats, bool media, bool textured);

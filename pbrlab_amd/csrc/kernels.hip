@@ -34,27 +34,26 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 
 __device__ __forceinline__ float4 mk4(V3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
 
-// ------------------------------------------------------------------ k_generate (render.cc:160-171)
-__global__ __launch_bounds__(kBlock) void k_generate(PathState P, Camera cam, const uint32_t* __restrict__ pix_index,
-                                                     uint32_t npix, uint32_t npaths, uint32_t slot0, uint32_t width,
-                                                     uint32_t first_pass, uint64_t seed_seq) {
-  // path slots [slot0, slot0 + npaths) of the chunk belong to this group; its queues start at entry 0
-  for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < npaths; j += gridDim.x * kBlock) {
-    const uint32_t i = slot0 + j;
-    uint32_t pass = first_pass + j / npix;
-    uint32_t gpix = pix_index[j % npix];
-    uint32_t x = gpix % width, y = gpix / width;
-    Rng rng = rng_seed(((uint64_t)pass << 32) + (uint64_t)gpix, seed_seq);
-    float jx = draw(rng);
-    float jy = draw(rng);
-    V3 org(cam.org[0], cam.org[1], cam.org[2]);
-    V3 target(cam.x_corner + cam.dx * ((float)x + jx), cam.y_corner - cam.dy * ((float)y + jy), cam.z_corner);
-    V3 dir = normalize_raw(target - org);
-    P.ray_d[i] = mk4(dir, kInf);  // origin (org, tmin 0), throughput (1, 1, 1, pdf 0) and flags 0 are implied (PathState::first)
-    P.L[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    P.rng[i] = rng.state;
-    P.q_in[j] = i;
-  }
+// ------------------------------------------------------------------ the camera sample (render.cc:160-171)
+// Path slot0 + j of a group: its pixel, its pass, the two draws of its own generator, the ray direction -- and the generator's
+// state after them.  A function of j: the first k_trace (TraceSinkT<.., FIRST>) and the first shading (path_head) evaluate it;
+// nothing of it is stored.
+__device__ __forceinline__ void camera_sample(const PathState& P, uint32_t j, V3& dir, uint64_t& rng_state) {
+  const uint32_t pass = P.first_pass + j / P.npix;
+  const uint32_t gpix = P.pix_index[j % P.npix];
+  const uint32_t x = gpix % P.width, y = gpix / P.width;
+  Rng rng = rng_seed(((uint64_t)pass << 32) + (uint64_t)gpix, P.seed_seq);
+  const float jx = draw(rng);
+  const float jy = draw(rng);
+  const V3 org(P.cam.org[0], P.cam.org[1], P.cam.org[2]);
+  const V3 target(P.cam.x_corner + P.cam.dx * ((float)x + jx), P.cam.y_corner - P.cam.dy * ((float)y + jy), P.cam.z_corner);
+  dir = normalize_raw(target - org);
+  rng_state = rng.state;
+}
+// what is left of the generation pass: the radiance of the group's paths starts at 0 (origin, throughput, flags, direction,
+// generator state and queue entry of the first bounce are implied: PathState::first)
+__global__ __launch_bounds__(kBlock) void k_generate(PathState P, uint32_t npaths) {
+  for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < npaths; j += gridDim.x * kBlock) P.L[P.slot0 + j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
 // ------------------------------------------------------------------ k_trace
@@ -68,7 +67,8 @@ __global__ __launch_bounds__(kBlock) void k_generate(PathState P, Camera cam, co
 //                kShSssExit  L += unoccluded ? c_vis : c_occ
 // SPLIT (dtrace_pv.h): the loads of a refill are issued together, then used.  A/B, frame ms: hair scene (C4) 236.2 -> 231.9,
 // triangle-only scenes 57.2 -> 58.5 (C2, the delivery's L load becomes unconditional), 436 -> 436 (C3): curve scenes only.
-template <bool SPLIT>
+// FIRST: the launch is a group's first (camera rays only: computed, not loaded; no shadow rays yet)
+template <bool SPLIT, bool FIRST = false>
 struct TraceSinkT {
   static constexpr bool kWalk = false;
   static constexpr bool kSplit = SPLIT;
@@ -101,14 +101,24 @@ struct TraceSinkT {
       P.L[p] = make_float4(q.L.x + add.x, q.L.y + add.y, q.L.z + add.z, q.L.w);
     }
   }
+  __device__ __forceinline__ void camera_ray(uint32_t idx, uint32_t& tag, V3& o, V3& d, float& tmin, float& tmax) const {
+    tag = P.slot0 + idx;
+    uint64_t state;
+    camera_sample(P, idx, d, state);
+    o = V3(P.cam_org[0], P.cam_org[1], P.cam_org[2]), tmin = 0.0f, tmax = kInf;
+  }
   __device__ __forceinline__ uint32_t load_entry(uint32_t idx) const {
+    if (FIRST) return 0u;
     return idx < n_closest ? P.q_in[idx] : P.q_shadow_in[idx - n_closest];
   }
   __device__ __forceinline__ bool load_ray(uint32_t idx, uint32_t entry, uint32_t& tag, V3& o, V3& d, float& tmin, float& tmax) const {
+    if (FIRST) {
+      camera_ray(idx, tag, o, d, tmin, tmax);
+      return false;
+    }
     if (idx < n_closest) {
       tag = entry & kQPathMask;
-      float4 o4 = make_float4(P.cam_org[0], P.cam_org[1], P.cam_org[2], 0.0f), d4 = P.ray_d[tag];
-      if (!P.first) o4 = P.ray_o[tag];
+      const float4 o4 = P.ray_o[tag], d4 = P.ray_d[tag];
       o = ld3(o4), d = ld3(d4), tmin = o4.w, tmax = d4.w;
       return false;
     }
@@ -119,10 +129,13 @@ struct TraceSinkT {
     return true;
   }
   __device__ __forceinline__ bool load(uint32_t idx, uint32_t& tag, V3& o, V3& d, float& tmin, float& tmax) const {
+    if (FIRST) {
+      camera_ray(idx, tag, o, d, tmin, tmax);
+      return false;
+    }
     if (idx < n_closest) {
       tag = P.q_in[idx] & kQPathMask;
-      float4 o4 = make_float4(P.cam_org[0], P.cam_org[1], P.cam_org[2], 0.0f), d4 = P.ray_d[tag];
-      if (!P.first) o4 = P.ray_o[tag];
+      const float4 o4 = P.ray_o[tag], d4 = P.ray_d[tag];
       o = ld3(o4), d = ld3(d4), tmin = o4.w, tmax = d4.w;
       return false;
     }
@@ -197,8 +210,10 @@ __device__ __forceinline__ void trace_stats_out(const PathState& P, const TravSt
     }
 }
 
-template <bool STATS, bool CURVES, bool WIDE = false>
-__global__ __launch_bounds__(kBlock, trace_blocks_per_cu(CURVES, WIDE)) void k_trace(PathState P, DScene sc) {
+// FIRST: one block per CU fewer -- the camera sample (64-bit multiplies of the generator, a square root, two divisions) lives in
+// the refill path and would spill 16 dwords into the traversal loop's register budget
+template <bool STATS, bool CURVES, bool WIDE = false, bool FIRST = false>
+__global__ __launch_bounds__(kBlock, trace_blocks_per_cu(CURVES, WIDE) - (FIRST ? 1 : 0)) void k_trace(PathState P, DScene sc) {
   __shared__ uint32_t stk[pv_lds_stack<CURVES, WIDE>() * kBlock];
   __shared__ float frm[CURVES ? 10 * kBlock : 1];
   // the top of the tree in LDS (triangle-only scenes: with the ribbon frames of curve scenes it would cost a block per CU)
@@ -214,9 +229,9 @@ __global__ __launch_bounds__(kBlock, trace_blocks_per_cu(CURVES, WIDE)) void k_t
   const uint32_t n_closest = P.counts[kCntIn], n_shadow = P.counts[kCntShadowIn];
   TravStats st = {};
   uint32_t overflow = 0u;
-  TraceSinkT<CURVES> sink = {P, n_closest};
+  TraceSinkT<CURVES, FIRST> sink = {P, n_closest};
   const unsigned long long t_start = P.wave_log ? wall_clock64() : 0ull;
-  trace_pv<2, STATS, CURVES, WIDE>(sc, n_closest + n_shadow, &P.counts[kCntHead], sink, stk + threadIdx.x, kBlock,
+  trace_pv<FIRST ? 0 : 2, STATS, CURVES, WIDE>(sc, n_closest + (FIRST ? 0u : n_shadow), &P.counts[kCntHead], sink, stk + threadIdx.x, kBlock,
                              P.spill + blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, st, &overflow,
                              CURVES ? frm + threadIdx.x : nullptr, top, ntop);
   if (overflow) P.counts[kCntOverflow] = 1u;
@@ -380,7 +395,7 @@ __global__ __launch_bounds__(kBlock) void k_classify(PathState P, DScene sc) {
       uint32_t i = tile * kTileItems + j * kBlock + threadIdx.x;
       dest[j] = 0, p[j] = 0, doomed[j] = false;
       if (i < n) {
-        uint32_t e = P.q_in[i];
+        const uint32_t e = P.first ? P.slot0 + i : P.q_in[i];  // (a group's first bounce: entry i is path slot0 + i)
         p[j] = e & kQPathMask;
         dest[j] = (e & kQSssBit) ? 1u : 0xFFu;
         doomed[j] = (e & kQDoomed) != 0u;
@@ -458,12 +473,18 @@ struct PathHead {
   uint32_t flags;
 };
 __device__ __forceinline__ bool path_head(const PathState& P, const DScene& sc, uint32_t p, uint64_t rng_inc, PathHead& c, bool first) {
-  float4 h4 = P.hit[p], d4 = P.ray_d[p];
+  float4 h4 = P.hit[p];
   float4 o4 = make_float4(P.cam_org[0], P.cam_org[1], P.cam_org[2], 0.0f), t4 = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
   c.flags = first ? 0u : kFlagNotFirst;  // set by every head after the first (render.cc:43-61: depth-0 emission has weight 1)
-  if (!first) o4 = P.ray_o[p], t4 = P.thr[p];  // the camera ray's values are implied (PathState::first)
+  uint64_t rng_state;
+  if (!first) {
+    o4 = P.ray_o[p], t4 = P.thr[p];
+    c.dir = ld3(P.ray_d[p]);
+    rng_state = P.rng[p];
+  } else {
+    camera_sample(P, p - P.slot0, c.dir, rng_state);  // the camera ray's values are implied or recomputed (PathState::first)
+  }
   c.h.t = h4.x, c.h.u = h4.y, c.h.v = h4.z, c.h.slot = __float_as_uint(h4.w);
-  c.dir = ld3(d4);
   c.s = make_surface(sc, ld3(o4), c.dir, c.h);
   c.thr = ld3(t4);
   if (c.s.face == kFront && c.s.lightrec != kNone) {  // render.cc:43-62, LightManager::ImplicitAreaLight
@@ -475,7 +496,7 @@ __device__ __forceinline__ bool path_head(const PathState& P, const DScene& sc, 
     float4 L4 = P.L[p];
     P.L[p] = mk4(ld3(L4) + w * emission * c.thr, L4.w);
   }
-  c.rng.state = P.rng[p], c.rng.inc = rng_inc;
+  c.rng.state = rng_state, c.rng.inc = rng_inc;
   float rr = spectrum_norm(c.thr);  // render.cc:66-68 (Q1)
   float u = draw(c.rng);
   if (rr < u) return false;
@@ -1172,7 +1193,7 @@ __global__ __launch_bounds__(kBlock, PB_TAIL_WAVES) void k_tail(PathState P, DSc
   for (uint32_t base = wave * per_wave; base < n; base += nwaves * per_wave) {  // (wave-uniform loop)
     uint32_t state = 0u;
     if (lane < per_wave && base + lane < n) {
-      const uint32_t e = P.q_in[base + lane];
+      const uint32_t e = P.first ? P.slot0 + base + lane : P.q_in[base + lane];
       state = (e & kQPathMask) | kHave | ((e & kQSssBit) ? kMedium : 0u) | (P.first ? kFirst : 0u);  // the tail starts at the very first bounce of tiny renders
     }
     bool paired = false;
@@ -1444,10 +1465,8 @@ static inline uint32_t grid_for(uint32_t n, uint32_t cap) {
   return g < cap ? g : cap;
 }
 
-void launch_generate(hipStream_t s, const PathState& P, const Camera& cam, const uint32_t* pix_index, uint32_t npix,
-                     uint32_t npaths, uint32_t slot0, uint32_t width, uint32_t first_pass, uint64_t seed_seq) {
-  hipLaunchKernelGGL(k_generate, dim3(grid_for(npaths, 8192)), dim3(kBlock), 0, s, P, cam, pix_index, npix, npaths, slot0,
-                     width, first_pass, seed_seq);
+void launch_generate(hipStream_t s, const PathState& P, uint32_t npaths) {
+  hipLaunchKernelGGL(k_generate, dim3(grid_for(npaths, 8192)), dim3(kBlock), 0, s, P, npaths);
 }
 void launch_trace(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, bool stats) {
   // Persistent kernel: at most the resident set.  A launch with fewer rays than that would fill gets fewer waves, so that
@@ -1469,6 +1488,22 @@ void launch_trace(hipStream_t s, const PathState& P, const DScene& sc, uint32_t 
     const uint32_t k = (uint32_t)strtoul(b, &end, 10);
     const uint32_t lim = (end && *end == ',') ? (uint32_t)strtoul(end + 1, nullptr, 10) : 0u;
     if (k >= 1u && n_upper <= lim && 256u * k < cap) cap = 256u * k;
+  }
+  if (P.first) {
+    // a group's first launch: camera rays only, computed by the sink (TraceSinkT<.., FIRST>); always the phase-voting kernel
+    cap -= 256u;  // (its launch bounds: one block per CU fewer)
+    dim3 g(blocks < 1u ? 1u : (blocks < cap ? blocks : cap));
+#define PB_LAUNCH_FIRST(ST)                                                                                      \
+  do {                                                                                                           \
+    if (wide && curves) hipLaunchKernelGGL((k_trace<ST, true, true, true>), g, dim3(kBlock), 0, s, P, sc);       \
+    else if (wide) hipLaunchKernelGGL((k_trace<ST, false, true, true>), g, dim3(kBlock), 0, s, P, sc);           \
+    else if (curves) hipLaunchKernelGGL((k_trace<ST, true, false, true>), g, dim3(kBlock), 0, s, P, sc);         \
+    else hipLaunchKernelGGL((k_trace<ST, false, false, true>), g, dim3(kBlock), 0, s, P, sc);                    \
+  } while (0)
+    if (stats) PB_LAUNCH_FIRST(true);
+    else PB_LAUNCH_FIRST(false);
+#undef PB_LAUNCH_FIRST
+    return;
   }
   if (wide && !curves && use_wave_pool()) {
     const uint32_t nb = (n_upper + 4u * rays_per_wave - 1u) / (4u * rays_per_wave), capw = 256u * PB_WP_BLOCKS;

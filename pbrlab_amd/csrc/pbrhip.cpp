@@ -1165,6 +1165,8 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
         const size_t off = gr.slot0;
         gr.P.q_in += off, gr.P.q_out += off, gr.P.q_principled += off, gr.P.q_hair += off, gr.P.q_sss += off, gr.P.q_shadow += off, gr.P.q_shadow_in += off;
         for (int k = 0; k < 3; k++) gr.P.cam_org[k] = cam.org[k];
+        gr.P.cam = cam, gr.P.pix_index = s->pix_index.p, gr.P.npix = npix, gr.P.width = d->width, gr.P.first_pass = gr.first_pass;
+        gr.P.slot0 = gr.slot0, gr.P.seed_seq = d->seed_seq;
         gr.tm = Timer{s, want_timing, nullptr};
       }
       bool lane_busy[kMaxGroups] = {};
@@ -1239,7 +1241,7 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
         hc[kCntIn] = gr.n0;
         HIPCHK(hipMemcpyAsync(gr.P.counts, hc, sizeof(uint32_t) * kCntNum, hipMemcpyHostToDevice, gst));
         HIPCHK(gr.tm.begin(&S.ms_generate));
-        launch_generate(gst, gr.P, cam, s->pix_index.p, npix, gr.n0, gr.slot0, d->width, gr.first_pass, d->seed_seq);
+        launch_generate(gst, gr.P, gr.n0);
         HIPCHK(gr.tm.end());
         return enqueue(gr);
       };
