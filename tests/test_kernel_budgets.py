@@ -34,7 +34,7 @@ BUDGETS = {
     "k_shade_principled<1>": (168, 44),          # media, no texture (C3, C5): the medium's coefficients come from the material record
     "k_shade_principled<2>": (168, 128),         # textured materials: ParamToBsdf and the medium per hit
     "k_tail<0, false, false, true>": (168, 52),    # no medium, no texture (C2); 20 -> 52 B with the packed two-triangle leaf test (C2 k_tail 3.7-4.2 -> 3.5-3.8 ms)
-    "k_tail<0, false, true, true>": (168, 20),     # ... with curves (C4)
+    "k_tail<0, false, true, true>": (168, 28),     # ... with curves (C4); 20 -> 28 B with the camera sample in the shading head (round 4)
     "k_tail<1, false, false, true>": (168, 200),   # media (C3)
     "k_tail<1, false, true, true>": (168, 168),    # media + curves (C5)
     "k_tail<2, false, false, true>": (168, 216),   # textured materials
