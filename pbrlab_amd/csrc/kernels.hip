@@ -424,7 +424,7 @@ __global__ __launch_bounds__(kBlock) void k_compact(PathState P) {
   constexpr int kItemsPerThread = kCompactItems, kTileItems = kItemsPerThread * kBlock;
   __shared__ uint32_t wcount[2][kItemsPerThread][kWavesPerBlock];
   __shared__ uint32_t base[2];
-  const uint32_t n0 = P.counts[kCntPrincipled], n1 = P.counts[kCntHair], n2 = P.counts[kCntSss];
+  const uint32_t n0 = P.counts[P.first == kFirstDirect ? kCntIn : kCntPrincipled], n1 = P.counts[kCntHair], n2 = P.counts[kCntSss];
   const uint32_t n = n0 + n1 + n2;
   const uint32_t ntiles = (n + kTileItems - 1) / kTileItems;
   uint32_t* const counters[2] = {&P.counts[kCntOut], &P.counts[kCntShadow]};
@@ -774,11 +774,20 @@ __global__ __launch_bounds__(kBlock, MODE == kShadePlain ? PB_SHADE_WAVES : PB_S
       dst[i] = reinterpret_cast<const uint32_t*>(&sc.materials[i / kWords].bsdf)[i % kWords];
   }
   if (staged || lights_staged) __syncthreads();
-  const uint32_t n = P.counts[kCntPrincipled];
+  // kFirstDirect: the camera rays of a scene with one shader kind were not classified -- entry i is path slot0 + i, and the drop
+  // rule of k_classify for a first bounce (a miss, or a primitive without material that is no light) is applied here
+  const bool direct = P.first == kFirstDirect;
+  const uint32_t n = P.counts[direct ? kCntIn : kCntPrincipled];
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-    const uint32_t p = P.q_principled[i];
-    P.q_principled[i] = p | shade_principled_path<MODE>(P, sc, p, rng_inc, P.first != 0u, staged ? lds_bsdf : nullptr,
-                                                         lights_staged ? lds_lights : nullptr);
+    const uint32_t p = direct ? P.slot0 + i : P.q_principled[i];
+    uint32_t r = 0u;
+    bool go = true;
+    if (direct) {
+      const uint32_t code = __float_as_uint(P.hit[p].w);
+      go = !(code == kNone || (!(code & kHitLight) && (code & kHitNoMaterial)));
+    }
+    if (go) r = shade_principled_path<MODE>(P, sc, p, rng_inc, P.first != 0u, staged ? lds_bsdf : nullptr, lights_staged ? lds_lights : nullptr);
+    P.q_principled[i] = p | r;
   }
 }
 

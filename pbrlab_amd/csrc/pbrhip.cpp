@@ -1199,9 +1199,15 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
           gr.P.wave_log_launch = wave_log_launches++;
           launch_trace(gst, gr.P, sc, 2 * n, want_stats);  // this bounce's closest rays + last bounce's shadow rays
           HIPCHK(gr.tm.end());
-          HIPCHK(gr.tm.begin(&S.ms_surface));
-          launch_classify(gst, gr.P, sc, n);
-          HIPCHK(gr.tm.end());
+          // a first bounce in a scene whose hits all take the principled shader needs no routing: the shading kernel walks the
+          // group's paths itself (kFirstDirect)
+          const bool direct = gr.P.first && !s->has_hair && !s->has_sss && env_u32("PBRHIP_FIRST_DIRECT", 1u) != 0u;
+          if (direct) gr.P.first = kFirstDirect;
+          if (!direct) {
+            HIPCHK(gr.tm.begin(&S.ms_surface));
+            launch_classify(gst, gr.P, sc, n);
+            HIPCHK(gr.tm.end());
+          }
           HIPCHK(gr.tm.begin(&S.ms_shade_principled));
           launch_shade_principled(gst, gr.P, sc, n, rng_inc, s->has_sss, s->has_textured);
           HIPCHK(gr.tm.end());
