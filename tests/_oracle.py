@@ -13,6 +13,36 @@ ORACLE_SO = os.environ.get("PBR_ORACLE_SO") or os.path.join(ORACLE_DIR, "libpbr_
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libref_leaf.so")
 
 MATH_LIBM, MATH_F64R = 0, 1
+def host_threads():
+    """CPUs this process may really use: min(os.cpu_count(), scheduler affinity, the cgroup's CPU quota).  The GPU boxes report 256
+    hardware threads and run the job under cpu.max = 16 CPUs: 256 oracle threads then take turns on 16 cores and finish LATER than
+    32 do (scripts/cpu_scaling.py: 5.6 Msamples/s at 32 threads, 3.4 at 256)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(round(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            pe = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(round(q / pe))))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def oracle_threads():
+    """worker threads for the oracle's pool: twice the usable CPUs where a quota is in force (the pool peaks there), else all of them"""
+    n, hw = host_threads(), os.cpu_count() or 1
+    return min(hw, 2 * n) if n < hw else n
+
+
 JOBS_BLOCKS, JOBS_TILE_PASS = 0, 1  # orc_render_jobs: the worker pool's job granularity (pbr_oracle.h)
 
 

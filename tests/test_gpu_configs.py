@@ -22,7 +22,7 @@ import _oracle as O  # noqa: E402
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 REL_L2_TOL = 1e-4
-THREADS = os.cpu_count() or 8
+THREADS = O.oracle_threads()
 
 
 @pytest.fixture(scope="module")

@@ -419,7 +419,7 @@ def test_whole_frames_on_the_benchmark_scenes(pa, config, monkeypatch):
     W, H, SPP = 480, 270, 4
     a = pa.RenderLayer()
     pa.Render(sg, W, H, SPP, layer=a)
-    rgba, cnt, _ = so.render(W, H, SPP, threads=os.cpu_count() or 8, math_mode=O.MATH_F64R)
+    rgba, cnt, _ = so.render(W, H, SPP, threads=O.oracle_threads(), math_mode=O.MATH_F64R)
     assert np.array_equal(a.count, cnt)
     ndiff, rel = image_check(a.rgba, rgba)
     assert ndiff == 0 and rel == 0.0, (ndiff, rel)
