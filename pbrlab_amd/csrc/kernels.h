@@ -33,8 +33,8 @@ struct PathState {
   // so k_generate does not store ray_o / thr and the first trace and shading do not load them; the only per-path flag
   // ("not the first bounce", MIS weight of emission) is the same bit.
   float cam_org[3];
-  uint32_t first;   // 1: a group's first bounce; 3 (kFirstDirect): ... of a scene whose hits all take the principled shader -- no hair, no
-                    // medium --: k_classify is skipped, k_shade_principled walks the paths slot0 .. slot0 + n itself and drops misses
+  uint32_t first;   // 1: a group's first bounce; 3 (kFirstDirect): ... of a scene without hair -- every first hit takes the principled shader --:
+                    // k_classify is skipped, k_shade_principled walks the paths slot0 .. slot0 + n itself and drops misses
   // ... and the camera sample of path slot0 + j itself is a function of j (render.cc:160-171: pixel = pix_index[j % npix], pass =
   // first_pass + j / npix, two draws of the sample's own generator): the first k_trace and the first shading compute it
   // (kernels.hip::camera_sample) instead of reading a stored direction, generator state and queue entry (round 4: k_generate only

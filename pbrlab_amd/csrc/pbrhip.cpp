@@ -1199,9 +1199,10 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
           gr.P.wave_log_launch = wave_log_launches++;
           launch_trace(gst, gr.P, sc, 2 * n, want_stats);  // this bounce's closest rays + last bounce's shadow rays
           HIPCHK(gr.tm.end());
-          // a first bounce in a scene whose hits all take the principled shader needs no routing: the shading kernel walks the
-          // group's paths itself (kFirstDirect)
-          const bool direct = gr.P.first && !s->has_hair && !s->has_sss && env_u32("PBRHIP_FIRST_DIRECT", 1u) != 0u;
+          // a first bounce in a scene without hair needs no routing -- every hit takes the principled shader --: the shading kernel
+          // walks the group's paths itself (kFirstDirect)
+          // (media do not matter here: no path is inside one before its first shading)
+          const bool direct = gr.P.first && !s->has_hair && env_u32("PBRHIP_FIRST_DIRECT", 1u) != 0u;
           if (direct) gr.P.first = kFirstDirect;
           if (!direct) {
             HIPCHK(gr.tm.begin(&S.ms_surface));
