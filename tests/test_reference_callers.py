@@ -54,6 +54,25 @@ def test_reference_cli_sources_compile_unmodified_against_the_shim(tmp_path):
         assert not os.path.exists(os.path.join(str(tmp_path), "rgba.png"))
 
 
+def test_forwarding_headers_are_one_liners():
+    """tests/cpp/fwd: the reference's header names, each nothing but an include of this repository's shim (no reference text)"""
+    fwd = os.path.join(ROOT, "tests", "cpp", "fwd")
+    names = sorted(os.path.relpath(os.path.join(dp, f), fwd) for dp, _, fs in os.walk(fwd) for f in fs)
+    assert names == ["image-utils.h", "io/curve-mesh-io.h", "io/image-io.h", "io/triangle-mesh-io.h", "material-param.h", "render-layer.h",
+                     "render.h", "scene.h"]
+    for n in names:
+        code = [l for l in open(os.path.join(fwd, n)).read().splitlines() if l.strip() and not l.startswith("//")]
+        assert code in (['#include "pbrlab_hip.hpp"'], ['#include "pbrlab_hip_io.hpp"']), (n, code)
+
+
+def test_oracle_thread_count_follows_the_cpu_quota():
+    """the GPU boxes report 256 hardware threads and give the job 16 CPUs (cgroup cpu.max): the oracle's pool is sized from what
+    the process may use, not from os.cpu_count()"""
+    import _oracle as O
+    n, t = O.host_threads(), O.oracle_threads()
+    assert 1 <= n <= (os.cpu_count() or 1) and n <= t <= (os.cpu_count() or 1) and t <= 2 * n
+
+
 @pytest.mark.gpu
 def test_reference_main_renders_through_this_library(tmp_path):
     import pbrlab_amd as pa
