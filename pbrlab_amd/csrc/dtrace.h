@@ -128,11 +128,22 @@ __device__ __forceinline__ void tri_test_pair(const float4& w0, const float4& w1
 // distances go to the smaller canonical id".  Returns true when the ray is an any-hit ray and a triangle was accepted.
 __device__ __forceinline__ uint32_t q_gid(const DScene& sc, uint32_t code);
 template <bool ANY_CT, bool STATS>
+__device__ __forceinline__ bool tri_pair_accept_s(const DScene& sc, const float4& w0, const float4& w1, const float4& w2, const float4& w3, const float4& w4,
+                                                  float o_x, float o_y, float o_z, float d_x, float d_y, float d_z, float i_x, float i_y, float i_z,
+                                                  float tmin, bool any_rt, Hit& hit, uint32_t& ntested);
+template <bool ANY_CT, bool STATS>
 __device__ __forceinline__ bool tri_pair_accept(const DScene& sc, const float4& w0, const float4& w1, const float4& w2, const float4& w3, const float4& w4,
                                                 V3 o, V3 d, V3 inv3, float tmin, bool any_rt, Hit& hit, uint32_t& ntested) {
+  return tri_pair_accept_s<ANY_CT, STATS>(sc, w0, w1, w2, w3, w4, o.x, o.y, o.z, d.x, d.y, d.z, inv3.x, inv3.y, inv3.z, tmin, any_rt, hit, ntested);
+}
+// (scalar ray parameters: a V3 passed by value into the packed test survives as a 12-byte stack object)
+template <bool ANY_CT, bool STATS>
+__device__ __forceinline__ bool tri_pair_accept_s(const DScene& sc, const float4& w0, const float4& w1, const float4& w2, const float4& w3, const float4& w4,
+                                                  float o_x, float o_y, float o_z, float d_x, float d_y, float d_z, float i_x, float i_y, float i_z,
+                                                  float tmin, bool any_rt, Hit& hit, uint32_t& ntested) {
   bool ok_a, ok_b;
   f2 t, u, v;
-  tri_test_pair(w0, w1, w2, w3, w4, o.x, o.y, o.z, d.x, d.y, d.z, inv3.x, inv3.y, inv3.z, tmin, ok_a, ok_b, t, u, v);
+  tri_test_pair(w0, w1, w2, w3, w4, o_x, o_y, o_z, d_x, d_y, d_z, i_x, i_y, i_z, tmin, ok_a, ok_b, t, u, v);
   const uint32_t code_a = __float_as_uint(w4.z), code_b = __float_as_uint(w4.w);
   ok_b = ok_b && code_b != kNone;  // (a leaf of one triangle stores it twice: the second copy is not a candidate)
   if (STATS) ntested += code_b != kNone ? 2u : 1u;

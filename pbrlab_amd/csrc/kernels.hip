@@ -21,6 +21,7 @@
 #include "dtrace_pv.h"
 #include "dtrace_pv2.h"
 #include "dtrace_wp.h"
+#include "dtrace_quad.h"
 
 namespace pb {
 
@@ -243,6 +244,34 @@ __global__ __launch_bounds__(kBlock, trace_blocks_per_cu(CURVES, WIDE) - (FIRST 
     }
   }
   if (STATS) trace_stats_out(P, st, n_closest, n_shadow);
+}
+
+// Small launches (the late iterations of a group, every launch of a small render) on one ray per QUAD of lanes (dtrace_quad.h).
+// Rays are dealt to the quads in order (no queue: at most a few rays per quad).  Triangle-only Q trees.  Off by default
+// (PBRHIP_QUAD_RAYS = the largest launch it takes): measured equal to k_trace on the benchmark frames, profiles/README.md.
+template <bool STATS>
+__global__ __launch_bounds__(kBlock) void k_trace_quad(PathState P, DScene sc) {
+  __shared__ uint32_t stk[kSimpleLdsStack * (kBlock / 4)];
+  const uint32_t n_closest = P.counts[kCntIn], n_shadow = P.counts[kCntShadowIn];
+  const uint32_t n = n_closest + n_shadow;
+  constexpr uint32_t quads = kBlock / 4;
+  const uint32_t quad = threadIdx.x >> 2;
+  uint32_t overflow = 0u;
+  TraceSinkT<false> sink = {P, n_closest};
+  for (uint32_t i = blockIdx.x * quads + quad; i < n; i += gridDim.x * quads) {
+    uint32_t tag;
+    V3 o, d;
+    float tmin, tmax;
+    const bool any = sink.load(i, tag, o, d, tmin, tmax);
+    Hit h;
+    const bool occluded = traverse_quad<2>(sc, o, d, tmin, tmax, h, stk + quad, quads, &overflow, any, P.spill + blockIdx.x * quads + quad, gridDim.x * quads);
+    if ((threadIdx.x & 3u) == 0u) sink.done(tag, h, occluded);
+  }
+  if (overflow) P.counts[kCntOverflow] = 1u;
+  if (STATS) {
+    TravStats st = {};
+    trace_stats_out(P, st, n_closest, n_shadow);
+  }
 }
 
 // The same launch on the two-rays-per-lane traversal (dtrace_pv2.h; Q tree only): fewer waves per SIMD, each carrying 128 rays.
@@ -1179,6 +1208,9 @@ __global__ __launch_bounds__(kBlock, PB_WALK_WAVES) void k_sss_walk(PathState P,
 // lanes and every odd lane becomes its neighbour's helper: it traverses the path's shadow ray while the even lane
 // traverses the continuation ray -- the two dependent-load chains of a bounce run side by side instead of one after the
 // other (what bounds k_tail is the chain of the longest path, not throughput).
+#ifndef PB_TAIL_OCTETS
+#define PB_TAIL_OCTETS 1  // triangle-only Q trees: eight lanes per path once at most eight paths of a wave are alive (below)
+#endif
 #ifndef PB_TAIL_WAVES
 #define PB_TAIL_WAVES 3  // min waves per SIMD of k_tail (<= 168 VGPRs: three blocks per CU hold 196 k lanes, so every path of a 256 Ki tail starts at once;
                          // A/B on C2: 2 -> 59.1 ms per frame / 12.1 ms for an eighth, 3 -> 58.6 / 11.8)
@@ -1199,27 +1231,31 @@ __global__ __launch_bounds__(kBlock, PB_TAIL_WAVES) void k_tail(PathState P, DSc
   const TraceSink sink = {P, 0u};
   uint32_t* const stack = stk + threadIdx.x;
   constexpr uint32_t kHave = 0x80000000u, kMedium = 0x40000000u, kFirst = 0x20000000u;  // lane state = path slot | flags
+  constexpr bool kOctets = PB_TAIL_OCTETS != 0 && WIDE && !CURVES;
   for (uint32_t base = wave * per_wave; base < n; base += nwaves * per_wave) {  // (wave-uniform loop)
     uint32_t state = 0u;
     if (lane < per_wave && base + lane < n) {
       const uint32_t e = P.first ? P.slot0 + base + lane : P.q_in[base + lane];
       state = (e & kQPathMask) | kHave | ((e & kQSssBit) ? kMedium : 0u) | (P.first ? kFirst : 0u);  // the tail starts at the very first bounce of tiny renders
     }
-    bool paired = false;
+    uint32_t team = 1u;  // lanes per path: 1, 2 (pairs) or 8 (octets)
     for (;;) {
       const unsigned long long act = __ballot((state & kHave) != 0u);
       if (act == 0ull) break;
-      if (!paired && __popcll(act) <= 32) {
-        // move the k-th live path to lane 2k (its state is this one word; everything else lives in the path's slot)
+      const uint32_t alive = (uint32_t)__popcll(act);
+      const uint32_t want_team = (kOctets && alive <= 8u) ? 8u : (alive <= 32u ? 2u : 1u);
+      if (want_team > team) {
+        // move the k-th live path to lane team * k (its state is this one word; everything else lives in the path's slot)
         uint32_t src = lane;
         bool mine = false;
         uint32_t k = 0;
         for (unsigned long long m = act; m; m &= m - 1ull, k++)
-          if (lane == 2u * k) src = (uint32_t)__builtin_ctzll(m), mine = true;
+          if (lane == want_team * k) src = (uint32_t)__builtin_ctzll(m), mine = true;
         const uint32_t moved = (uint32_t)__shfl((int)state, (int)src);
         state = mine ? moved : 0u;
-        paired = true;
+        team = want_team;
       }
+      const bool paired = team == 2u;
       const uint32_t p = state & kQPathMask;
       uint32_t r = 0u;
       if (state & kHave) {
@@ -1234,7 +1270,36 @@ __global__ __launch_bounds__(kBlock, PB_TAIL_WAVES) void k_tail(PathState P, DSc
         state &= ~kFirst;
       }
       const bool want_shadow = (r & kRShadow) != 0u, want_closest = (r & kRAlive) != 0u;
-      if (!paired) {
+      if (kOctets && team == 8u) {
+        // lanes 0-3 of the octet: the path's continuation ray; lanes 4-7: its shadow ray -- one ray per quad (dtrace_quad.h)
+        const bool upper = (lane & 4u) != 0u;
+        float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f), d4 = o4, s4 = o4;
+        if (want_shadow || want_closest) o4 = P.ray_o[p];
+        if (want_closest) d4 = P.ray_d[p];
+        if (want_shadow) s4 = P.sh_d[p];
+        const int lead = (int)(lane & ~7u);
+        const float ox = __shfl(o4.x, lead), oy = __shfl(o4.y, lead), oz = __shfl(o4.z, lead), ow = __shfl(o4.w, lead);
+        const float cx = __shfl(d4.x, lead), cy = __shfl(d4.y, lead), cz = __shfl(d4.z, lead), cw = __shfl(d4.w, lead);
+        const float sx = __shfl(s4.x, lead), sy = __shfl(s4.y, lead), sz = __shfl(s4.z, lead), sw = __shfl(s4.w, lead);
+        const float dx = upper ? sx : cx, dy = upper ? sy : cy, dz = upper ? sz : cz, dw = upper ? sw : cw;
+        const uint32_t wants = (uint32_t)__shfl((int)((want_closest ? 1u : 0u) | (want_shadow ? 2u : 0u)), lead);
+        const bool go = (wants & (upper ? 2u : 1u)) != 0u;
+        Hit h = {0.f, 0.f, 0.f, kNone};
+        bool occluded = false;
+        const uint32_t col = threadIdx.x & ~3u;
+        if (go) occluded = traverse_quad<2>(sc, V3(ox, oy, oz), V3(dx, dy, dz), ow, dw, h, stk + col, kBlock, &overflow, upper,
+                                            P.spill + blockIdx.x * kBlock + col, spill_stride);
+        const bool occ_up = __shfl((int)occluded, lead + 4) != 0;
+        if (want_shadow) {
+          Hit none = {0.f, 0.f, 0.f, kNone};
+          sink.done(p | 0x80000000u, none, occ_up);
+          n_shadow++;
+        }
+        if (want_closest) {
+          P.hit[p] = make_float4(h.t, h.u, h.v, __uint_as_float(h.slot));
+          n_closest++;
+        }
+      } else if (!paired) {
         if (want_shadow) {
           const float4 o4 = P.ray_o[p], d4 = P.sh_d[p];
           Hit h;
@@ -1424,6 +1489,26 @@ __global__ __launch_bounds__(kBlock) void k_hook_any(DScene sc, const float4* __
   if (overflow) *overflow_flag = 1u;
 }
 
+// One ray per QUAD of lanes (dtrace_quad.h), selected with PBRHIP_QUAD=1 for triangle-only Q trees: must agree bit for bit.
+template <bool ANY>
+__global__ __launch_bounds__(kBlock) void k_hook_quad(DScene sc, const float4* __restrict__ rays, uint32_t n, HookHit* __restrict__ hits,
+                                                      uint8_t* __restrict__ occ, uint32_t* overflow_flag, uint32_t* spill) {
+  __shared__ uint32_t stk[kSimpleLdsStack * (kBlock / 4)];
+  uint32_t overflow = 0u;
+  const uint32_t quad = threadIdx.x >> 2, quads = kBlock / 4;
+  for (uint32_t i = blockIdx.x * quads + quad; i < n; i += gridDim.x * quads) {
+    float4 o4 = rays[2 * i], d4 = rays[2 * i + 1];
+    Hit h;
+    const bool o = traverse_quad<ANY ? 1 : 0>(sc, ld3(o4), ld3(d4), o4.w, fminf(d4.w, INFINITY), h, stk + quad, quads, &overflow, ANY,
+                                             spill + blockIdx.x * quads + quad, gridDim.x * quads);
+    if ((threadIdx.x & 3u) == 0u) {
+      if (ANY) occ[i] = o ? 1 : 0;
+      else hits[i] = hook_result(sc, ld3(o4), ld3(d4), h);
+    }
+  }
+  if (overflow) *overflow_flag = 1u;
+}
+
 // queue flip between iterations: counts[In] = counts[Out]; the per-iteration counters restart at 0
 __global__ void k_advance(uint32_t* counts) {
   if (threadIdx.x == 0) {
@@ -1460,6 +1545,17 @@ bool trace_uses_wide(const DScene& sc) { return use_wide(sc); }
 #ifndef PB_TRACEWP_DEFAULT
 #define PB_TRACEWP_DEFAULT 0
 #endif
+#ifndef PB_QUAD_RAYS
+#define PB_QUAD_RAYS 0u  // k_trace launches of at most this many rays run on k_trace_quad (PBRHIP_QUAD_RAYS overrides)
+#endif
+static inline uint32_t quad_rays() {
+  const char* e = getenv("PBRHIP_QUAD_RAYS");
+  return e ? (uint32_t)strtoul(e, nullptr, 10) : PB_QUAD_RAYS;
+}
+static inline bool use_quad() {
+  const char* e = getenv("PBRHIP_QUAD");
+  return e && e[0] == '1';
+}
 static inline bool use_wave_pool() {
   const char* e = getenv("PBRHIP_TRACEWP");
   return e ? atoi(e) != 0 : PB_TRACEWP_DEFAULT != 0;
@@ -1472,6 +1568,10 @@ static inline uint32_t grid_for(uint32_t n, uint32_t cap) {
   uint32_t g = (n + kBlock - 1) / kBlock;
   if (g < 1) g = 1;
   return g < cap ? g : cap;
+}
+static inline uint32_t quad_grid(uint32_t n) {  // one ray per quad of lanes: 64 rays per block
+  const uint32_t g = (n + 63u) / 64u;
+  return g < 1u ? 1u : (g < 2048u ? g : 2048u);
 }
 
 void launch_generate(hipStream_t s, const PathState& P, uint32_t npaths) {
@@ -1512,6 +1612,13 @@ void launch_trace(hipStream_t s, const PathState& P, const DScene& sc, uint32_t 
     if (stats) PB_LAUNCH_FIRST(true);
     else PB_LAUNCH_FIRST(false);
 #undef PB_LAUNCH_FIRST
+    return;
+  }
+  if (wide && !curves && n_upper <= quad_rays()) {
+    // a small launch: one ray per quad of lanes
+    const dim3 gq(quad_grid(n_upper));
+    if (stats) hipLaunchKernelGGL((k_trace_quad<true>), gq, dim3(kBlock), 0, s, P, sc);
+    else hipLaunchKernelGGL((k_trace_quad<false>), gq, dim3(kBlock), 0, s, P, sc);
     return;
   }
   if (wide && !curves && use_wave_pool()) {
@@ -1615,6 +1722,10 @@ void launch_hook_closest(hipStream_t s, const DScene& sc, const float4* rays, ui
     else hipLaunchKernelGGL((k_hook_closest<true, false>), dim3(grid_for(n, 4096)), dim3(kBlock), 0, s, sc, rays, n, out, counts + kCntOverflow, spill);
     return;
   }
+  if (wide && !curves && use_quad()) {
+    hipLaunchKernelGGL((k_hook_quad<false>), dim3(quad_grid(n)), dim3(kBlock), 0, s, sc, rays, n, out, (uint8_t*)nullptr, counts + kCntOverflow, spill);
+    return;
+  }
   if (wide && !curves && use_wave_pool()) {
     const uint32_t nb = (n + 255u) / 256u;
     hipLaunchKernelGGL((k_hook_wp<false>), dim3(nb < 1u ? 1u : (nb < 512u ? nb : 512u)), dim3(kBlock), 0, s, sc, rays, n, out, (uint8_t*)nullptr, counts, spill);
@@ -1632,6 +1743,10 @@ void launch_hook_any(hipStream_t s, const DScene& sc, const float4* rays, uint32
     if (wide && curves) hipLaunchKernelGGL((k_hook_any<true, true>), dim3(grid_for(n, 4096)), dim3(kBlock), 0, s, sc, rays, n, out, counts + kCntOverflow, spill);
     else if (wide) hipLaunchKernelGGL((k_hook_any<false, true>), dim3(grid_for(n, 4096)), dim3(kBlock), 0, s, sc, rays, n, out, counts + kCntOverflow, spill);
     else hipLaunchKernelGGL((k_hook_any<true, false>), dim3(grid_for(n, 4096)), dim3(kBlock), 0, s, sc, rays, n, out, counts + kCntOverflow, spill);
+    return;
+  }
+  if (wide && !curves && use_quad()) {
+    hipLaunchKernelGGL((k_hook_quad<true>), dim3(quad_grid(n)), dim3(kBlock), 0, s, sc, rays, n, (HookHit*)nullptr, out, counts + kCntOverflow, spill);
     return;
   }
   if (wide && !curves && use_wave_pool()) {

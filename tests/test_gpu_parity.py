@@ -615,11 +615,14 @@ def test_triangle_soup_and_ties(pa, seed, extra_slivers):
                 os.environ.pop("PBRHIP_SIMPLE_TRAVERSAL", None)
 
 
-@pytest.mark.parametrize("which", ["PBRHIP_TRACE2", "PBRHIP_TRACEWP"])
+@pytest.mark.parametrize("which", ["PBRHIP_TRACE2", "PBRHIP_TRACEWP", "PBRHIP_QUAD"])
 def test_alternative_traversals_bit_exact(pa, pairs, which):
     """The two traversal kernels of round 4 that were measured and not selected -- two rays per lane (dtrace_pv2.h) and the
     wave-pooled traversal (dtrace_wp.h) -- stay in the library behind PBRHIP_TRACE2 / PBRHIP_TRACEWP (read per launch): hits
-    do not depend on the visiting order, so soups (ties, slivers, tmax == hit distance) and whole renders are bit-identical."""
+    do not depend on the visiting order, so soups (ties, slivers, tmax == hit distance) and whole renders are bit-identical.
+    PBRHIP_QUAD: one ray per quad of lanes (dtrace_quad.h) -- k_tail runs it by default once a wave has at most eight paths
+    left (the tail_paths=3000 renders below and every small render of this suite); here the hooks and every k_trace launch
+    (PBRHIP_QUAD_RAYS) run it as well."""
     import _soups
     desc, so, rays = _soups.triangle_soup(2, 30)
     hb = so.trace_closest(rays, brute_force=True)
@@ -628,6 +631,8 @@ def test_alternative_traversals_bit_exact(pa, pairs, which):
     ob = so.trace_any(short, brute_force=True)
     sg = pa.scene_from_desc(desc)
     os.environ[which] = "1"
+    if which == "PBRHIP_QUAD":
+        os.environ["PBRHIP_QUAD_RAYS"] = str(1 << 30)
     try:
         assert_hits_equal(sg.trace_closest(rays), hb)
         assert np.array_equal(sg.trace_any(short), ob)
@@ -640,6 +645,7 @@ def test_alternative_traversals_bit_exact(pa, pairs, which):
                 assert np.array_equal(layer.count, cnt) and layer.rgba.tobytes() == rgba.tobytes(), (which, name, tail)
     finally:
         os.environ.pop(which, None)
+        os.environ.pop("PBRHIP_QUAD_RAYS", None)
 
 
 @pytest.mark.parametrize("seed", range(4))
