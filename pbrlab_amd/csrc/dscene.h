@@ -102,20 +102,31 @@ constexpr uint32_t kSlotMatHair = 4u;   // material kind, denormalised here so a
 constexpr uint32_t kSlotMatNone = 8u;   // touching the material table (shader.cc:11-17 for "none")
 constexpr uint32_t kSlotHasUV = 16u;
 
+// What shading needs of a primitive, 128 bytes, laid out by how often a hit needs it: the first 32 bytes serve every hit on a
+// flat triangle (2 lane requests of 16 B -- the shading kernels are bound by the vector memory path's request rate, TD_TD_BUSY
+// 0.90: profiles/README.md); corner normals / control points / texcoords only for the hits whose code says so (kHitMore).
+// ng, ns_flat: the geometric normal normalize_raw(cross(v1 - v0, v2 - v0)) and the shading normal of a triangle without corner
+// normals, vnormalize(cross(v1 - v0, v2 - v1)) (CalcGeometryNormal, triangle-mesh.cc:181-184), of the mesh's own (local) corners:
+// evaluated at commit by the very functions the kernels used to call per hit (dmath.h, host and device: IEEE single precision,
+// no contraction) -- 6 words instead of 9, and no cross product, square root and division per hit.
 struct alignas(128) ShadeRec {
-  float v[9];   // triangle corners xyz (the mesh's own, local space: only the geometric normal is taken from them).  Curve piece: words 0..15 of the record (v[0..8], n[0..6]) hold the cubic's
-  float n[9];   // four control points xyzr instead.  Triangle: corner shading normals xyz (kSlotHasNormals)
-  uint32_t gid, material, lightrec, flags;
-  uint32_t instance_id, geom_id, prim_id;
-  float uv[6];  // corner texcoords (kSlotHasUV), mesh/triangle-mesh.cc:126-156
-  uint32_t pad[1];
+  float ng[3];
+  uint32_t matflags;  // material (24 bits; 0xFFFFFF = none) | kSlot* flags << 24
+  float ns_flat[3];
+  uint32_t lightrec;
+  float n[9];         // words 8..16: corner shading normals xyz (kSlotHasNormals).  Curve piece: words 8..23 hold the cubic's four control points xyzr
+  uint32_t pad0;
+  float uv[6];        // words 18..23: corner texcoords (kSlotHasUV), mesh/triangle-mesh.cc:126-156
+  uint32_t gid, instance_id, geom_id, prim_id;  // words 24..27
+  uint32_t pad[4];
 };
 static_assert(sizeof(ShadeRec) == 128, "one cache line per primitive");
 
 // hit record code (Hit::slot, P.hit[].w): slot | routing bits; kNone = miss.  The routing bits are stored with the
 // primitive's traversal data (.w of the third 16-byte word of its slot), so a hit can be routed (k_classify) without
 // touching the primitive's ShadeRec line.
-constexpr uint32_t kHitSlotMask = 0x0FFFFFFFu;
+constexpr uint32_t kHitSlotMask = 0x07FFFFFFu;
+constexpr uint32_t kHitMore = 1u << 27;        // shading needs words 8..23 of the ShadeRec (corner normals, texcoords, a curve's control points)
 constexpr uint32_t kHitHair = 1u << 28;        // hair material (== kSlotMatHair)
 constexpr uint32_t kHitLight = 1u << 29;       // the primitive is an area-light primitive (lightrec != kNone)
 constexpr uint32_t kHitNoMaterial = 1u << 30;  // == kSlotMatNone

@@ -22,29 +22,30 @@ struct Surface {
 __device__ __forceinline__ Surface make_surface(const DScene& sc, V3 org, V3 dir, const Hit& h, uint32_t* instance_id = nullptr) {
   Surface s;
   const float4* r = reinterpret_cast<const float4*>(sc.shade + (h.slot & kHitSlotMask));
-  float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5];
-  // words: v[0..8] n[9..17] gid(18) material(19) lightrec(20) flags(21) instance(22) geom(23) prim(24)
-  s.material = __float_as_uint(r4.w), s.lightrec = __float_as_uint(r5.x), s.flags = __float_as_uint(r5.y);
-  if (instance_id) *instance_id = __float_as_uint(r5.z);
+  // words: ng[0..2] matflags(3) ns_flat[4..6] lightrec(7) | n[8..16] (17) uv[18..23] | gid(24) instance(25) geom(26) prim(27)  (dscene.h)
+  const float4 r0 = r[0], r1 = r[1];
+  float4 r2 = make_float4(0.f, 0.f, 0.f, 0.f), r3 = r2, r4 = r2, r5 = r2;
+  if (h.slot & kHitMore) r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5];  // (the hit code says so: the four loads leave with the first two)
+  const uint32_t mf = __float_as_uint(r0.w);
+  s.material = (mf & 0x00FFFFFFu) == 0x00FFFFFFu ? kNone : (mf & 0x00FFFFFFu), s.flags = mf >> 24, s.lightrec = __float_as_uint(r1.w);
+  if (instance_id) *instance_id = sc.shade[h.slot & kHitSlotMask].instance_id;
   s.tu = 0.f, s.tv = 0.f;  // curves: (0,0) (scene.cc:243-245)
   if (s.flags & kSlotIsCurve) {
-    float4 cp[4] = {r0, r1, r2, r3};  // the cubic's control points (xyzr) live in words 0..15 of a curve piece's record
+    float4 cp[4] = {r2, r3, r4, r5};  // the cubic's control points (xyzr)
     s.n_g = normalize_raw(bezier_tangent(cp, h.u));
     s.n_s = s.n_g;  // scene.cc:222-223
   } else {
-    V3 v0(r0.x, r0.y, r0.z), v1(r0.w, r1.x, r1.y), v2(r1.z, r1.w, r2.x);
-    s.n_g = normalize_raw(cross(v1 - v0, v2 - v0));
+    s.n_g = V3(r0.x, r0.y, r0.z);
     if (s.flags & kSlotHasNormals) {
-      V3 n0(r2.y, r2.z, r2.w), n1(r3.x, r3.y, r3.z), n2(r3.w, r4.x, r4.y);
+      V3 n0(r2.x, r2.y, r2.z), n1(r2.w, r3.x, r3.y), n2(r3.z, r3.w, r4.x);
       s.n_s = vnormalize(lerp3(n0, n1, n2, h.u, h.v));
     } else {
-      s.n_s = vnormalize(cross(v1 - v0, v2 - v1));  // CalcGeometryNormal, triangle-mesh.cc:181-184
+      s.n_s = V3(r1.x, r1.y, r1.z);
     }
     if (s.flags & kSlotHasUV) {  // TriangleMesh::FetchTexcoord, triangle-mesh.cc:126-156 (only textured scenes pay)
-      float4 r6 = r[6], r7 = r[7];  // words 24..31: prim, uv[0..5], pad
       float w0 = 1.0f - h.u - h.v;
-      s.tu = w0 * r6.y + h.u * r6.w + h.v * r7.y;
-      s.tv = w0 * r6.z + h.u * r7.x + h.v * r7.z;
+      s.tu = w0 * r4.z + h.u * r5.x + h.v * r5.z;
+      s.tv = w0 * r4.w + h.u * r5.y + h.v * r5.w;
     } else {
       s.tu = h.u, s.tv = h.v;
     }

@@ -18,12 +18,27 @@ namespace pb {
 //   queues (u32 path slots): q_in/q_out (ping-pong), q_principled, q_hair, q_sss, q_shadow; the shadow-ray payload
 //     sits at the path's own slot: sh_d (dir, tmax) | sh_c (contribution if visible, mode) | sh_e (contribution if occluded:
 //     medium exits only); origin and tmin are ray_o's (the shadow ray starts where the continuation ray starts)
+// Path state in HBM.  After the first bounce the live paths are sparse in slot space (132.7 M camera paths of a C2 frame, 104 M
+// later bounces in all): what a path-sized access costs then is the number of LINES it touches, not its bytes.  The words a kernel
+// reads and writes together therefore share a record: rec (64 B per path) = ray origin + tmin | direction + tmax | throughput + pdf |
+// generator state -- one line for the shading kernels' five loads and four stores, one for k_trace's ray; srec (32 B) = a shadow
+// ray's direction + tmax | its pending contribution; ssrec (64 B) = what a random walk carries (sigma_t, sigma_s + entry instance,
+// throughput + step index, entry frame).  hit and L stay arrays of their own: k_trace writes / k_accumulate reads
+// them densely.  The members keep their names: PathView<T, STRIDE>::operator[] is the indexing every kernel already does.
+template <typename T, int STRIDE>
+struct PathView {
+  T* base;
+  __host__ __device__ __forceinline__ T& operator[](size_t i) const { return base[i * STRIDE]; }
+};
 struct PathState {
-  float4 *ray_o, *ray_d, *thr, *L, *hit;
-  uint64_t* rng;
-  float4 *sss_sigt, *sss_sigs, *sss_thr, *sss_ez, *sss_A;
+  PathView<float4, 4> ray_o, ray_d, thr;  // rec + 0 / 1 / 2
+  PathView<uint64_t, 8> rng;              // rec + 3 (8 of its 16 bytes)
+  float4 *L, *hit;
+  PathView<float4, 4> sss_sigt, sss_sigs, sss_thr, sss_ez;  // the random walk's record (64 B per path): one line per walk start / step
+  float4* sss_A;
   uint32_t *q_in, *q_out, *q_principled, *q_hair, *q_sss, *q_shadow, *q_shadow_in;
-  float4 *sh_d, *sh_c, *sh_e;
+  PathView<float4, 2> sh_d, sh_c;         // srec + 0 / 1
+  float4* sh_e;
   uint32_t* spill;               // traversal-stack spill area: (kStackDepth - LDS part) x resident threads
   uint32_t* counts;              // kCnt*
   unsigned long long* stats;     // kStat*; null unless the render collects statistics

@@ -563,7 +563,7 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
     const HostInstance& in = s->instances[pr.instance_id];
     const HostMesh& m = *inst_mesh(s, pr.instance_id, pr.geom_id);
     uint32_t mat = in.material_ids[pr.geom_id][pr.prim_id];
-    if (mat != kNone && mat >= s->materials.size()) return fail(PBRHIP_EINVAL, "material id %u out of range", mat);
+    if (mat != kNone && (mat >= s->materials.size() || mat >= 0x00FFFFFFu)) return fail(PBRHIP_EINVAL, "material id %u out of range", mat);
     ShadeRec& sr = shade[k];
     memset(&sr, 0, sizeof(sr));
     uint32_t flags = 0, lightrec = kNone;
@@ -575,9 +575,17 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
       for (int c = 0; c < 3; c++) {
         // traversal: what Embree sees (the transformed triangle); shading: the mesh's own corners -- the geometric normal
         // Embree reports for an instance is in the instance's local space and pbrlab uses it as it is
-        const V3 w = world_vertex(in, m, pr.prim_id, c), v = mesh_vertex(m, pr.prim_id, c);
+        const V3 w = world_vertex(in, m, pr.prim_id, c);
         sl[c] = make_float4(w.x, w.y, w.z, 0.f);
-        sr.v[3 * c + 0] = v.x, sr.v[3 * c + 1] = v.y, sr.v[3 * c + 2] = v.z;
+      }
+      {
+        // the two normals every hit on this triangle would otherwise compute from its corners (ShadeRec, dscene.h): the kernels'
+        // own functions, evaluated here
+        const V3 v0 = mesh_vertex(m, pr.prim_id, 0), v1 = mesh_vertex(m, pr.prim_id, 1), v2 = mesh_vertex(m, pr.prim_id, 2);
+        const V3 ng = normalize_raw(cross(v1 - v0, v2 - v0));
+        const V3 nf = vnormalize(cross(v1 - v0, v2 - v1));  // CalcGeometryNormal, triangle-mesh.cc:181-184
+        sr.ng[0] = ng.x, sr.ng[1] = ng.y, sr.ng[2] = ng.z;
+        sr.ns_flat[0] = nf.x, sr.ns_flat[1] = nf.y, sr.ns_flat[2] = nf.z;
       }
       uint32_t a = m.nid[pr.prim_id * 3 + 0], b = m.nid[pr.prim_id * 3 + 1], c = m.nid[pr.prim_id * 3 + 2];
       if (a != kNone && b != kNone && c != kNone) {  // triangle-mesh.cc:81-84
@@ -611,13 +619,15 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
       sl[0] = make_float4(a[0], a[1], a[2], a[3]);
       sl[1] = make_float4(b[0], b[1], b[2], b[3]);
       sl[2] = make_float4(__builtin_bit_cast(float, pr.sub), 0.f, 0.f, 0.f);
-      // shading needs the cubic itself (tangent = dP/du at the hit): control points xyzr in words 0..15 of the record
+      // shading needs the cubic itself (tangent = dP/du at the hit): control points xyzr in words 8..23 of the record
       float* w = reinterpret_cast<float*>(&sr);
-      for (int c = 0; c < 16; c++) w[c] = cps[c];
+      for (int c = 0; c < 16; c++) w[8 + c] = cps[c];
     }
-    sr.gid = g, sr.material = mat, sr.lightrec = lightrec, sr.flags = flags;
+    sr.gid = g, sr.lightrec = lightrec;
+    sr.matflags = (mat == kNone ? 0x00FFFFFFu : mat) | (flags << 24);
     const uint32_t route = ((flags & kSlotMatHair) ? kHitHair : 0u) | ((flags & kSlotMatNone) ? kHitNoMaterial : 0u) |
-                           (lightrec != kNone ? kHitLight : 0u);
+                           (lightrec != kNone ? kHitLight : 0u) |
+                           ((flags & (kSlotHasNormals | kSlotHasUV | kSlotIsCurve)) ? kHitMore : 0u);
     sl[2].w = __builtin_bit_cast(float, route);  // travels with the hit record (Hit::slot)
     sr.instance_id = pr.instance_id, sr.geom_id = pr.geom_id, sr.prim_id = pr.prim_id;
   }
@@ -901,7 +911,7 @@ static Camera make_camera(const pbrhip_scene* s, uint32_t width, uint32_t height
 }
 
 // ------------------------------------------------------------------ render
-static constexpr uint64_t kBytesPerPath = 5 * 16 + 8 + 5 * 16 + 7 * 4 + 3 * 16;  // ensure_paths()
+static constexpr uint64_t kBytesPerPath = 64 + 32 + 2 * 16 + 5 * 16 + 16 + 7 * 4;  // ensure_paths(): rec, srec, L + hit, sss, sh_e, queues
 namespace {
 struct Timer {
   pbrhip_scene* s;
@@ -989,14 +999,13 @@ static int ensure_groups(pbrhip_scene* s, uint32_t groups) {
 }
 
 static int ensure_paths(pbrhip_scene* s, size_t n) {
-  HIPCHK(s->ray_o.reserve(n));
-  HIPCHK(s->ray_d.reserve(n));
-  HIPCHK(s->thr.reserve(n));
+  HIPCHK(s->rec.reserve(4 * n));   // ray_o | ray_d | thr | rng (kernels.h::PathState)
+  HIPCHK(s->srec.reserve(2 * n));  // sh_d | sh_c
   HIPCHK(s->L.reserve(n));
   HIPCHK(s->hit.reserve(n));
-  for (auto& b : s->sss) HIPCHK(b.reserve(n));
-  for (auto& b : s->sh) HIPCHK(b.reserve(n));
-  HIPCHK(s->rng.reserve(n));
+  HIPCHK(s->ssrec.reserve(4 * n));  // sss_sigt | sss_sigs | sss_thr | sss_ez
+  HIPCHK(s->sss_A.reserve(n));
+  HIPCHK(s->sh_e.reserve(n));
   for (auto& b : s->q) HIPCHK(b.reserve(n));
   HIPCHK(s->counts.reserve(kCntNum * kMaxGroups));
   HIPCHK(s->stats.reserve(kStatNum));
@@ -1080,9 +1089,7 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
       size_t free_b = 0, total_b = 0;
       HIPCHK(hipMemGetInfo(&free_b, &total_b));
       // what this scene already holds for path state counts as available
-      size_t have = (s->ray_o.n + s->ray_d.n + s->thr.n + s->L.n + s->hit.n) * 16 + s->rng.n * 8;
-      for (auto& b : s->sss) have += b.n * 16;
-      for (auto& b : s->sh) have += b.n * 16;
+      size_t have = (s->rec.n + s->srec.n + s->ssrec.n + s->L.n + s->hit.n + s->sh_e.n + s->sss_A.n) * 16;
       for (auto& b : s->q) have += b.n * 4;
       max_paths = std::min<uint64_t>(kMaxPathsInFlight,
                                      std::max<uint64_t>(1ull << 20, (uint64_t)((free_b + have) * 0.6) / kBytesPerPath));
@@ -1099,16 +1106,16 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
     // A working set that is nearly large enough is used as it is: growing it means freeing and re-allocating every path-state
     // array (65 GB at the largest chunk: 1.3 s), and the chunk size does not change the image.  (An eighth of the C5 frame asks
     // for 258 passes = 267.5 M paths where the whole frame had allocated 265.4 M.)
-    if (s->ray_o.n < (size_t)chunk_passes * npix && s->ray_o.n / npix >= 1 && (double)(s->ray_o.n / npix) >= 0.75 * chunk_passes)
-      chunk_passes = (uint32_t)(s->ray_o.n / npix);
+    if (s->hit.n < (size_t)chunk_passes * npix && s->hit.n / npix >= 1 && (double)(s->hit.n / npix) >= 0.75 * chunk_passes)
+      chunk_passes = (uint32_t)(s->hit.n / npix);
     if (int rc = ensure_paths(s, (size_t)chunk_passes * npix)) return rc;
     PathState P;
-    P.ray_o = s->ray_o.p, P.ray_d = s->ray_d.p, P.thr = s->thr.p, P.L = s->L.p, P.hit = s->hit.p;
-    P.rng = s->rng.p;
-    P.sss_sigt = s->sss[0].p, P.sss_sigs = s->sss[1].p, P.sss_thr = s->sss[2].p;
-    P.sss_ez = s->sss[3].p, P.sss_A = s->sss[4].p;
+    P.ray_o.base = s->rec.p, P.ray_d.base = s->rec.p + 1, P.thr.base = s->rec.p + 2, P.L = s->L.p, P.hit = s->hit.p;
+    P.rng.base = reinterpret_cast<uint64_t*>(s->rec.p + 3);
+    P.sss_sigt.base = s->ssrec.p, P.sss_sigs.base = s->ssrec.p + 1, P.sss_thr.base = s->ssrec.p + 2;
+    P.sss_ez.base = s->ssrec.p + 3, P.sss_A = s->sss_A.p;
     P.q_in = s->q[0].p, P.q_out = s->q[1].p, P.q_principled = s->q[2].p, P.q_hair = s->q[3].p, P.q_sss = s->q[4].p, P.q_shadow = s->q[5].p, P.q_shadow_in = s->q[6].p;
-    P.sh_d = s->sh[0].p, P.sh_c = s->sh[1].p, P.sh_e = s->sh[2].p;
+    P.sh_d.base = s->srec.p, P.sh_c.base = s->srec.p + 1, P.sh_e = s->sh_e.p;
     P.counts = s->counts.p, P.stats = want_stats ? s->stats.p : nullptr, P.spill = s->spill.p;
     P.first = 0u, P.cam_org[0] = P.cam_org[1] = P.cam_org[2] = 0.f;
     P.no_medium = s->has_sss ? 0u : 1u;

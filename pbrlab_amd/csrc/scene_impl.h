@@ -104,8 +104,7 @@ struct pbrhip_scene {
   pb::DevBuf<pb::BvhNode> d_light_boxes;
   pb::DScene dscene;
   // render working set (grown on demand, reused across calls)
-  pb::DevBuf<float4> ray_o, ray_d, thr, L, hit, sss[5], sh[3];
-  pb::DevBuf<uint64_t> rng;
+  pb::DevBuf<float4> rec, srec, ssrec, L, hit, sss_A, sh_e;  // path state (kernels.h::PathState): rec = 4 words of 16 B per path, srec = 2
   pb::DevBuf<uint32_t> q[7], counts, pix_index, spill;
   pb::DevBuf<unsigned long long> stats;
   pb::DevBuf<float> own_rgba;

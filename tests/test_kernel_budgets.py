@@ -31,15 +31,15 @@ BUDGETS = {
     "k_shade_principled<0>": (168, 0),           # no medium, no texture (C2, C4)
     # the kernels below keep scratch at three waves per SIMD, measured against two waves without it (profiles/README.md: the
     # general shading kernel alone is 9 % faster at two, the C3 frame 2 % slower; k_tail likewise in round 2): pinned as they are
-    "k_shade_principled<1>": (168, 44),          # media, no texture (C3, C5): the medium's coefficients come from the material record
-    "k_shade_principled<2>": (168, 128),         # textured materials: ParamToBsdf and the medium per hit
+    "k_shade_principled<1>": (168, 28),          # media, no texture (C3, C5): the medium's coefficients come from the material record
+    "k_shade_principled<2>": (168, 108),         # textured materials: ParamToBsdf and the medium per hit
     # (triangle-only scenes: + 16-32 B with the octets of round 4 -- eight lanes per path once a wave has at most eight left,
     # dtrace_quad.h; measured WITH them: k_tail of an eighth of C2 1.59 -> 1.30 ms, the frame 51.0 -> 50.5 ms on the same box)
     "k_tail<0, false, false, true>": (168, 84),    # no medium, no texture (C2); 20 -> 52 B with the packed two-triangle leaf test (C2 k_tail 3.7-4.2 -> 3.5-3.8 ms)
     "k_tail<0, false, true, true>": (168, 28),     # ... with curves (C4); 20 -> 28 B with the camera sample in the shading head (round 4)
     "k_tail<1, false, false, true>": (168, 216),   # media (C3)
-    "k_tail<1, false, true, true>": (168, 168),    # media + curves (C5)
-    "k_tail<2, false, false, true>": (168, 240),   # textured materials
+    "k_tail<1, false, true, true>": (168, 184),    # media + curves (C5); 168 -> 184 B with the interleaved path-state records (round 4: C3 frame 327 -> 311 ms with them)
+    "k_tail<2, false, false, true>": (168, 244),   # textured materials
     "k_trace_quad<false>": (128, 0),             # one ray per quad of lanes (small launches; off by default)
     "k_shade_hair": (136, 0),
     "k_sss_step": (208, 0),  # 156 -> 201 VGPRs with the packed light pretest (round 4): 3.55 ms per 64 spp of C3 before and after
