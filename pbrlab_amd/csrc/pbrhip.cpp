@@ -978,12 +978,34 @@ void pb::shard_pixels(uint32_t w, uint32_t h, uint32_t rank, uint32_t world, uin
 
 int pb::ensure_pixels(pbrhip_scene* s, uint32_t w, uint32_t h, uint32_t rank, uint32_t world, uint32_t block) {
   if (block == 0) block = 64;
-  if (s->pk_w == w && s->pk_h == h && s->pk_rank == rank && s->pk_world == world && s->pk_block == block && s->pix_index.p) return PBRHIP_OK;
+  uint32_t pt = 8u;
+  if (const char* e = getenv("PBRHIP_PIXEL_TILE")) pt = (uint32_t)strtoul(e, nullptr, 10);
+  if (s->pk_w == w && s->pk_h == h && s->pk_rank == rank && s->pk_world == world && s->pk_block == block && s->pk_tile == pt && s->pix_index.p) return PBRHIP_OK;
   std::vector<uint32_t> pix;
   shard_pixels(w, h, rank, world, block, &pix);
-  HIPCHK(s->pix_index.upload(pix, s->stream));
+  // The order the paths of a pass are laid out in (path j of a pass = pixel pix[j]): the rank's blocks in shard_pixels' order, and
+  // inside a block sub-blocks of PBRHIP_PIXEL_TILE x PBRHIP_PIXEL_TILE pixels (default 8) instead of rows -- a wave's 64 camera
+  // rays are an 8 x 8 patch, not a 64 x 1 strip: they share more of the tree, and so do their later bounces.  A permutation of
+  // the list: every value is a function of (pixel, pass) alone, images do not change.
+  HIPCHK(s->pix_index.upload(pix, s->stream));  // (the shard's own order: what the exchange packs and unpacks by, multi.cpp)
+  if (pt > 1u && pt < block) {
+    std::vector<uint32_t> ordered;
+    ordered.reserve(pix.size());
+    uint32_t t = 0;
+    for (uint32_t by = 0; by < h; by += block)
+      for (uint32_t bx = 0; bx < w; bx += block, t++) {
+        if (t % world != rank) continue;
+        const uint32_t ey = std::min(by + block, h), ex = std::min(bx + block, w);
+        for (uint32_t sy = by; sy < ey; sy += pt)
+          for (uint32_t sx = bx; sx < ex; sx += pt)
+            for (uint32_t y = sy; y < std::min(sy + pt, ey); y++)
+              for (uint32_t x = sx; x < std::min(sx + pt, ex); x++) ordered.push_back(y * w + x);
+      }
+    pix.swap(ordered);
+  }
+  HIPCHK(s->path_pix.upload(pix, s->stream));
   HIPCHK(hipStreamSynchronize(s->stream));
-  s->pk_w = w, s->pk_h = h, s->pk_rank = rank, s->pk_world = world, s->pk_block = block, s->pk_npix = (uint32_t)pix.size();
+  s->pk_w = w, s->pk_h = h, s->pk_rank = rank, s->pk_world = world, s->pk_block = block, s->pk_tile = pt, s->pk_npix = (uint32_t)pix.size();
   return PBRHIP_OK;
 }
 
@@ -1172,7 +1194,7 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
         const size_t off = gr.slot0;
         gr.P.q_in += off, gr.P.q_out += off, gr.P.q_principled += off, gr.P.q_hair += off, gr.P.q_sss += off, gr.P.q_shadow += off, gr.P.q_shadow_in += off;
         for (int k = 0; k < 3; k++) gr.P.cam_org[k] = cam.org[k];
-        gr.P.cam = cam, gr.P.pix_index = s->pix_index.p, gr.P.npix = npix, gr.P.width = d->width, gr.P.first_pass = gr.first_pass;
+        gr.P.cam = cam, gr.P.pix_index = s->path_pix.p, gr.P.npix = npix, gr.P.width = d->width, gr.P.first_pass = gr.first_pass;
         gr.P.slot0 = gr.slot0, gr.P.seed_seq = d->seed_seq;
         gr.tm = Timer{s, want_timing, nullptr};
       }
@@ -1311,7 +1333,7 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
           PA.L = P.L + gr.slot0;
           Timer tm{s, want_timing, st};
           HIPCHK(tm.begin(&S.ms_accumulate));
-          launch_accumulate(st, PA, s->pix_index.p, npix, gr.npass, d_rgba, d_count);
+          launch_accumulate(st, PA, s->path_pix.p, npix, gr.npass, d_rgba, d_count);
           HIPCHK(tm.end());
           HIPCHK(hipGetLastError());
           if (want_timing) {

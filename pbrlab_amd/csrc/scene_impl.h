@@ -105,7 +105,7 @@ struct pbrhip_scene {
   pb::DScene dscene;
   // render working set (grown on demand, reused across calls)
   pb::DevBuf<float4> rec, srec, ssrec, L, hit, sss_A, sh_e;  // path state (kernels.h::PathState): rec = 4 words of 16 B per path, srec = 2
-  pb::DevBuf<uint32_t> q[7], counts, pix_index, spill;
+  pb::DevBuf<uint32_t> q[7], counts, pix_index, path_pix, spill;  // pix_index: the rank's pixels in the shard's order (exchange); path_pix: in the order the paths are laid out in
   pb::DevBuf<unsigned long long> stats;
   pb::DevBuf<float> own_rgba;
   pb::DevBuf<uint32_t> own_count;
@@ -115,7 +115,7 @@ struct pbrhip_scene {
   uint32_t* h_counts = nullptr;            // pinned, kMaxGroups x kCntNum
   std::vector<hipStream_t> group_streams;  // streams of path groups 1.. (group 0 uses `stream`)
   // pixel list cache key (ensure_pixels)
-  uint32_t pk_w = 0, pk_h = 0, pk_rank = 0, pk_world = 0, pk_block = 0, pk_npix = 0;
+  uint32_t pk_w = 0, pk_h = 0, pk_rank = 0, pk_world = 0, pk_block = 0, pk_tile = 0, pk_npix = 0;
   std::vector<hipEvent_t> events;
   // layer exchange (multi.cpp): packed shard of this rank / staging for the shards of the others
   pb::DevBuf<float> xchg_send, xchg_recv;

@@ -119,6 +119,28 @@ def test_render_odd_size_and_larger(pa, pairs):
         image_check(layer.rgba, rgba)
 
 
+@pytest.mark.parametrize("tile", ["1", "3", "8", "16", "100"])
+def test_path_order_inside_a_block_does_not_matter(pa, pairs, tile, monkeypatch):
+    """The paths of a pass are laid out block by block and, inside a block, in patches of PBRHIP_PIXEL_TILE x PBRHIP_PIXEL_TILE
+    pixels (default 8: a wave's camera rays are an 8 x 8 patch; 1 or >= the block: rows).  Every value is a function of
+    (pixel, pass) alone: the image is the oracle's whatever the order, at sizes that are no multiples of anything, alone and
+    sharded (the exchange keeps the shard's own pixel order)."""
+    desc, sg, so = pairs["ggx"]
+    monkeypatch.setenv("PBRHIP_PIXEL_TILE", tile)
+    for (w, h, spp) in [(131, 77, 3), (7, 5, 2)]:
+        layer = pa.RenderLayer()
+        pa.Render(sg, w, h, spp, layer=layer)
+        rgba, cnt, _ = so.render(w, h, spp, threads=8, math_mode=O.MATH_F64R)
+        assert np.array_equal(layer.count, cnt) and layer.rgba.tobytes() == rgba.tobytes(), (tile, w, h)
+        acc, cacc = np.zeros_like(layer.rgba), np.zeros_like(layer.count)
+        for r in range(3):
+            part = pa.RenderLayer()
+            pa.Render(sg, w, h, spp, layer=part, tile_rank=r, tile_world=3, shard_block=16)
+            acc += part.rgba
+            cacc += part.count
+        assert acc.tobytes() == rgba.tobytes() and np.array_equal(cacc, cnt), (tile, w, h)
+
+
 def test_chunking_and_progressive_are_exact(pa, pairs):
     """results must not depend on how passes are chunked (max_paths_in_flight) and a resumed render
     (first_pass + NO_CLEAR) equals the one-shot render bit for bit"""
