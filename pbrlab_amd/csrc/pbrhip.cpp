@@ -1070,7 +1070,9 @@ static std::vector<uint32_t> plan_groups(uint32_t np, uint32_t npix, uint32_t wa
   // holds at least 96 Mi paths (the whole 132.7 M-path frame: 60.4 -> 58.9 ms; one group's launch-bound drains and its
   // k_tail overlap the other's bulk work); one group below that (a half / quarter / eighth of the frame: 32.6 / 19.7 /
   // 12.1 ms with one group against 32.2 / 19.9 / 12.8 with two -- every extra group adds its own latency-bound launches)
-  if ((uint64_t)np * npix >= (96ull << 20) && np >= 2) g.push_back(np / 2), g.push_back(np - np / 2);
+  // Round 4, after the shading kernels got faster: two groups also pay for a half and a quarter of the frame (27.1-27.2 / 16.0-16.4 ms
+  // against 27.9-28.2 / 16.6-16.7 with one), not for an eighth (10.0-10.2 either way): the threshold is 24 Mi paths now.
+  if ((uint64_t)np * npix >= (24ull << 20) && np >= 2) g.push_back(np / 2), g.push_back(np - np / 2);
   else g.push_back(np);
   return g;
 }
