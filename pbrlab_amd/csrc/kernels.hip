@@ -1545,6 +1545,12 @@ bool trace_uses_wide(const DScene& sc) { return use_wide(sc); }
 #ifndef PB_TRACEWP_DEFAULT
 #define PB_TRACEWP_DEFAULT 0
 #endif
+#ifndef PB_TRACE_SMALL1_RAYS
+#define PB_TRACE_SMALL1_RAYS 16000000u  // launches of at most this many rays (upper bound): PB_TRACE_SMALL1_BLOCKS blocks per CU
+#define PB_TRACE_SMALL1_BLOCKS 4u
+#define PB_TRACE_SMALL2_RAYS 4000000u   // ... and of at most this many: PB_TRACE_SMALL2_BLOCKS
+#define PB_TRACE_SMALL2_BLOCKS 3u
+#endif
 #ifndef PB_QUAD_RAYS
 #define PB_QUAD_RAYS 0u  // k_trace launches of at most this many rays run on k_trace_quad (PBRHIP_QUAD_RAYS overrides)
 #endif
@@ -1592,11 +1598,17 @@ void launch_trace(hipStream_t s, const PathState& P, const DScene& sc, uint32_t 
     const uint32_t k = (uint32_t)strtoul(b, nullptr, 10);
     if (k >= 1u && 256u * k < cap) cap = 256u * k;
   }
-  if (const char* b = getenv("PBRHIP_TRACE_BLOCKS_SMALL")) {  // "k,n": k blocks per CU for launches of at most n rays
+  if (const char* b = getenv("PBRHIP_TRACE_BLOCKS_SMALL")) {  // "k,n": k blocks per CU for launches of at most n rays ("0,0": none)
     char* end = nullptr;
     const uint32_t k = (uint32_t)strtoul(b, &end, 10);
     const uint32_t lim = (end && *end == ',') ? (uint32_t)strtoul(end + 1, nullptr, 10) : 0u;
     if (k >= 1u && n_upper <= lim && 256u * k < cap) cap = 256u * k;
+  } else if (wide && !curves) {
+    // Fewer resident blocks for the launches that do not fill the chip for long (round 4, after the shading kernels got faster;
+    // scripts/sched_ab.py, rank 0's share of the C2 frame): their drain -- every wave waiting for its longest ray -- runs at
+    // fewer waves per SIMD, and the other path group's kernels find room on the CUs.
+    if (n_upper <= PB_TRACE_SMALL2_RAYS) cap = std::min(cap, 256u * PB_TRACE_SMALL2_BLOCKS);
+    else if (n_upper <= PB_TRACE_SMALL1_RAYS) cap = std::min(cap, 256u * PB_TRACE_SMALL1_BLOCKS);
   }
   if (P.first) {
     // a group's first launch: camera rays only, computed by the sink (TraceSinkT<.., FIRST>); always the phase-voting kernel
