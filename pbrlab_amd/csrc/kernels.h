@@ -8,11 +8,11 @@
 
 namespace pb {
 
-// Per-path state, SoA, float4-packed so that a wave reads/writes 1 KiB per instruction.
+// Per-path state, 16-byte words, grouped into records (below).
 // N = paths of one chunk (pixels of this rank's tiles x passes in the chunk); slot = pass_local*npix + pixel.
-//   ray_o (org.xyz, tmin) | ray_d (dir.xyz, tmax) | thr (throughput.rgb, bsdf pdf) | L (contribution.rgb, -)
-//   hit (t, u, v, slot bits) | rng (PCG32 state, u64)                                              = 88 B
-//   random-walk state, touched only by paths inside a medium:                                       80 B
+//   ray_o (org.xyz, tmin) | ray_d (dir.xyz, tmax) | thr (throughput.rgb, bsdf pdf) | rng (PCG32 state, u64)   = rec, 64 B
+//   hit (t, u, v, slot bits) | L (contribution.rgb, -)                                              arrays of their own
+//   random-walk state, touched only by paths inside a medium (ssrec 64 B + sss_A):
 //     sss_sigt (sigma_t.rgb) | sss_sigs (sigma_s.rgb, entry instance id) | sss_thr (walk throughput, step index)
 //     sss_ez (entry frame normal) | sss_A (resolved first NEE)
 //   queues (u32 path slots): q_in/q_out (ping-pong), q_principled, q_hair, q_sss, q_shadow; the shadow-ray payload

@@ -1,7 +1,7 @@
 // kernels.hip -- the wavefront path tracer's device kernels (gfx950, wave64).
 //
-// One path = one (pixel, pass) sample.  Path state lives in HBM as float4-packed SoA indexed by the
-// path slot; stages exchange *queues of slot ids*, compacted tile-wise (2048 entries, one atomic per
+// One path = one (pixel, pass) sample.  Path state lives in HBM, in records indexed by the path slot
+// (kernels.h::PathState); stages exchange *queues of slot ids*, compacted tile-wise (2048 entries, one atomic per
 // tile and queue).  One iteration of the host loop (pbrhip.cpp::render_impl) =
 //
 //   k_trace           rtcIntersect1 (raytracer_impl.cc:268-278) for the live paths' rays AND rtcOccluded1 + the tail of
