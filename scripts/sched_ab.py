@@ -15,7 +15,7 @@ W, H = 1920, 1080
 rgba = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda"); cnt = torch.zeros((H, W), dtype=torch.int32, device="cuda")
 torch.cuda.synchronize()
 REPS = int(os.environ.get("REPS", "3"))
-KEYS = ("PBRHIP_WIDE", "PBRHIP_WIDE_WALK", "PBRHIP_RAYS_PER_WAVE", "PBRHIP_GROUPS", "PBRHIP_WINDOW", "PBRHIP_BULK_DIV", "PBRHIP_GROUP_MIN_PATHS", "PBRHIP_STREAMS", "PBRHIP_TAIL_PATHS", "PBRHIP_QUAD_RAYS", "PBRHIP_PIXEL_TILE", "PBRHIP_TRACE_BLOCKS_SMALL", "PBRHIP_TRACE_BLOCKS", "PBRHIP_BURST")
+KEYS = ("PBRHIP_WIDE", "PBRHIP_WIDE_WALK", "PBRHIP_RAYS_PER_WAVE", "PBRHIP_GROUPS", "PBRHIP_WINDOW", "PBRHIP_BULK_DIV", "PBRHIP_GROUP_MIN_PATHS", "PBRHIP_STREAMS", "PBRHIP_TAIL_PATHS", "PBRHIP_QUAD_RAYS", "PBRHIP_PIXEL_TILE", "PBRHIP_TRACE_BLOCKS_SMALL", "PBRHIP_TRACE_BLOCKS", "PBRHIP_RETIRE")
 CONFIGS = [
     {"PBRHIP_STREAMS": "1"},
     {"PBRHIP_STREAMS": "2"},                                 # round 1's default for big chunks
