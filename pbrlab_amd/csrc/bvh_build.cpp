@@ -22,6 +22,9 @@ namespace {
 #define PB_SAH_BINS 48  // (round 4: 16 -> 48 bins: k_trace of C2 -2.4 %, of the hair scene -3.9 %, of C5 -0.6 %; 24 and 32 are better on two of the three)
 #endif
 constexpr int kBins = PB_SAH_BINS;
+#ifndef PB_SAH_SWEEP
+#define PB_SAH_SWEEP 256  // ranges of at most this many primitives are split by the exact SAH (all positions of all axes) instead of by bins
+#endif
 constexpr float kTraversalCost = 1.0f;
 constexpr float kPrimCost = 1.5f;
 
@@ -94,6 +97,35 @@ struct Builder {
       mid = (uint32_t)(std::partition(order.begin() + first, order.begin() + first + count,
                                       [&](uint32_t g) { return kinds[g] == 0; }) -
                        order.begin());
+    } else if (count <= (uint32_t)PB_SAH_SWEEP) {
+      // small ranges: the exact SAH -- every split position of every axis (the bins are too coarse down here), the two sides
+      // priced by the LEAVES they will make (kMaxLeaf primitives each: an odd split of four triangles costs a third leaf)
+      auto leaves = [](uint32_t n) { return (float)((n + (uint32_t)kMaxLeaf - 1u) / (uint32_t)kMaxLeaf); };
+      std::vector<uint32_t> idx(order.begin() + first, order.begin() + first + count), best_idx;
+      std::vector<float> rarea(count);
+      float best_cost = std::numeric_limits<float>::infinity();
+      uint32_t best_k = 0;
+      for (int a = 0; a < 3; a++) {
+        if (!(cbox.hi[a] - cbox.lo[a] > 0.f)) continue;
+        std::sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return cen[3 * x + a] < cen[3 * y + a] || (cen[3 * x + a] == cen[3 * y + a] && x < y); });
+        Box acc;
+        acc.reset();
+        for (uint32_t k = count - 1; k > 0; k--) acc.grow(lo + 3 * idx[k], hi + 3 * idx[k]), rarea[k] = acc.area();
+        acc.reset();
+        bool better = false;
+        for (uint32_t k = 0; k + 1 < count; k++) {
+          acc.grow(lo + 3 * idx[k], hi + 3 * idx[k]);
+          const float cost = acc.area() * leaves(k + 1) + rarea[k + 1] * leaves(count - k - 1);
+          if (cost < best_cost) best_cost = cost, best_k = k + 1, better = true;
+        }
+        if (better) best_idx = idx;
+      }
+      if (!best_idx.empty()) {
+        std::copy(best_idx.begin(), best_idx.end(), order.begin() + first);
+        mid = first + best_k;
+      } else {
+        mid = first + count / 2;  // all centroids coincide: halves in the order they are in
+      }
     } else {
       int best_axis = -1, best_bin = 0;
       float best_cost = std::numeric_limits<float>::infinity();
