@@ -408,14 +408,19 @@ struct TileCompactor {
 // path already knew the throughput and the generator state the roulette will use) and whose hit primitive is no light
 // ends at the head of its shading without storing anything (path_head returns false), so it is dropped here instead of
 // idling in a shading wave; likewise a hit on a primitive without material.  The routing bits come with the hit code.
+// The principled hits of a tile (2048 entries) leave it in two runs -- first the hits whose shading fetches the long part of the
+// ShadeRec (kHitMore: corner normals / texcoords: the smooth meshes), then the hits on flat triangles -- so that a shading wave is
+// mostly one kind or the other: the same queue, the same lines touched per tile, fewer waves that run both sides of every branch
+// (north star: "per-closure material sorting", here by what the hit code already says; separate queues lose: profiles/README.md).
 __global__ __launch_bounds__(kBlock) void k_classify(PathState P, DScene sc) {
   constexpr int kItemsPerThread = kClassifyItems, kTileItems = kItemsPerThread * kBlock;
-  __shared__ uint32_t wcount[3][kItemsPerThread][kWavesPerBlock];
-  __shared__ uint32_t base[3];
+  __shared__ uint32_t wcount[4][kItemsPerThread][kWavesPerBlock];
+  __shared__ uint32_t base[4];
+  __shared__ uint32_t tile_principled[2];  // this tile's two runs: counted in LDS, reserved in the queue with ONE atomic
   const uint32_t n = P.counts[kCntIn];
   const uint32_t ntiles = (n + kTileItems - 1) / kTileItems;
-  uint32_t* const counters[3] = {&P.counts[kCntSss], &P.counts[kCntPrincipled], &P.counts[kCntHair]};
-  uint32_t* const queues[3] = {P.q_sss, P.q_principled, P.q_hair};
+  uint32_t* const counters[4] = {&P.counts[kCntSss], &tile_principled[0], &P.counts[kCntHair], &tile_principled[1]};
+  uint32_t* const queues[4] = {P.q_sss, P.q_principled, P.q_hair, P.q_principled};
   for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     uint32_t p[kItemsPerThread], dest[kItemsPerThread];
     bool doomed[kItemsPerThread];
@@ -434,11 +439,19 @@ __global__ __launch_bounds__(kBlock) void k_classify(PathState P, DScene sc) {
     for (int j = 0; j < kItemsPerThread; j++)
       if (dest[j] == 0xFFu) {
         const uint32_t code = __float_as_uint(P.hit[p[j]].w);
-        dest[j] = (code & kHitHair) ? 3u : 2u;
+        dest[j] = (code & kHitHair) ? 3u : ((code & kHitMore) ? 2u : 4u);
         if (code == kNone || (!(code & kHitLight) && (doomed[j] || (code & kHitNoMaterial)))) dest[j] = 0u;
       }
-    TileCompactor<3, kItemsPerThread> tc = {wcount, base, {}};
-    tc.run(dest, counters);
+    if (threadIdx.x < 2) tile_principled[threadIdx.x] = 0u;
+    __syncthreads();
+    TileCompactor<4, kItemsPerThread> tc = {wcount, base, {}};
+    tc.run(dest, counters);  // (base[1] = base[3] = 0: the two runs were counted from 0)
+    if (threadIdx.x == 0) {
+      const uint32_t a = tile_principled[0], b = tile_principled[1];
+      const uint32_t g = (a + b) ? atomicAdd(&P.counts[kCntPrincipled], a + b) : 0u;
+      base[1] = g, base[3] = g + a;
+    }
+    __syncthreads();
 #pragma unroll
     for (int j = 0; j < kItemsPerThread; j++)
       if (dest[j]) queues[dest[j] - 1][tc.slot(j, dest[j])] = p[j];
