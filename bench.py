@@ -41,15 +41,19 @@ WORKLOADS = {
                scene="cornell_hair", variant="sss", width=3840, height=2160, spp=1024),
 }
 
-# algorithmic bytes of the traversal kernel k_trace: 64 B per binary / 128 B per 4-wide BVH node visited, 48 B per
+# algorithmic bytes of the traversal kernel k_trace: 64 B per binary / Q-tree node visited (80 B per 8-wide O-tree node), 48 B per
 # triangle tested, 64 B per curve tested; per closest-hit ray 32 B ray + 16 B hit record + 4 B queue entry; per
 # shadow ray 32 B ray (origin shared with the continuation ray) + 4 B queue entry + 16 B pending contribution
 NODE_B, TRI_B, CURVE_B, RAY_B, SHADOW_RAY_B = 64, 48, 64, 52, 52
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-SIMDS, CLOCK_HZ = 1024, 2.4e9   # 256 CUs x 4 SIMDs; MI355X_MICROARCH.md peak engine clock
-GATHER_PEAK_GBS = 256 * 2.4 * 14.6  # per-lane gathers through the vector L1: 14.6 B per clock and CU, measured (scripts/ubench/vmem_quads.hip)
+SIMDS, XCDS, CUS, CLOCK_HZ = 1024, 8, 256, 2.4e9   # 256 CUs x 4 SIMDs in 8 XCDs; MI355X_MICROARCH.md peak engine clock (the measured clock is reported next to it)
+# Per-lane 16-byte gathers through the vector L1 (every lane its own 64-byte item, four global_load_dwordx4; the table resident in
+# L1): 23.9 bytes per clock and CU, measured with one 16 KB table for all blocks at 1 / 2 / 4 / 6 blocks per CU
+# (scripts/ubench/vmem_gather2.hip, profiles/r5_gather2.txt; L2-resident: 21.9; a fully coalesced control: 31.7).  An ESTIMATE of
+# what the load path can deliver to k_trace's access pattern -- it never sets `bound`.
+GATHER_L1_BYTES_PER_CLK_CU = 23.9
 
 
 def csrc_hash():
@@ -69,11 +73,11 @@ def csrc_hash():
 
 
 def pmc_record(workload, spp, world, kernel):
-    """Counters cannot be read live, so they come from the committed PMC passes of this round (profiles/r4_<workload>_pmc.json,
+    """Counters cannot be read live, so they come from the committed PMC passes of this round (profiles/r5_<workload>_pmc.json,
     written by scripts/profile_round.py: FETCH_SIZE, WRITE_SIZE and SQ counters in separate --pmc passes over one render of
     the same workload, per kernel).  They are only used when that file was collected on the very kernel sources that are
     running (csrc_hash) and on the same configuration; otherwise the counter-based fields are null."""
-    path = os.path.join(ROOT, "profiles", f"r4_{workload}_pmc.json")
+    path = os.path.join(ROOT, "profiles", f"r5_{workload}_pmc.json")
     if world != 1 or not os.path.exists(path):
         return None, "no PMC record for this configuration"
     rec = json.load(open(path))
@@ -85,14 +89,17 @@ def pmc_record(workload, spp, world, kernel):
     return k, rec.get("source", "")
 
 
-PMC_PASSES = ["FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY"]
+# (one rocprofv3 run per group; FETCH_SIZE / WRITE_SIZE apart as the guide prescribes; 8 SQ slots, GRBM and TCP are their own blocks)
+PMC_PASSES = ["FETCH_SIZE", "WRITE_SIZE",
+              "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE",
+              "TCP_TOTAL_ACCESSES_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum"]
 
 
 def pmc_live(workload, spp, kernel, budget_s):
     """The counters of `kernel` measured by THIS run: rocprofv3 --pmc passes (counters only: no trace flag next to --pmc, one
     pass per counter group as MI355X_MICROARCH.md prescribes; FETCH_SIZE / WRITE_SIZE apart) over one render of the workload as
     one path group in child processes (scripts/render_once.py: the program itself after `--`), after the timed region.
-    Returns (record like profiles/r4_<workload>_pmc.json's kernel entry, note) or (None, why) -- the caller then falls back
+    Returns (record like profiles/r5_<workload>_pmc.json's kernel entry, note) or (None, why) -- the caller then falls back
     to the committed record."""
     import collections
     import csv
@@ -244,6 +251,27 @@ def cpu_baseline(workload):
                         "schedule_efficiency": r["schedule_efficiency"], "sample": r["sample"]} for r in runs]}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: run
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>`
+    as a child process (one fresh process per GPU, each reads RANK / LOCAL_RANK / WORLD_SIZE), pass its output through -- rank 0
+    prints the JSON line -- and return its exit code.  Nothing in this process has imported torch or touched the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    if os.environ.get("BENCH_SPAWN_DRY_RUN"):   # (CPU test: what would be started)
+        print(json.dumps({"spawn": cmd}))
+        return 0
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -267,7 +295,19 @@ def main():
     ap.add_argument("--exchange", default="gather", choices=["gather", "reduce", "torch"],
                     help="N > 1: how the RenderLayer reaches rank 0: gather / reduce = RCCL inside libpbrhip "
                          "(pbrhip_comm_gather_layer / pbrhip_comm_reduce_layer), torch = torch.distributed.reduce")
+    ap.add_argument("--spawn-selftest", action="store_true", help=argparse.SUPPRESS)   # CPU test of the launcher path (tests/test_dist_cpu.py)
     args = ap.parse_args()
+    if args.spawn_selftest and "WORLD_SIZE" in os.environ:
+        # a rank started by spawn_ranks(): rendezvous over gloo on 127.0.0.1, one collective, rank 0 prints the line (no GPU involved)
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        t = torch.tensor([dist.get_rank() + 1])
+        dist.all_reduce(t)
+        if dist.get_rank() == 0:
+            print(json.dumps({"selftest": dist.get_world_size(), "sum": int(t.item())}))
+        dist.destroy_process_group()
+        return
     if args.cpu_baseline_child:
         print(json.dumps(cpu_baseline_run(args.cpu_baseline_child, 0, args.cpu_seconds)))
         return
@@ -278,12 +318,17 @@ def main():
     from pbrlab_amd import api
     from pbrlab_amd.dist import reduce_layer
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N rank processes ourselves -- torch.distributed.run as a CHILD,
+        # decided here, before this process has imported torch or touched the GPU (a process that initialised the GPU must never
+        # be replaced by another program) -- hand on rank 0's JSON line and the launcher's exit code.
+        sys.exit(spawn_ranks(args.gpus))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}: launch it with --nproc-per-node {args.gpus} (or without a launcher)")
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -416,48 +461,69 @@ def main():
             # counter-based ceilings, from this round's committed PMC passes on these very kernel sources (else null)
             default_cfg = not (args.max_paths or args.streams or args.spp)
             pmc, pmc_note = (None, "non-default configuration")
+            trace_kernel = "pb::k_trace8<false" if node_b == 80 else "pb::k_trace<false"   # the O tree's kernel (80-byte nodes) or the Q / binary tree's
             if default_cfg and world == 1 and not args.no_live_pmc:
-                pmc, pmc_note = pmc_live(args.workload, spp, "pb::k_trace<false", args.pmc_budget)
+                pmc, pmc_note = pmc_live(args.workload, spp, trace_kernel, args.pmc_budget)
             if pmc is None and default_cfg:
                 live_note = pmc_note
-                pmc, pmc_note = pmc_record(args.workload, spp, world, "pb::k_trace<false")
+                pmc, pmc_note = pmc_record(args.workload, spp, world, trace_kernel)
                 pmc_note = f"{pmc_note} [committed record; {live_note}]" if pmc else f"{pmc_note}; {live_note}"
-            traffic = frac_hbm_counter = valu = None
-            bound = "hbm"
-            # third ceiling (round 4): the vector-memory GATHER path.  A per-lane 64-byte item fetch (four global_load_dwordx4) is
-            # served at 14.6 bytes per clock and CU whatever the lanes' address pattern (scripts/ubench/vmem_quads.hip: 299 / 274
-            # cycles per 64 x 64 B wave step from L1-resident tables -- own item per lane / four lanes per item -- and 360 / 332 from
-            # L2-resident ones): 256 CUs x 2.4 GHz x 14.6 B = 8.97 TB/s.  Every node, triangle leaf, curve piece and ray record of
-            # k_trace takes that path, so the ALGORITHMIC bytes of a launch over its solo duration are a fraction of THIS peak.
-            gather = {"peak": GATHER_PEAK_GBS, "achieved": bytes_step / (solo_ms * 1e-3) / 1e9, "frac": bytes_step / (solo_ms * 1e-3) / 1e9 / GATHER_PEAK_GBS,
-                      "note": "algorithmic bytes per launch / solo launch duration / the measured per-lane gather throughput of the vector L1 path "
-                              "(14.6 B per clock and CU: scripts/ubench/vmem_quads.hip, profiles/README.md)"}
+            traffic = frac_hbm_counter = valu = gather = None
+            bound, fracs = "hbm", {}
             if pmc:
                 traffic = pmc["hbm_bytes_per_dispatch_fetch_x2"]
+                n_disp = max(pmc["dispatches"], 1)
                 # HBM-side bytes per launch / the launch's duration when it has the GPU to itself / the 8 TB/s peak
                 frac_hbm_counter = traffic / solo_launch_s / 1e9 / HBM_PEAK_GBS
-                if pmc.get("SQ_INSTS_VALU"):
-                    n_disp = max(pmc["dispatches"], 1)
-                    t_valu = pmc["SQ_INSTS_VALU"] / n_disp * 4.0 / (SIMDS * CLOCK_HZ)   # a wave64 VALU instruction holds its SIMD for 4 cycles
-                    valu = {"insts_valu_per_launch": pmc["SQ_INSTS_VALU"] / n_disp, "insts_salu_per_launch": pmc.get("SQ_INSTS_SALU", 0) / n_disp,
-                            "issue_bound_ms": t_valu * 1e3, "frac": t_valu / solo_launch_s,
-                            "lanes_per_valu": pmc["SQ_THREAD_CYCLES_VALU"] / pmc["SQ_INSTS_VALU"] if pmc.get("SQ_THREAD_CYCLES_VALU") else None,
+                fracs["hbm"] = frac_hbm_counter
+                # the kernel's own cycles: GRBM_GUI_ACTIVE is summed over the 8 XCDs (and over the launches of the pass)
+                cycles = pmc.get("GRBM_GUI_ACTIVE", 0.0) / XCDS
+                clock_hz = cycles / n_disp / solo_launch_s if cycles else None   # (counter pass / solo timing of the same launches: an estimate)
+                if pmc.get("SQ_ACTIVE_INST_VALU") and cycles:
+                    # VALU ceiling as a COUNTER RATIO (round 5; VERDICT round 4: a constant of 4 cycles per instruction was wrong for v_fma_f32
+                    # and a constant of 2 is wrong for everything else): SQ_ACTIVE_INST_VALU counts, in units of 4 cycles, the time the
+                    # waves spend executing VALU instructions; over 1024 SIMDs x the kernel's active cycles it is the fraction of the
+                    # launch the VALU pipes are busy.  Calibrated on kernels that are VALU-bound by construction
+                    # (scripts/ubench/valu_rate.hip, profiles/r5_ubench_pmc.txt): v_pk_fma / v_pk_mul / v_pk_add / v_min / v_cvt_f32_ubyte /
+                    # v_mul_lo_u32 (4.2-4.7 cycles per wave64 instruction and SIMD each, measured) read 0.96-0.99, v_rcp_f32 (8.2 cycles)
+                    # 0.98, the instruction mix of a Q-node slab test 1.02 -- and a stream of NOTHING BUT v_fma_f32 reads 1.70: that one
+                    # instruction class issues in 2.3-2.6 cycles and the counter prices it at 4.  k_trace has ~8 % plain v_fma_f32.
+                    frac_valu = pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / (SIMDS * cycles)
+                    valu = {"frac": frac_valu, "insts_valu_per_launch": pmc.get("SQ_INSTS_VALU", 0.0) / n_disp, "insts_salu_per_launch": pmc.get("SQ_INSTS_SALU", 0) / n_disp,
+                            "active_cycles_per_launch": cycles / n_disp, "clock_ghz": clock_hz / 1e9 if clock_hz else None,
+                            "cycles_per_valu_inst": pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / pmc["SQ_INSTS_VALU"] if pmc.get("SQ_INSTS_VALU") else None,
+                            "lanes_per_valu": pmc["SQ_THREAD_CYCLES_VALU"] / pmc["SQ_INSTS_VALU"] if pmc.get("SQ_THREAD_CYCLES_VALU") and pmc.get("SQ_INSTS_VALU") else None,
                             "wait_any_frac": pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"] if pmc.get("SQ_WAVE_CYCLES") else None,
-                            "note": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz) / launch duration (solo): the fraction of the launch "
-                                    "the VALU pipes are issuing, whatever the EXEC mask; lanes_per_valu = SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU"}
-                    if valu["frac"] > frac_hbm_counter:
-                        bound = "valu"
-                if gather["frac"] > max(frac_hbm_counter, valu["frac"] if valu else 0.0):
-                    bound = "gather"
-            roofline = {"bound": bound, "kernel": "k_trace (closest-hit rays of bounce k + shadow rays of bounce k-1)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                            "note": "frac = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs): a counter ratio over the kernel's own active cycles "
+                                    "(no clock assumed), ~1.0 on VALU-bound calibration kernels of this instruction mix; clock_ghz = active cycles / solo launch duration"}
+                    fracs["valu"] = frac_valu
+                if pmc.get("TCP_TOTAL_ACCESSES_sum") and cycles:
+                    # the vector-memory load path: 16-byte lane accesses x 16 B over the kernel's cycles, against what the same access
+                    # pattern gets from an L1-resident table (GATHER_L1_BYTES_PER_CLK_CU, measured).  An estimate: reported, never `bound`.
+                    b_clk_cu = pmc["TCP_TOTAL_ACCESSES_sum"] * 16.0 / (cycles * CUS)
+                    tag, miss = pmc.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0), pmc.get("TCP_TCC_READ_REQ_sum", 0.0)
+                    gather = {"frac": b_clk_cu / GATHER_L1_BYTES_PER_CLK_CU, "bytes_per_clk_cu": b_clk_cu, "peak_bytes_per_clk_cu": GATHER_L1_BYTES_PER_CLK_CU,
+                              "l1_hit_rate": 1.0 - miss / tag if tag else None, "lanes_per_line": pmc["TCP_TOTAL_ACCESSES_sum"] / tag if tag else None,
+                              "l2_read_latency_cycles": pmc["TCP_TCC_READ_REQ_LATENCY_sum"] / miss if miss and pmc.get("TCP_TCC_READ_REQ_LATENCY_sum") else None,
+                              "note": "ESTIMATE (does not set `bound`): TCP_TOTAL_ACCESSES x 16 B per clock and CU over the measured rate of per-lane 64-byte gathers "
+                                      "from an L1-resident table (scripts/ubench/vmem_gather2.hip: 23.9 B/clk/CU at 1-6 blocks per CU; L2-resident 21.9; "
+                                      "coalesced control 31.7; beyond L2 the unit of cost is the 128-byte line: ~60 G lines/s chip-wide)"}
+                ok = {k: v for k, v in fracs.items() if v is not None and v <= 1.0}   # a ceiling fraction above 1 is a broken model, never a bound
+                if ok:
+                    bound = max(ok, key=ok.get)
+            roofline = {"bound": bound, "kernel": ("k_trace8" if node_b == 80 else "k_trace") + " (closest-hit rays of bounce k + shadow rays of bounce k-1)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                         "note": "achieved / frac = ALGORITHMIC bytes (64 B per node visit -- binary tree or the Q tree's quantised 4-wide node --, 48 B per triangle test, 32 B per curve-piece test on the Q tree (64 on the binary tree), 52 B per ray: SURVEY 8d) / kernel "
                                 "time (HIP events on the launch's own stream, timed region) -- NOT a ceiling: the scene is served from L2 / "
                                 "Infinity Cache, so it can exceed 1.  The ceilings are frac_hbm_counter (HBM-side bytes from the FETCH_SIZE / "
-                                "WRITE_SIZE PMC passes per launch / solo launch duration / 8 TB/s), valu.frac (VALU issue) and gather.frac (the "
-                                "vector-memory gather path, 8.97 TB/s measured); `bound` names the largest.  By default the frame runs as two path groups on two HIP streams whose launches overlap, so "
+                                "WRITE_SIZE PMC passes per launch / solo launch duration / 8 TB/s) and valu.frac (VALU pipes busy, a counter ratio); "
+                                "gather.frac (the vector L1's per-lane gather rate) is an estimate.  By default the frame runs as two path groups on two HIP streams whose launches overlap, so "
                                 "per-launch durations of the timed region include shared time; `solo` and kernel_ms_per_step are from an "
-                                "untimed extra render as ONE group, every launch alone on the GPU",
+                                "untimed extra render as ONE group, every launch alone on the GPU.  `bound` names the largest COUNTER-DERIVED fraction "
+                                "(frac_hbm_counter, valu.frac) that is <= 1; when none of them is near 1 (see `limiter`) the kernel is bound by the latency "
+                                "of its dependent item fetches times the rays in flight, not by a unit's throughput",
+                        "limiter": (None if not fracs else ("latency of dependent fetches x rays in flight: no unit above 0.7 (" + ", ".join(f"{k} {v:.2f}" for k, v in sorted(fracs.items())) + ")"
+                                                            if max(fracs.values()) < 0.7 else max(fracs, key=fracs.get))),
                         "solo": {"launches_per_step": solo["n_trace_closest"], "avg_launch_ms": solo_launch_s * 1e3,
                                  "achieved": bytes_step / (solo_ms * 1e-3) / 1e9,
                                  "frac": bytes_step / (solo_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_frame": solo["ms_total"]},

@@ -156,6 +156,7 @@ struct HookHit {  // == pbrhip_hit == TraceResult (raytracer.h:9-17)
 
 void launch_generate(hipStream_t s, const PathState& P, uint32_t npaths);  // clears the radiance of the group's paths (PathState::slot0 ...)
 void launch_trace(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, bool stats);
+bool trace_uses_wide8(const DScene& sc);  // ... the O tree (8-wide; k_trace, k_sss_walk, the phase-voting hooks)
 bool trace_uses_wide(const DScene& sc);  // the traversal kernels walk the 4-wide tree of this scene (now: PBRHIP_WIDE is read per launch)
 void launch_tail(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc, bool stats, bool media, bool textured);
 void launch_classify(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper);

@@ -19,6 +19,7 @@
 #include "dshade.h"
 #include "kernels.h"
 #include "dtrace_pv.h"
+#include "dtrace_pv8.h"
 #include "dtrace_pv2.h"
 #include "dtrace_wp.h"
 #include "dtrace_quad.h"
@@ -235,6 +236,34 @@ __global__ __launch_bounds__(kBlock, trace_blocks_per_cu(CURVES, WIDE) - (FIRST 
   trace_pv<FIRST ? 0 : 2, STATS, CURVES, WIDE>(sc, n_closest + (FIRST ? 0u : n_shadow), &P.counts[kCntHead], sink, stk + threadIdx.x, kBlock,
                              P.spill + blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, st, &overflow,
                              CURVES ? frm + threadIdx.x : nullptr, top, ntop);
+  if (overflow) P.counts[kCntOverflow] = 1u;
+  if (P.wave_log && __lane_id() == 0 && P.wave_log_launch < kWaveLogLaunches) {
+    const uint32_t w = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+    if (w < kWaveLogWaves) {
+      unsigned long long* o = P.wave_log + ((size_t)P.wave_log_launch * kWaveLogWaves + w) * 4;
+      o[0] = t_start, o[1] = wall_clock64(), o[2] = st.it_refill | ((unsigned long long)st.refill_ticks << 32), o[3] = st.it_node + st.it_tri + st.it_curve;
+    }
+  }
+  if (STATS) trace_stats_out(P, st, n_closest, n_shadow);
+}
+
+// The same launch over the O tree (dtrace_pv8.h: eight children per node, 80-byte items, octant-ordered visits, one stack entry
+// per node): triangle-only scenes whose tree was built on the host (DScene::wide8).  PBRHIP_WIDE8=0 selects the Q tree (read per launch).
+#ifndef PB_TRACE_BLOCKS_WIDE8
+#define PB_TRACE_BLOCKS_WIDE8 6
+#endif
+constexpr uint32_t kTraceBlocksPerCUWide8 = PB_TRACE_BLOCKS_WIDE8;
+static_assert(kTraceBlocksPerCUWide8 * 256u <= kTraceGridCap, "the O tree's k_trace grid fits the spill area sized by kTraceGridCap");
+template <bool STATS, bool FIRST = false>
+__global__ __launch_bounds__(kBlock, kTraceBlocksPerCUWide8 - (FIRST ? 1 : 0)) void k_trace8(PathState P, DScene sc) {
+  __shared__ uint2 stk[kPv8LdsStack * kBlock];
+  const uint32_t n_closest = P.counts[kCntIn], n_shadow = P.counts[kCntShadowIn];
+  TravStats st = {};
+  uint32_t overflow = 0u;
+  TraceSinkT<false, FIRST> sink = {P, n_closest};
+  const unsigned long long t_start = P.wave_log ? wall_clock64() : 0ull;
+  trace_pv8<FIRST ? 0 : 2, STATS>(sc, n_closest + (FIRST ? 0u : n_shadow), &P.counts[kCntHead], sink, stk + threadIdx.x, kBlock,
+                                  reinterpret_cast<uint2*>(P.spill) + blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, st, &overflow);
   if (overflow) P.counts[kCntOverflow] = 1u;
   if (P.wave_log && __lane_id() == 0 && P.wave_log_launch < kWaveLogLaunches) {
     const uint32_t w = (blockIdx.x * kBlock + threadIdx.x) >> 6;
@@ -1208,6 +1237,29 @@ __global__ __launch_bounds__(kBlock, PB_WALK_WAVES) void k_sss_walk(PathState P,
   }
 }
 
+// ... and over the O tree (dtrace_pv8.h)
+template <bool STATS>
+__global__ __launch_bounds__(kBlock, PB_WALK_WAVES) void k_sss_walk8(PathState P, DScene sc, uint64_t rng_inc) {
+  __shared__ uint2 stk[kPv8LdsStack * kBlock];
+  __shared__ float walk[kWalkWords * kBlock];
+  const uint32_t n = P.counts[kCntSss];
+  TravStats st = {};
+  uint32_t overflow = 0u;
+  WalkSink sink = {P, rng_inc, walk + threadIdx.x, 0u};
+  trace_pv8<0, STATS>(sc, n, &P.counts[kCntWalkHead], sink, stk + threadIdx.x, kBlock,
+                      reinterpret_cast<uint2*>(P.spill) + blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, st, &overflow);
+  if (overflow) P.counts[kCntOverflow] = 1u;
+  if (STATS) {
+    const uint32_t a = wave_sum(sink.n_rays), nn = wave_sum(st.nodes), nt = wave_sum(st.tris + st.curves);
+    if (__lane_id() == 0 && a) atomicAdd(&P.stats[kStatTailClosestRays], (unsigned long long)a);
+    if (__lane_id() == 0) {
+      atomicAdd(&P.stats[kStatWalkNodes], (unsigned long long)nn), atomicAdd(&P.stats[kStatWalkTris], (unsigned long long)nt);
+      atomicAdd(&P.stats[kStatWalkTurns], (unsigned long long)(st.it_node + st.it_tri + st.it_curve));
+      atomicAdd(&P.stats[kStatWalkSteps], (unsigned long long)st.it_refill);
+    }
+  }
+}
+
 // ------------------------------------------------------------------ k_tail
 // The tail of a chunk -- few live paths, many bounces left -- is bound by latency, not throughput: every wavefront
 // iteration costs ~0.2 ms of launches and drains however few paths it moves (91 iterations on C2, 70 of them with
@@ -1458,6 +1510,17 @@ __global__ __launch_bounds__(kBlock) void k_hook_pv(DScene sc, const float4* __r
                              spill + blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, st, &overflow, CURVES ? frm + threadIdx.x : nullptr);
   if (overflow) counts[kCntOverflow] = 1u;
 }
+template <bool ANY>  // the O tree (dtrace_pv8.h): the variant k_trace8 runs
+__global__ __launch_bounds__(kBlock) void k_hook_pv8(DScene sc, const float4* __restrict__ rays, uint32_t n, HookHit* hits, uint8_t* occ, uint32_t* counts,
+                                                     uint32_t* spill) {
+  __shared__ uint2 stk[kPv8LdsStack * kBlock];
+  TravStats st = {};
+  uint32_t overflow = 0u;
+  HookSink sink = {sc, rays, hits, occ};
+  trace_pv8<ANY ? 1 : 0, false>(sc, n, &counts[kCntHead], sink, stk + threadIdx.x, kBlock, reinterpret_cast<uint2*>(spill) + blockIdx.x * kBlock + threadIdx.x,
+                                gridDim.x * kBlock, st, &overflow);
+  if (overflow) counts[kCntOverflow] = 1u;
+}
 template <bool ANY>
 __global__ __launch_bounds__(kBlock, 2) void k_hook_wp(DScene sc, const float4* __restrict__ rays, uint32_t n, HookHit* hits, uint8_t* occ,
                                                       uint32_t* counts, uint32_t* spill) {
@@ -1547,6 +1610,12 @@ static inline bool use_wide(const DScene& sc) {
     else hipLaunchKernelGGL((KERNEL<PRE, false, false>), __VA_ARGS__);                          \
   } while (0)
 bool trace_uses_wide(const DScene& sc) { return use_wide(sc); }
+// the O tree (8-wide, dtrace_pv8.h) serves k_trace, k_sss_walk and the phase-voting hooks of the triangle-only scenes that have one (PBRHIP_WIDE8=0: never; read per launch)
+static inline bool use_wide8(const DScene& sc) {
+  const char* e = getenv("PBRHIP_WIDE8");
+  return sc.wide8 != nullptr && sc.num_curves == 0 && use_wide(sc) && !(e && atoi(e) == 0);
+}
+bool trace_uses_wide8(const DScene& sc) { return use_wide8(sc); }
 // the two-rays-per-lane traversal (dtrace_pv2.h) serves the Q tree; PBRHIP_TRACE2=0: one ray per lane (read per launch)
 #ifndef PB_TRACE2_DEFAULT
 #define PB_TRACE2_DEFAULT 0
@@ -1623,9 +1692,24 @@ void launch_trace(hipStream_t s, const PathState& P, const DScene& sc, uint32_t 
     if (n_upper <= PB_TRACE_SMALL2_RAYS) cap = std::min(cap, 256u * PB_TRACE_SMALL2_BLOCKS);
     else if (n_upper <= PB_TRACE_SMALL1_RAYS) cap = std::min(cap, 256u * PB_TRACE_SMALL1_BLOCKS);
   }
+  const bool wide8 = use_wide8(sc) && !use_wave_pool() && !use_two_rays(false) && (P.first || n_upper > quad_rays());
+  if (wide8) {
+    // (the resident-block rules of the Q tree's kernel; its launch bounds allow kTraceBlocksPerCUWide8)
+    cap = std::min(cap, 256u * kTraceBlocksPerCUWide8);
+    if (P.first) cap = std::max(cap, 512u) - 256u;
+    const dim3 g8(blocks < 1u ? 1u : (blocks < cap ? blocks : cap));
+    if (P.first) {
+      if (stats) hipLaunchKernelGGL((k_trace8<true, true>), g8, dim3(kBlock), 0, s, P, sc);
+      else hipLaunchKernelGGL((k_trace8<false, true>), g8, dim3(kBlock), 0, s, P, sc);
+    } else {
+      if (stats) hipLaunchKernelGGL((k_trace8<true, false>), g8, dim3(kBlock), 0, s, P, sc);
+      else hipLaunchKernelGGL((k_trace8<false, false>), g8, dim3(kBlock), 0, s, P, sc);
+    }
+    return;
+  }
   if (P.first) {
     // a group's first launch: camera rays only, computed by the sink (TraceSinkT<.., FIRST>); always the phase-voting kernel
-    cap -= 256u;  // (its launch bounds: one block per CU fewer)
+    cap = std::max(cap, 512u) - 256u;  // (its launch bounds: one block per CU fewer; never below one block per CU -- PBRHIP_TRACE_BLOCKS=1 used to make this 0)
     dim3 g(blocks < 1u ? 1u : (blocks < cap ? blocks : cap));
 #define PB_LAUNCH_FIRST(ST)                                                                                      \
   do {                                                                                                           \
@@ -1700,6 +1784,11 @@ void launch_sss_walk(hipStream_t s, const PathState& P, const DScene& sc, uint32
   const bool curves = sc.num_curves != 0;
   const char* ww = getenv("PBRHIP_WIDE_WALK");
   const bool wide = use_wide(sc) && !(ww && atoi(ww) == 0);
+  if (wide && use_wide8(sc)) {
+    if (stats) hipLaunchKernelGGL((k_sss_walk8<true>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
+    else hipLaunchKernelGGL((k_sss_walk8<false>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
+    return;
+  }
   if (stats) PB_LAUNCH_TRAV(k_sss_walk, true, curves, wide, g, dim3(kBlock), 0, s, P, sc, rng_inc);
   else PB_LAUNCH_TRAV(k_sss_walk, false, curves, wide, g, dim3(kBlock), 0, s, P, sc, rng_inc);
 }
@@ -1757,6 +1846,10 @@ void launch_hook_closest(hipStream_t s, const DScene& sc, const float4* rays, ui
     return;
   }
   const dim3 g(grid_for(n, kTraceGridCap));
+  if (use_wide8(sc)) {
+    hipLaunchKernelGGL((k_hook_pv8<false>), g, dim3(kBlock), 0, s, sc, rays, n, out, (uint8_t*)nullptr, counts, spill);
+    return;
+  }
   if (wide && curves) hipLaunchKernelGGL((k_hook_pv<false, true, true>), g, dim3(kBlock), 0, s, sc, rays, n, out, (uint8_t*)nullptr, counts, spill);
   else if (wide) hipLaunchKernelGGL((k_hook_pv<false, false, true>), g, dim3(kBlock), 0, s, sc, rays, n, out, (uint8_t*)nullptr, counts, spill);
   else hipLaunchKernelGGL((k_hook_pv<false, true, false>), g, dim3(kBlock), 0, s, sc, rays, n, out, (uint8_t*)nullptr, counts, spill);
@@ -1780,6 +1873,10 @@ void launch_hook_any(hipStream_t s, const DScene& sc, const float4* rays, uint32
     return;
   }
   const dim3 g(grid_for(n, kTraceGridCap));
+  if (use_wide8(sc)) {
+    hipLaunchKernelGGL((k_hook_pv8<true>), g, dim3(kBlock), 0, s, sc, rays, n, (HookHit*)nullptr, out, counts, spill);
+    return;
+  }
   if (wide && curves) hipLaunchKernelGGL((k_hook_pv<true, true, true>), g, dim3(kBlock), 0, s, sc, rays, n, (HookHit*)nullptr, out, counts, spill);
   else if (wide) hipLaunchKernelGGL((k_hook_pv<true, false, true>), g, dim3(kBlock), 0, s, sc, rays, n, (HookHit*)nullptr, out, counts, spill);
   else hipLaunchKernelGGL((k_hook_pv<true, true, false>), g, dim3(kBlock), 0, s, sc, rays, n, (HookHit*)nullptr, out, counts, spill);

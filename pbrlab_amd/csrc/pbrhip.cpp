@@ -657,7 +657,7 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
   // children per node with quantised boxes (64 B per node), followed by its own compact triangle slots and by the curve
   // pieces stored as chains of points (16 B per piece instead of a 64-byte slot): dscene.h::QNode.
   std::vector<QNode> wide;
-  std::vector<float4> qtri, qpts;
+  std::vector<float4> qtri, qpts, wide8;
   std::vector<uint32_t> qhit;
   const char* wide_env = getenv("PBRHIP_WIDE");
   static_assert(kMaxLeaf <= 2, "build_qtree expects at most two primitives per leaf of the binary tree");
@@ -699,6 +699,17 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
     // and meet triangles rarely): 48 bytes per triangle -- three corners, the hit code in the third word's .w -- one after the other.
     bool tri_pairs = true;
     for (uint8_t kd : kinds) tri_pairs = tri_pairs && kd == 0;
+    // the five words of the TriPair of a triangle leaf (slots first .. first + count - 1 of the binary tree)
+    auto pair_words = [&](uint32_t first, uint32_t count, float4* o) {
+      const float4* a = &slots[4 * (size_t)first];
+      const float4* b = count == 2 ? &slots[4 * (size_t)(first + 1)] : a;  // (one triangle: stored twice, the copy is no candidate)
+      const float ca = __builtin_bit_cast(float, slot_code[first]), cb = __builtin_bit_cast(float, count == 2 ? slot_code[first + 1] : kNone);
+      o[0] = make_float4(a[0].x, b[0].x, a[0].y, b[0].y);
+      o[1] = make_float4(a[0].z, b[0].z, a[1].x, b[1].x);
+      o[2] = make_float4(a[1].y, b[1].y, a[1].z, b[1].z);
+      o[3] = make_float4(a[2].x, b[2].x, a[2].y, b[2].y);
+      o[4] = make_float4(a[2].z, b[2].z, ca, cb);
+    };
     auto tri_pair = [&](uint32_t first, uint32_t count) -> uint32_t {
       if (!tri_pairs) {
         const uint32_t rec = (uint32_t)(qtri.size() / 3);
@@ -709,14 +720,8 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
         return rec;
       }
       const uint32_t rec = (uint32_t)(qtri.size() / kTriPairWords);
-      const float4* a = &slots[4 * (size_t)first];
-      const float4* b = count == 2 ? &slots[4 * (size_t)(first + 1)] : a;  // (one triangle: stored twice, the copy is no candidate)
-      const float ca = __builtin_bit_cast(float, slot_code[first]), cb = __builtin_bit_cast(float, count == 2 ? slot_code[first + 1] : kNone);
-      qtri.push_back(make_float4(a[0].x, b[0].x, a[0].y, b[0].y));
-      qtri.push_back(make_float4(a[0].z, b[0].z, a[1].x, b[1].x));
-      qtri.push_back(make_float4(a[1].y, b[1].y, a[1].z, b[1].z));
-      qtri.push_back(make_float4(a[2].x, b[2].x, a[2].y, b[2].y));
-      qtri.push_back(make_float4(a[2].z, b[2].z, ca, cb));
+      qtri.resize(qtri.size() + kTriPairWords);
+      pair_words(first, count, &qtri[(size_t)rec * kTriPairWords]);
       return rec;
     };
     auto map_leaf = [&](uint32_t ref, const float* blo, const float* bhi, QChild* o) -> int {
@@ -744,6 +749,16 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
       return 1;
     };
     if (qpts.size() >= (1u << 27) || build_qtree(bvh.nodes, map_leaf, &wide) > (uint32_t)kStackDepth) wide.clear();
+    // The O tree of a triangle-only scene (dscene.h::Node8; dtrace_pv8.h): eight children per node, nodes and TriPairs as 80-byte
+    // items of one array.  PBRHIP_WIDE8=0 at commit: none.  PBRHIP_Q8_COST="node,leaf": the collapse's prices (tuning).
+    const char* w8 = getenv("PBRHIP_WIDE8");
+    if (!wide.empty() && tri_pairs && !(w8 && atoi(w8) == 0)) {
+      double cn = 1.0, cl = 1.0;
+      if (const char* e = getenv("PBRHIP_Q8_COST")) sscanf(e, "%lf,%lf", &cn, &cl);
+      auto leaf_item = [&](uint32_t ref, float4* o) { pair_words((ref & 0x3FFFFFFFu) >> 3, (ref & 7u) + 1u, o); };
+      const uint32_t depth8 = build_q8tree(bvh.nodes, leaf_item, &wide8, cn, cl);
+      if (depth8 == 0 || depth8 > 32u) wide8.clear();  // (kStackDepth8 of dtrace_pv8.h: one stack entry per level)
+    }
   }
   if (wide.empty()) s->d_wide.release(), s->d_qhit.release();
   if (getenv("PBRHIP_DEBUG")) fprintf(stderr, "pbrhip: commit: %u binary nodes, %zu wide nodes, %zu slots, %zu triangle leaves + %zu points in the Q tree\n", num_nodes, wide.size(), (size_t)ns, qtri.size() / kTriPairWords, qpts.size());
@@ -753,6 +768,23 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
     if (!qtri.empty()) HIPCHK(hipMemcpyAsync(s->d_wide.p + wide.size() * 4, qtri.data(), qtri.size() * 16, hipMemcpyHostToDevice, st));
     if (!qpts.empty()) HIPCHK(hipMemcpyAsync(s->d_wide.p + wide.size() * 4 + qtri.size(), qpts.data(), qpts.size() * 16, hipMemcpyHostToDevice, st));
     HIPCHK(s->d_qhit.upload(qhit, st));
+  }
+  if (wide8.empty()) s->d_wide8.release();
+  else HIPCHK(s->d_wide8.upload(wide8, st));
+  if (getenv("PBRHIP_DEBUG") && !wide8.empty()) {
+    size_t nodes8 = 0, kids8 = 0;
+    std::vector<uint32_t> todo{0u};
+    while (!todo.empty()) {
+      const uint32_t id = todo.back();
+      todo.pop_back();
+      Node8 nd;
+      memcpy(&nd, &wide8[(size_t)id * kNode8Words], sizeof(nd));
+      const uint32_t im = nd.masks & 255u, pr = (nd.masks | (nd.masks >> 8)) & 255u;
+      nodes8++, kids8 += (size_t)__builtin_popcount(pr);
+      for (int k = 0; k < 8; k++)
+        if ((im >> k) & 1u) todo.push_back(nd.base + (uint32_t)__builtin_popcount(pr & ((1u << k) - 1u)));
+    }
+    fprintf(stderr, "pbrhip: commit: O tree: %zu items (%zu nodes, %.2f children per node)\n", wide8.size() / kNode8Words, nodes8, (double)kids8 / (double)std::max<size_t>(nodes8, 1));
   }
   HIPCHK(s->d_shade.upload(shade, st));
   HIPCHK(s->d_materials.upload(mats, st));
@@ -786,6 +818,7 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
   for (uint8_t kd : kinds) d.num_curves += kd ? 1u : 0u;
   d.wide = wide.empty() ? nullptr : s->d_wide.p, d.wide_nodes = (uint32_t)wide.size();
   d.q_tri0 = (uint32_t)wide.size() * 4u, d.q_pt0 = d.q_tri0 + (uint32_t)qtri.size(), d.q_hitcode = wide.empty() ? nullptr : s->d_qhit.p;
+  d.wide8 = wide8.empty() ? nullptr : s->d_wide8.p, d.wide8_items = (uint32_t)(wide8.size() / kNode8Words);
   d.top_nodes = gpu_built ? 0u : std::min<uint32_t>(num_nodes, (uint32_t)kTopNodes);
   d.wide_top_nodes = std::min<uint32_t>((uint32_t)wide.size(), (uint32_t)kTopNodes);
   // light sampling works on the meshes' local positions (light-manager.h:128-136 "TODO transform"), the raytracer on the
@@ -1239,6 +1272,7 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
             HIPCHK(gr.tm.begin(&S.ms_surface));
             launch_classify(gst, gr.P, sc, n);
             HIPCHK(gr.tm.end());
+            S.n_surface++;
           }
           HIPCHK(gr.tm.begin(&S.ms_shade_principled));
           launch_shade_principled(gst, gr.P, sc, n, rng_inc, s->has_sss, s->has_textured);
@@ -1259,7 +1293,7 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
           HIPCHK(gr.tm.begin(&S.ms_compact));
           launch_compact(gst, gr.P, n);
           HIPCHK(gr.tm.end());
-          S.n_trace_closest++, S.n_surface++, S.n_shade_principled++;
+          S.n_trace_closest++, S.n_shade_principled++;
           launch_advance(gst, gr.P);
           std::swap(gr.P.q_in, gr.P.q_out);
           std::swap(gr.P.q_shadow, gr.P.q_shadow_in);
@@ -1393,7 +1427,7 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
     publish(done);
   }
   S.passes_done = done;
-  S.node_bytes = trace_uses_wide(s->dscene) ? sizeof(QNode) : sizeof(BvhNode);
+  S.node_bytes = trace_uses_wide8(s->dscene) ? sizeof(Node8) : (trace_uses_wide(s->dscene) ? sizeof(QNode) : sizeof(BvhNode));
   S.curve_bytes = trace_uses_wide(s->dscene) ? 32 : 64;
   S.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   if (stats) *stats = S;

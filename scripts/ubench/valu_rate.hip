@@ -1,0 +1,714 @@
+// Micro-benchmark (round 5): what ONE wave64 VALU instruction costs on gfx950, per instruction class, and what the SQ counters say
+// about a kernel that is known to be VALU-bound.  VERDICT round 4: bench.py priced every VALU instruction at 4 cycles; the
+// guide says a wave64 v_fma_f32 issues over 2 cycles on a SIMD-32.  This program prints cycles per wave-instruction and SIMD
+// (events, nominal 2.4 GHz AND -- when run under rocprofv3 --pmc GRBM_GUI_ACTIVE -- per measured cycle) for
+//   fma     : independent v_fma_f32 chains (8 per lane)
+//   pk_fma  : independent v_pk_fma_f32 chains (what the slab tests of k_trace are made of)
+//   pk_mul / pk_add : v_pk_mul_f32, v_pk_add_f32;  min : v_min_f32 (gfx950 has no packed fp32 min / max: the f2 min / max of the slab tests are two scalar instructions each);  mullo : v_mul_lo_u32 (the generator)
+//   cvt     : v_cvt_f32_ubyte0..3 (the dequantisation of a Q node)
+//   rcp     : v_rcp_f32 (quarter rate on earlier parts)
+//   mix     : the instruction mix of one Q-node slab test (cvt, pk_fma, pk_add, pk_mul, pk_min / pk_max, fma)
+// each at 8 waves per SIMD (blocks = 256 CUs x 8, 256 threads) so that issue, not latency, is what is timed; and asserts that
+// the plain fma costs 2 +- 0.6 cycles.  Kernel names are distinct so that a PMC pass lists them separately:
+//   SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, SQ_INST_CYCLES_VALU, SQ_BUSY_CU_CYCLES, SQ_WAVE_CYCLES, GRBM_GUI_ACTIVE
+// calibrate the counter ratio bench.py reports as roofline.valu.frac (a VALU-bound kernel must read ~1).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef float f2 __attribute__((ext_vector_type(2)));
+#define ITERS 1500
+#define UNROLL 8
+
+__global__ __launch_bounds__(256) void u_fma(float* out) {
+  float a[8];
+  float b = 0.999f + threadIdx.x * 1e-9f, c = 1e-3f;
+#pragma unroll
+  for (int k = 0; k < 8; k++) a[k] = 1.0f + threadIdx.x * 1e-6f + k;
+#pragma unroll 1
+  for (int i = 0; i < ITERS; ++i) {
+    asm volatile("v_fma_f32 %0, %0, %8, %9\n"
+                   "v_fma_f32 %1, %1, %8, %9\n"
+                   "v_fma_f32 %2, %2, %8, %9\n"
+                   "v_fma_f32 %3, %3, %8, %9\n"
+                   "v_fma_f32 %4, %4, %8, %9\n"
+                   "v_fma_f32 %5, %5, %8, %9\n"
+                   "v_fma_f32 %6, %6, %8, %9\n"
+                   "v_fma_f32 %7, %7, %8, %9\n"
+                   "v_fma_f32 %0, %0, %8, %9\n"
+                   "v_fma_f32 %1, %1, %8, %9\n"
+                   "v_fma_f32 %2, %2, %8, %9\n"
+                   "v_fma_f32 %3, %3, %8, %9\n"
+                   "v_fma_f32 %4, %4, %8, %9\n"
+                   "v_fma_f32 %5, %5, %8, %9\n"
+                   "v_fma_f32 %6, %6, %8, %9\n"
+                   "v_fma_f32 %7, %7, %8, %9\n"
+                   "v_fma_f32 %0, %0, %8, %9\n"
+                   "v_fma_f32 %1, %1, %8, %9\n"
+                   "v_fma_f32 %2, %2, %8, %9\n"
+                   "v_fma_f32 %3, %3, %8, %9\n"
+                   "v_fma_f32 %4, %4, %8, %9\n"
+                   "v_fma_f32 %5, %5, %8, %9\n"
+                   "v_fma_f32 %6, %6, %8, %9\n"
+                   "v_fma_f32 %7, %7, %8, %9\n"
+                   "v_fma_f32 %0, %0, %8, %9\n"
+                   "v_fma_f32 %1, %1, %8, %9\n"
+                   "v_fma_f32 %2, %2, %8, %9\n"
+                   "v_fma_f32 %3, %3, %8, %9\n"
+                   "v_fma_f32 %4, %4, %8, %9\n"
+                   "v_fma_f32 %5, %5, %8, %9\n"
+                   "v_fma_f32 %6, %6, %8, %9\n"
+                   "v_fma_f32 %7, %7, %8, %9\n"
+                   "v_fma_f32 %0, %0, %8, %9\n"
+                   "v_fma_f32 %1, %1, %8, %9\n"
+                   "v_fma_f32 %2, %2, %8, %9\n"
+                   "v_fma_f32 %3, %3, %8, %9\n"
+                   "v_fma_f32 %4, %4, %8, %9\n"
+                   "v_fma_f32 %5, %5, %8, %9\n"
+                   "v_fma_f32 %6, %6, %8, %9\n"
+                   "v_fma_f32 %7, %7, %8, %9\n"
+                   "v_fma_f32 %0, %0, %8, %9\n"
+                   "v_fma_f32 %1, %1, %8, %9\n"
+                   "v_fma_f32 %2, %2, %8, %9\n"
+                   "v_fma_f32 %3, %3, %8, %9\n"
+                   "v_fma_f32 %4, %4, %8, %9\n"
+                   "v_fma_f32 %5, %5, %8, %9\n"
+                   "v_fma_f32 %6, %6, %8, %9\n"
+                   "v_fma_f32 %7, %7, %8, %9\n"
+                   "v_fma_f32 %0, %0, %8, %9\n"
+                   "v_fma_f32 %1, %1, %8, %9\n"
+                   "v_fma_f32 %2, %2, %8, %9\n"
+                   "v_fma_f32 %3, %3, %8, %9\n"
+                   "v_fma_f32 %4, %4, %8, %9\n"
+                   "v_fma_f32 %5, %5, %8, %9\n"
+                   "v_fma_f32 %6, %6, %8, %9\n"
+                   "v_fma_f32 %7, %7, %8, %9\n"
+                   "v_fma_f32 %0, %0, %8, %9\n"
+                   "v_fma_f32 %1, %1, %8, %9\n"
+                   "v_fma_f32 %2, %2, %8, %9\n"
+                   "v_fma_f32 %3, %3, %8, %9\n"
+                   "v_fma_f32 %4, %4, %8, %9\n"
+                   "v_fma_f32 %5, %5, %8, %9\n"
+                   "v_fma_f32 %6, %6, %8, %9\n"
+                   "v_fma_f32 %7, %7, %8, %9\n"
+                   : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(b), "v"(c));
+  }
+  float s = 0;
+  for (int k = 0; k < 8; k++) s += a[k];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void u_pk_fma(float* out) {
+  f2 a[8];
+  f2 b = {0.999f + threadIdx.x * 1e-9f, 0.998f}, c = {1e-3f, 2e-3f};
+#pragma unroll
+  for (int k = 0; k < 8; k++) a[k] = f2{1.0f + threadIdx.x * 1e-6f + k, 2.0f + k};
+#pragma unroll 1
+  for (int i = 0; i < ITERS; ++i) {
+    asm volatile("v_pk_fma_f32 %0, %0, %8, %9\n"
+                   "v_pk_fma_f32 %1, %1, %8, %9\n"
+                   "v_pk_fma_f32 %2, %2, %8, %9\n"
+                   "v_pk_fma_f32 %3, %3, %8, %9\n"
+                   "v_pk_fma_f32 %4, %4, %8, %9\n"
+                   "v_pk_fma_f32 %5, %5, %8, %9\n"
+                   "v_pk_fma_f32 %6, %6, %8, %9\n"
+                   "v_pk_fma_f32 %7, %7, %8, %9\n"
+                   "v_pk_fma_f32 %0, %0, %8, %9\n"
+                   "v_pk_fma_f32 %1, %1, %8, %9\n"
+                   "v_pk_fma_f32 %2, %2, %8, %9\n"
+                   "v_pk_fma_f32 %3, %3, %8, %9\n"
+                   "v_pk_fma_f32 %4, %4, %8, %9\n"
+                   "v_pk_fma_f32 %5, %5, %8, %9\n"
+                   "v_pk_fma_f32 %6, %6, %8, %9\n"
+                   "v_pk_fma_f32 %7, %7, %8, %9\n"
+                   "v_pk_fma_f32 %0, %0, %8, %9\n"
+                   "v_pk_fma_f32 %1, %1, %8, %9\n"
+                   "v_pk_fma_f32 %2, %2, %8, %9\n"
+                   "v_pk_fma_f32 %3, %3, %8, %9\n"
+                   "v_pk_fma_f32 %4, %4, %8, %9\n"
+                   "v_pk_fma_f32 %5, %5, %8, %9\n"
+                   "v_pk_fma_f32 %6, %6, %8, %9\n"
+                   "v_pk_fma_f32 %7, %7, %8, %9\n"
+                   "v_pk_fma_f32 %0, %0, %8, %9\n"
+                   "v_pk_fma_f32 %1, %1, %8, %9\n"
+                   "v_pk_fma_f32 %2, %2, %8, %9\n"
+                   "v_pk_fma_f32 %3, %3, %8, %9\n"
+                   "v_pk_fma_f32 %4, %4, %8, %9\n"
+                   "v_pk_fma_f32 %5, %5, %8, %9\n"
+                   "v_pk_fma_f32 %6, %6, %8, %9\n"
+                   "v_pk_fma_f32 %7, %7, %8, %9\n"
+                   "v_pk_fma_f32 %0, %0, %8, %9\n"
+                   "v_pk_fma_f32 %1, %1, %8, %9\n"
+                   "v_pk_fma_f32 %2, %2, %8, %9\n"
+                   "v_pk_fma_f32 %3, %3, %8, %9\n"
+                   "v_pk_fma_f32 %4, %4, %8, %9\n"
+                   "v_pk_fma_f32 %5, %5, %8, %9\n"
+                   "v_pk_fma_f32 %6, %6, %8, %9\n"
+                   "v_pk_fma_f32 %7, %7, %8, %9\n"
+                   "v_pk_fma_f32 %0, %0, %8, %9\n"
+                   "v_pk_fma_f32 %1, %1, %8, %9\n"
+                   "v_pk_fma_f32 %2, %2, %8, %9\n"
+                   "v_pk_fma_f32 %3, %3, %8, %9\n"
+                   "v_pk_fma_f32 %4, %4, %8, %9\n"
+                   "v_pk_fma_f32 %5, %5, %8, %9\n"
+                   "v_pk_fma_f32 %6, %6, %8, %9\n"
+                   "v_pk_fma_f32 %7, %7, %8, %9\n"
+                   "v_pk_fma_f32 %0, %0, %8, %9\n"
+                   "v_pk_fma_f32 %1, %1, %8, %9\n"
+                   "v_pk_fma_f32 %2, %2, %8, %9\n"
+                   "v_pk_fma_f32 %3, %3, %8, %9\n"
+                   "v_pk_fma_f32 %4, %4, %8, %9\n"
+                   "v_pk_fma_f32 %5, %5, %8, %9\n"
+                   "v_pk_fma_f32 %6, %6, %8, %9\n"
+                   "v_pk_fma_f32 %7, %7, %8, %9\n"
+                   "v_pk_fma_f32 %0, %0, %8, %9\n"
+                   "v_pk_fma_f32 %1, %1, %8, %9\n"
+                   "v_pk_fma_f32 %2, %2, %8, %9\n"
+                   "v_pk_fma_f32 %3, %3, %8, %9\n"
+                   "v_pk_fma_f32 %4, %4, %8, %9\n"
+                   "v_pk_fma_f32 %5, %5, %8, %9\n"
+                   "v_pk_fma_f32 %6, %6, %8, %9\n"
+                   "v_pk_fma_f32 %7, %7, %8, %9\n"
+                   : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(b), "v"(c));
+  }
+  float s = 0;
+  for (int k = 0; k < 8; k++) s += a[k].x + a[k].y;
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void u_pk_mul(float* out) {
+  f2 a[8];
+  f2 b = {0.9999f + threadIdx.x * 1e-9f, 1.0001f};
+#pragma unroll
+  for (int k = 0; k < 8; k++) a[k] = f2{1.0f + threadIdx.x * 1e-6f + k, 2.0f + k};
+#pragma unroll 1
+  for (int i = 0; i < ITERS; ++i) {
+    asm volatile("v_pk_mul_f32 %0, %0, %8\n"
+                   "v_pk_mul_f32 %1, %1, %8\n"
+                   "v_pk_mul_f32 %2, %2, %8\n"
+                   "v_pk_mul_f32 %3, %3, %8\n"
+                   "v_pk_mul_f32 %4, %4, %8\n"
+                   "v_pk_mul_f32 %5, %5, %8\n"
+                   "v_pk_mul_f32 %6, %6, %8\n"
+                   "v_pk_mul_f32 %7, %7, %8\n"
+                   "v_pk_mul_f32 %0, %0, %8\n"
+                   "v_pk_mul_f32 %1, %1, %8\n"
+                   "v_pk_mul_f32 %2, %2, %8\n"
+                   "v_pk_mul_f32 %3, %3, %8\n"
+                   "v_pk_mul_f32 %4, %4, %8\n"
+                   "v_pk_mul_f32 %5, %5, %8\n"
+                   "v_pk_mul_f32 %6, %6, %8\n"
+                   "v_pk_mul_f32 %7, %7, %8\n"
+                   "v_pk_mul_f32 %0, %0, %8\n"
+                   "v_pk_mul_f32 %1, %1, %8\n"
+                   "v_pk_mul_f32 %2, %2, %8\n"
+                   "v_pk_mul_f32 %3, %3, %8\n"
+                   "v_pk_mul_f32 %4, %4, %8\n"
+                   "v_pk_mul_f32 %5, %5, %8\n"
+                   "v_pk_mul_f32 %6, %6, %8\n"
+                   "v_pk_mul_f32 %7, %7, %8\n"
+                   "v_pk_mul_f32 %0, %0, %8\n"
+                   "v_pk_mul_f32 %1, %1, %8\n"
+                   "v_pk_mul_f32 %2, %2, %8\n"
+                   "v_pk_mul_f32 %3, %3, %8\n"
+                   "v_pk_mul_f32 %4, %4, %8\n"
+                   "v_pk_mul_f32 %5, %5, %8\n"
+                   "v_pk_mul_f32 %6, %6, %8\n"
+                   "v_pk_mul_f32 %7, %7, %8\n"
+                   "v_pk_mul_f32 %0, %0, %8\n"
+                   "v_pk_mul_f32 %1, %1, %8\n"
+                   "v_pk_mul_f32 %2, %2, %8\n"
+                   "v_pk_mul_f32 %3, %3, %8\n"
+                   "v_pk_mul_f32 %4, %4, %8\n"
+                   "v_pk_mul_f32 %5, %5, %8\n"
+                   "v_pk_mul_f32 %6, %6, %8\n"
+                   "v_pk_mul_f32 %7, %7, %8\n"
+                   "v_pk_mul_f32 %0, %0, %8\n"
+                   "v_pk_mul_f32 %1, %1, %8\n"
+                   "v_pk_mul_f32 %2, %2, %8\n"
+                   "v_pk_mul_f32 %3, %3, %8\n"
+                   "v_pk_mul_f32 %4, %4, %8\n"
+                   "v_pk_mul_f32 %5, %5, %8\n"
+                   "v_pk_mul_f32 %6, %6, %8\n"
+                   "v_pk_mul_f32 %7, %7, %8\n"
+                   "v_pk_mul_f32 %0, %0, %8\n"
+                   "v_pk_mul_f32 %1, %1, %8\n"
+                   "v_pk_mul_f32 %2, %2, %8\n"
+                   "v_pk_mul_f32 %3, %3, %8\n"
+                   "v_pk_mul_f32 %4, %4, %8\n"
+                   "v_pk_mul_f32 %5, %5, %8\n"
+                   "v_pk_mul_f32 %6, %6, %8\n"
+                   "v_pk_mul_f32 %7, %7, %8\n"
+                   "v_pk_mul_f32 %0, %0, %8\n"
+                   "v_pk_mul_f32 %1, %1, %8\n"
+                   "v_pk_mul_f32 %2, %2, %8\n"
+                   "v_pk_mul_f32 %3, %3, %8\n"
+                   "v_pk_mul_f32 %4, %4, %8\n"
+                   "v_pk_mul_f32 %5, %5, %8\n"
+                   "v_pk_mul_f32 %6, %6, %8\n"
+                   "v_pk_mul_f32 %7, %7, %8\n"
+                   : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(b));
+  }
+  float s = 0;
+  for (int k = 0; k < 8; k++) s += a[k].x + a[k].y;
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void u_pk_add(float* out) {
+  f2 a[8];
+  f2 b = {1e-7f + threadIdx.x * 1e-9f, 1e-6f};
+#pragma unroll
+  for (int k = 0; k < 8; k++) a[k] = f2{1.0f + threadIdx.x * 1e-6f + k, 2.0f + k};
+#pragma unroll 1
+  for (int i = 0; i < ITERS; ++i) {
+    asm volatile("v_pk_add_f32 %0, %0, %8\n"
+                   "v_pk_add_f32 %1, %1, %8\n"
+                   "v_pk_add_f32 %2, %2, %8\n"
+                   "v_pk_add_f32 %3, %3, %8\n"
+                   "v_pk_add_f32 %4, %4, %8\n"
+                   "v_pk_add_f32 %5, %5, %8\n"
+                   "v_pk_add_f32 %6, %6, %8\n"
+                   "v_pk_add_f32 %7, %7, %8\n"
+                   "v_pk_add_f32 %0, %0, %8\n"
+                   "v_pk_add_f32 %1, %1, %8\n"
+                   "v_pk_add_f32 %2, %2, %8\n"
+                   "v_pk_add_f32 %3, %3, %8\n"
+                   "v_pk_add_f32 %4, %4, %8\n"
+                   "v_pk_add_f32 %5, %5, %8\n"
+                   "v_pk_add_f32 %6, %6, %8\n"
+                   "v_pk_add_f32 %7, %7, %8\n"
+                   "v_pk_add_f32 %0, %0, %8\n"
+                   "v_pk_add_f32 %1, %1, %8\n"
+                   "v_pk_add_f32 %2, %2, %8\n"
+                   "v_pk_add_f32 %3, %3, %8\n"
+                   "v_pk_add_f32 %4, %4, %8\n"
+                   "v_pk_add_f32 %5, %5, %8\n"
+                   "v_pk_add_f32 %6, %6, %8\n"
+                   "v_pk_add_f32 %7, %7, %8\n"
+                   "v_pk_add_f32 %0, %0, %8\n"
+                   "v_pk_add_f32 %1, %1, %8\n"
+                   "v_pk_add_f32 %2, %2, %8\n"
+                   "v_pk_add_f32 %3, %3, %8\n"
+                   "v_pk_add_f32 %4, %4, %8\n"
+                   "v_pk_add_f32 %5, %5, %8\n"
+                   "v_pk_add_f32 %6, %6, %8\n"
+                   "v_pk_add_f32 %7, %7, %8\n"
+                   "v_pk_add_f32 %0, %0, %8\n"
+                   "v_pk_add_f32 %1, %1, %8\n"
+                   "v_pk_add_f32 %2, %2, %8\n"
+                   "v_pk_add_f32 %3, %3, %8\n"
+                   "v_pk_add_f32 %4, %4, %8\n"
+                   "v_pk_add_f32 %5, %5, %8\n"
+                   "v_pk_add_f32 %6, %6, %8\n"
+                   "v_pk_add_f32 %7, %7, %8\n"
+                   "v_pk_add_f32 %0, %0, %8\n"
+                   "v_pk_add_f32 %1, %1, %8\n"
+                   "v_pk_add_f32 %2, %2, %8\n"
+                   "v_pk_add_f32 %3, %3, %8\n"
+                   "v_pk_add_f32 %4, %4, %8\n"
+                   "v_pk_add_f32 %5, %5, %8\n"
+                   "v_pk_add_f32 %6, %6, %8\n"
+                   "v_pk_add_f32 %7, %7, %8\n"
+                   "v_pk_add_f32 %0, %0, %8\n"
+                   "v_pk_add_f32 %1, %1, %8\n"
+                   "v_pk_add_f32 %2, %2, %8\n"
+                   "v_pk_add_f32 %3, %3, %8\n"
+                   "v_pk_add_f32 %4, %4, %8\n"
+                   "v_pk_add_f32 %5, %5, %8\n"
+                   "v_pk_add_f32 %6, %6, %8\n"
+                   "v_pk_add_f32 %7, %7, %8\n"
+                   "v_pk_add_f32 %0, %0, %8\n"
+                   "v_pk_add_f32 %1, %1, %8\n"
+                   "v_pk_add_f32 %2, %2, %8\n"
+                   "v_pk_add_f32 %3, %3, %8\n"
+                   "v_pk_add_f32 %4, %4, %8\n"
+                   "v_pk_add_f32 %5, %5, %8\n"
+                   "v_pk_add_f32 %6, %6, %8\n"
+                   "v_pk_add_f32 %7, %7, %8\n"
+                   : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(b));
+  }
+  float s = 0;
+  for (int k = 0; k < 8; k++) s += a[k].x + a[k].y;
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void u_min(float* out) {
+  float a[8];
+  float b = 0.5f + threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < 8; k++) a[k] = 1.0f + threadIdx.x * 1e-6f + k;
+#pragma unroll 1
+  for (int i = 0; i < ITERS; ++i) {
+    asm volatile("v_min_f32 %0, %0, %8\n"
+                   "v_min_f32 %1, %1, %8\n"
+                   "v_min_f32 %2, %2, %8\n"
+                   "v_min_f32 %3, %3, %8\n"
+                   "v_min_f32 %4, %4, %8\n"
+                   "v_min_f32 %5, %5, %8\n"
+                   "v_min_f32 %6, %6, %8\n"
+                   "v_min_f32 %7, %7, %8\n"
+                   "v_min_f32 %0, %0, %8\n"
+                   "v_min_f32 %1, %1, %8\n"
+                   "v_min_f32 %2, %2, %8\n"
+                   "v_min_f32 %3, %3, %8\n"
+                   "v_min_f32 %4, %4, %8\n"
+                   "v_min_f32 %5, %5, %8\n"
+                   "v_min_f32 %6, %6, %8\n"
+                   "v_min_f32 %7, %7, %8\n"
+                   "v_min_f32 %0, %0, %8\n"
+                   "v_min_f32 %1, %1, %8\n"
+                   "v_min_f32 %2, %2, %8\n"
+                   "v_min_f32 %3, %3, %8\n"
+                   "v_min_f32 %4, %4, %8\n"
+                   "v_min_f32 %5, %5, %8\n"
+                   "v_min_f32 %6, %6, %8\n"
+                   "v_min_f32 %7, %7, %8\n"
+                   "v_min_f32 %0, %0, %8\n"
+                   "v_min_f32 %1, %1, %8\n"
+                   "v_min_f32 %2, %2, %8\n"
+                   "v_min_f32 %3, %3, %8\n"
+                   "v_min_f32 %4, %4, %8\n"
+                   "v_min_f32 %5, %5, %8\n"
+                   "v_min_f32 %6, %6, %8\n"
+                   "v_min_f32 %7, %7, %8\n"
+                   "v_min_f32 %0, %0, %8\n"
+                   "v_min_f32 %1, %1, %8\n"
+                   "v_min_f32 %2, %2, %8\n"
+                   "v_min_f32 %3, %3, %8\n"
+                   "v_min_f32 %4, %4, %8\n"
+                   "v_min_f32 %5, %5, %8\n"
+                   "v_min_f32 %6, %6, %8\n"
+                   "v_min_f32 %7, %7, %8\n"
+                   "v_min_f32 %0, %0, %8\n"
+                   "v_min_f32 %1, %1, %8\n"
+                   "v_min_f32 %2, %2, %8\n"
+                   "v_min_f32 %3, %3, %8\n"
+                   "v_min_f32 %4, %4, %8\n"
+                   "v_min_f32 %5, %5, %8\n"
+                   "v_min_f32 %6, %6, %8\n"
+                   "v_min_f32 %7, %7, %8\n"
+                   "v_min_f32 %0, %0, %8\n"
+                   "v_min_f32 %1, %1, %8\n"
+                   "v_min_f32 %2, %2, %8\n"
+                   "v_min_f32 %3, %3, %8\n"
+                   "v_min_f32 %4, %4, %8\n"
+                   "v_min_f32 %5, %5, %8\n"
+                   "v_min_f32 %6, %6, %8\n"
+                   "v_min_f32 %7, %7, %8\n"
+                   "v_min_f32 %0, %0, %8\n"
+                   "v_min_f32 %1, %1, %8\n"
+                   "v_min_f32 %2, %2, %8\n"
+                   "v_min_f32 %3, %3, %8\n"
+                   "v_min_f32 %4, %4, %8\n"
+                   "v_min_f32 %5, %5, %8\n"
+                   "v_min_f32 %6, %6, %8\n"
+                   "v_min_f32 %7, %7, %8\n"
+                   : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(b));
+  }
+  float s = 0;
+  for (int k = 0; k < 8; k++) s += a[k];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void u_cvt(float* out, unsigned seed) {
+  float a[8];
+  unsigned w = seed * (threadIdx.x + 1u);
+#pragma unroll
+  for (int k = 0; k < 8; k++) a[k] = 1.0f + threadIdx.x * 1e-6f + k;
+#pragma unroll 1
+  for (int i = 0; i < ITERS; ++i) {
+    asm volatile("v_cvt_f32_ubyte0 %0, %8\n"
+                   "v_cvt_f32_ubyte1 %1, %8\n"
+                   "v_cvt_f32_ubyte2 %2, %8\n"
+                   "v_cvt_f32_ubyte3 %3, %8\n"
+                   "v_cvt_f32_ubyte0 %4, %8\n"
+                   "v_cvt_f32_ubyte1 %5, %8\n"
+                   "v_cvt_f32_ubyte2 %6, %8\n"
+                   "v_cvt_f32_ubyte3 %7, %8\n"
+                   "v_cvt_f32_ubyte0 %0, %8\n"
+                   "v_cvt_f32_ubyte1 %1, %8\n"
+                   "v_cvt_f32_ubyte2 %2, %8\n"
+                   "v_cvt_f32_ubyte3 %3, %8\n"
+                   "v_cvt_f32_ubyte0 %4, %8\n"
+                   "v_cvt_f32_ubyte1 %5, %8\n"
+                   "v_cvt_f32_ubyte2 %6, %8\n"
+                   "v_cvt_f32_ubyte3 %7, %8\n"
+                   "v_cvt_f32_ubyte0 %0, %8\n"
+                   "v_cvt_f32_ubyte1 %1, %8\n"
+                   "v_cvt_f32_ubyte2 %2, %8\n"
+                   "v_cvt_f32_ubyte3 %3, %8\n"
+                   "v_cvt_f32_ubyte0 %4, %8\n"
+                   "v_cvt_f32_ubyte1 %5, %8\n"
+                   "v_cvt_f32_ubyte2 %6, %8\n"
+                   "v_cvt_f32_ubyte3 %7, %8\n"
+                   "v_cvt_f32_ubyte0 %0, %8\n"
+                   "v_cvt_f32_ubyte1 %1, %8\n"
+                   "v_cvt_f32_ubyte2 %2, %8\n"
+                   "v_cvt_f32_ubyte3 %3, %8\n"
+                   "v_cvt_f32_ubyte0 %4, %8\n"
+                   "v_cvt_f32_ubyte1 %5, %8\n"
+                   "v_cvt_f32_ubyte2 %6, %8\n"
+                   "v_cvt_f32_ubyte3 %7, %8\n"
+                   "v_cvt_f32_ubyte0 %0, %8\n"
+                   "v_cvt_f32_ubyte1 %1, %8\n"
+                   "v_cvt_f32_ubyte2 %2, %8\n"
+                   "v_cvt_f32_ubyte3 %3, %8\n"
+                   "v_cvt_f32_ubyte0 %4, %8\n"
+                   "v_cvt_f32_ubyte1 %5, %8\n"
+                   "v_cvt_f32_ubyte2 %6, %8\n"
+                   "v_cvt_f32_ubyte3 %7, %8\n"
+                   "v_cvt_f32_ubyte0 %0, %8\n"
+                   "v_cvt_f32_ubyte1 %1, %8\n"
+                   "v_cvt_f32_ubyte2 %2, %8\n"
+                   "v_cvt_f32_ubyte3 %3, %8\n"
+                   "v_cvt_f32_ubyte0 %4, %8\n"
+                   "v_cvt_f32_ubyte1 %5, %8\n"
+                   "v_cvt_f32_ubyte2 %6, %8\n"
+                   "v_cvt_f32_ubyte3 %7, %8\n"
+                   "v_cvt_f32_ubyte0 %0, %8\n"
+                   "v_cvt_f32_ubyte1 %1, %8\n"
+                   "v_cvt_f32_ubyte2 %2, %8\n"
+                   "v_cvt_f32_ubyte3 %3, %8\n"
+                   "v_cvt_f32_ubyte0 %4, %8\n"
+                   "v_cvt_f32_ubyte1 %5, %8\n"
+                   "v_cvt_f32_ubyte2 %6, %8\n"
+                   "v_cvt_f32_ubyte3 %7, %8\n"
+                   "v_cvt_f32_ubyte0 %0, %8\n"
+                   "v_cvt_f32_ubyte1 %1, %8\n"
+                   "v_cvt_f32_ubyte2 %2, %8\n"
+                   "v_cvt_f32_ubyte3 %3, %8\n"
+                   "v_cvt_f32_ubyte0 %4, %8\n"
+                   "v_cvt_f32_ubyte1 %5, %8\n"
+                   "v_cvt_f32_ubyte2 %6, %8\n"
+                   "v_cvt_f32_ubyte3 %7, %8\n"
+                   : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(w));
+  }
+  float s = 0;
+  for (int k = 0; k < 8; k++) s += a[k];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void u_rcp(float* out) {
+  float a[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) a[k] = 1.0f + threadIdx.x * 1e-3f + k;
+#pragma unroll 1
+  for (int i = 0; i < ITERS; ++i) {
+    asm volatile("v_rcp_f32 %0, %0\n"
+                   "v_rcp_f32 %1, %1\n"
+                   "v_rcp_f32 %2, %2\n"
+                   "v_rcp_f32 %3, %3\n"
+                   "v_rcp_f32 %4, %4\n"
+                   "v_rcp_f32 %5, %5\n"
+                   "v_rcp_f32 %6, %6\n"
+                   "v_rcp_f32 %7, %7\n"
+                   "v_rcp_f32 %0, %0\n"
+                   "v_rcp_f32 %1, %1\n"
+                   "v_rcp_f32 %2, %2\n"
+                   "v_rcp_f32 %3, %3\n"
+                   "v_rcp_f32 %4, %4\n"
+                   "v_rcp_f32 %5, %5\n"
+                   "v_rcp_f32 %6, %6\n"
+                   "v_rcp_f32 %7, %7\n"
+                   "v_rcp_f32 %0, %0\n"
+                   "v_rcp_f32 %1, %1\n"
+                   "v_rcp_f32 %2, %2\n"
+                   "v_rcp_f32 %3, %3\n"
+                   "v_rcp_f32 %4, %4\n"
+                   "v_rcp_f32 %5, %5\n"
+                   "v_rcp_f32 %6, %6\n"
+                   "v_rcp_f32 %7, %7\n"
+                   "v_rcp_f32 %0, %0\n"
+                   "v_rcp_f32 %1, %1\n"
+                   "v_rcp_f32 %2, %2\n"
+                   "v_rcp_f32 %3, %3\n"
+                   "v_rcp_f32 %4, %4\n"
+                   "v_rcp_f32 %5, %5\n"
+                   "v_rcp_f32 %6, %6\n"
+                   "v_rcp_f32 %7, %7\n"
+                   "v_rcp_f32 %0, %0\n"
+                   "v_rcp_f32 %1, %1\n"
+                   "v_rcp_f32 %2, %2\n"
+                   "v_rcp_f32 %3, %3\n"
+                   "v_rcp_f32 %4, %4\n"
+                   "v_rcp_f32 %5, %5\n"
+                   "v_rcp_f32 %6, %6\n"
+                   "v_rcp_f32 %7, %7\n"
+                   "v_rcp_f32 %0, %0\n"
+                   "v_rcp_f32 %1, %1\n"
+                   "v_rcp_f32 %2, %2\n"
+                   "v_rcp_f32 %3, %3\n"
+                   "v_rcp_f32 %4, %4\n"
+                   "v_rcp_f32 %5, %5\n"
+                   "v_rcp_f32 %6, %6\n"
+                   "v_rcp_f32 %7, %7\n"
+                   "v_rcp_f32 %0, %0\n"
+                   "v_rcp_f32 %1, %1\n"
+                   "v_rcp_f32 %2, %2\n"
+                   "v_rcp_f32 %3, %3\n"
+                   "v_rcp_f32 %4, %4\n"
+                   "v_rcp_f32 %5, %5\n"
+                   "v_rcp_f32 %6, %6\n"
+                   "v_rcp_f32 %7, %7\n"
+                   "v_rcp_f32 %0, %0\n"
+                   "v_rcp_f32 %1, %1\n"
+                   "v_rcp_f32 %2, %2\n"
+                   "v_rcp_f32 %3, %3\n"
+                   "v_rcp_f32 %4, %4\n"
+                   "v_rcp_f32 %5, %5\n"
+                   "v_rcp_f32 %6, %6\n"
+                   "v_rcp_f32 %7, %7\n"
+                   : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : );
+  }
+  float s = 0;
+  for (int k = 0; k < 8; k++) s += a[k];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void u_mullo(float* out) {
+  unsigned a[8];
+  unsigned b = 1664525u + threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < 8; k++) a[k] = threadIdx.x + k;
+#pragma unroll 1
+  for (int i = 0; i < ITERS; ++i) {
+    asm volatile("v_mul_lo_u32 %0, %0, %8\n"
+                   "v_mul_lo_u32 %1, %1, %8\n"
+                   "v_mul_lo_u32 %2, %2, %8\n"
+                   "v_mul_lo_u32 %3, %3, %8\n"
+                   "v_mul_lo_u32 %4, %4, %8\n"
+                   "v_mul_lo_u32 %5, %5, %8\n"
+                   "v_mul_lo_u32 %6, %6, %8\n"
+                   "v_mul_lo_u32 %7, %7, %8\n"
+                   "v_mul_lo_u32 %0, %0, %8\n"
+                   "v_mul_lo_u32 %1, %1, %8\n"
+                   "v_mul_lo_u32 %2, %2, %8\n"
+                   "v_mul_lo_u32 %3, %3, %8\n"
+                   "v_mul_lo_u32 %4, %4, %8\n"
+                   "v_mul_lo_u32 %5, %5, %8\n"
+                   "v_mul_lo_u32 %6, %6, %8\n"
+                   "v_mul_lo_u32 %7, %7, %8\n"
+                   "v_mul_lo_u32 %0, %0, %8\n"
+                   "v_mul_lo_u32 %1, %1, %8\n"
+                   "v_mul_lo_u32 %2, %2, %8\n"
+                   "v_mul_lo_u32 %3, %3, %8\n"
+                   "v_mul_lo_u32 %4, %4, %8\n"
+                   "v_mul_lo_u32 %5, %5, %8\n"
+                   "v_mul_lo_u32 %6, %6, %8\n"
+                   "v_mul_lo_u32 %7, %7, %8\n"
+                   "v_mul_lo_u32 %0, %0, %8\n"
+                   "v_mul_lo_u32 %1, %1, %8\n"
+                   "v_mul_lo_u32 %2, %2, %8\n"
+                   "v_mul_lo_u32 %3, %3, %8\n"
+                   "v_mul_lo_u32 %4, %4, %8\n"
+                   "v_mul_lo_u32 %5, %5, %8\n"
+                   "v_mul_lo_u32 %6, %6, %8\n"
+                   "v_mul_lo_u32 %7, %7, %8\n"
+                   "v_mul_lo_u32 %0, %0, %8\n"
+                   "v_mul_lo_u32 %1, %1, %8\n"
+                   "v_mul_lo_u32 %2, %2, %8\n"
+                   "v_mul_lo_u32 %3, %3, %8\n"
+                   "v_mul_lo_u32 %4, %4, %8\n"
+                   "v_mul_lo_u32 %5, %5, %8\n"
+                   "v_mul_lo_u32 %6, %6, %8\n"
+                   "v_mul_lo_u32 %7, %7, %8\n"
+                   "v_mul_lo_u32 %0, %0, %8\n"
+                   "v_mul_lo_u32 %1, %1, %8\n"
+                   "v_mul_lo_u32 %2, %2, %8\n"
+                   "v_mul_lo_u32 %3, %3, %8\n"
+                   "v_mul_lo_u32 %4, %4, %8\n"
+                   "v_mul_lo_u32 %5, %5, %8\n"
+                   "v_mul_lo_u32 %6, %6, %8\n"
+                   "v_mul_lo_u32 %7, %7, %8\n"
+                   "v_mul_lo_u32 %0, %0, %8\n"
+                   "v_mul_lo_u32 %1, %1, %8\n"
+                   "v_mul_lo_u32 %2, %2, %8\n"
+                   "v_mul_lo_u32 %3, %3, %8\n"
+                   "v_mul_lo_u32 %4, %4, %8\n"
+                   "v_mul_lo_u32 %5, %5, %8\n"
+                   "v_mul_lo_u32 %6, %6, %8\n"
+                   "v_mul_lo_u32 %7, %7, %8\n"
+                   "v_mul_lo_u32 %0, %0, %8\n"
+                   "v_mul_lo_u32 %1, %1, %8\n"
+                   "v_mul_lo_u32 %2, %2, %8\n"
+                   "v_mul_lo_u32 %3, %3, %8\n"
+                   "v_mul_lo_u32 %4, %4, %8\n"
+                   "v_mul_lo_u32 %5, %5, %8\n"
+                   "v_mul_lo_u32 %6, %6, %8\n"
+                   "v_mul_lo_u32 %7, %7, %8\n"
+                   : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(b));
+  }
+  unsigned s = 0;
+  for (int k = 0; k < 8; k++) s += a[k];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = (float)s;
+}
+// the slab test of one pair of children of a quantised node, as dtrace.h::box_test4q issues it: 12 conversions, 6 packed fma
+// (dequantisation), 6 packed subtractions, 6 packed multiplications, 10 packed min / max, 4 fma (widening) = 44 instructions
+__global__ __launch_bounds__(256) void u_mix(float* out, unsigned seed) {
+  unsigned q[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) q[k] = seed * (threadIdx.x + 1u) + k * 0x01030507u;
+  const f2 s = {1e-3f, 1e-3f}, g = {-1.0f, -1.0f}, o = {0.25f + threadIdx.x * 1e-4f, 0.25f + threadIdx.x * 1e-4f}, inv = {1.5f, 1.5f};
+  float acc = 0.f;
+  constexpr int kInstr = 44;
+#pragma unroll 1
+  for (int i = 0; i < ITERS * UNROLL * 8 / kInstr; ++i) {
+    f2 a = {0.f, 0.f}, b = {1e30f, 1e30f};
+#pragma unroll
+    for (int ax = 0; ax < 3; ax++) {
+      const unsigned lo = q[ax], hi = q[3 + ax];
+      const f2 l2 = {(float)(lo & 255u), (float)((lo >> 8) & 255u)}, h2 = {(float)(hi & 255u), (float)((hi >> 8) & 255u)};
+      const f2 p = (__builtin_elementwise_fma(l2, s, g) - o) * inv, r = (__builtin_elementwise_fma(h2, s, g) - o) * inv;
+      if (ax == 0) a = __builtin_elementwise_min(p, r), b = __builtin_elementwise_max(p, r);
+      else a = __builtin_elementwise_max(a, __builtin_elementwise_min(p, r)), b = __builtin_elementwise_min(b, __builtin_elementwise_max(p, r));
+    }
+    const float e = 1.52587890625e-05f;
+    acc += __builtin_fmaf(-fabsf(a.x), e, a.x) + __builtin_fmaf(-fabsf(a.y), e, a.y) + __builtin_fmaf(fabsf(b.x), e, b.x) + __builtin_fmaf(fabsf(b.y), e, b.y);
+#pragma unroll
+    for (int k = 0; k < 6; k++) q[k] += 0x00010001u;
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
+int main() {
+  float* d;
+  const int blocks = 256 * 8, threads = 256;
+  (void)hipMalloc(&d, sizeof(float) * blocks * threads);
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0), (void)hipEventCreate(&e1);
+  constexpr int kModes = 9;
+  const char* names[kModes] = {"v_fma_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32", "v_min_f32", "v_cvt_f32_ubyteN", "v_rcp_f32", "v_mul_lo_u32", "Q-node slab mix"};
+  double cyc_fma = 0.0;
+  for (int rep = 0; rep < 2; ++rep)
+    for (int mode = 0; mode < kModes; ++mode) {
+      (void)hipEventRecord(e0);
+      switch (mode) {
+        case 0: hipLaunchKernelGGL(u_fma, dim3(blocks), dim3(threads), 0, 0, d); break;
+        case 1: hipLaunchKernelGGL(u_pk_fma, dim3(blocks), dim3(threads), 0, 0, d); break;
+        case 2: hipLaunchKernelGGL(u_pk_mul, dim3(blocks), dim3(threads), 0, 0, d); break;
+        case 3: hipLaunchKernelGGL(u_pk_add, dim3(blocks), dim3(threads), 0, 0, d); break;
+        case 4: hipLaunchKernelGGL(u_min, dim3(blocks), dim3(threads), 0, 0, d); break;
+        case 5: hipLaunchKernelGGL(u_cvt, dim3(blocks), dim3(threads), 0, 0, d, 12345u); break;
+        case 6: hipLaunchKernelGGL(u_rcp, dim3(blocks), dim3(threads), 0, 0, d); break;
+        case 7: hipLaunchKernelGGL(u_mullo, dim3(blocks), dim3(threads), 0, 0, d); break;
+        default: hipLaunchKernelGGL(u_mix, dim3(blocks), dim3(threads), 0, 0, d, 12345u); break;
+      }
+      (void)hipEventRecord(e1);
+      (void)hipEventSynchronize(e1);
+      float ms;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      // wave-instructions per SIMD: 8 waves x ITERS x UNROLL x 8 (the mix: the same count rounded down to whole tests; its loop
+      // overhead -- 6 integer adds per 44 -- is not counted)
+      const double per_simd = 8.0 * (mode == kModes - 1 ? (double)(ITERS * UNROLL * 8 / 44) * 44 : (double)ITERS * UNROLL * 8);
+      const double cyc = ms * 1e-3 * 2.4e9 / per_simd;
+      if (rep) {
+        printf("%-28s %8.3f ms  %5.2f cycles per wave-instruction and SIMD at the nominal 2.4 GHz\n", names[mode], ms, cyc);
+        if (mode == 0) cyc_fma = cyc;
+      }
+    }
+  if (!(cyc_fma > 1.4 && cyc_fma < 2.6)) {
+    printf("ASSERT: v_fma_f32 expected at 2 cycles per wave64 instruction (SIMD-32), measured %.2f\n", cyc_fma);
+    return 1;
+  }
+  printf("ok: a wave64 v_fma_f32 issues over %.2f cycles (guide: 2)\n", cyc_fma);
+  return 0;
+}

@@ -138,3 +138,22 @@ def test_tile_rank_map():
     assert sum(len(g) for g in got) == len(all_tiles) == 510
     assert np.array_equal(got[3], all_tiles[3::8])
     assert [len(g) for g in got] == [64, 64, 64, 64, 64, 64, 63, 63]
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus N` with no launcher (WORLD_SIZE unset) must start N rank processes itself -- torch.distributed.run as a
+    child, before anything touches the GPU -- and hand on rank 0's line (it used to end in SystemExit).  Here on the
+    CPU: the dry run shows the command, and the self-test runs it for real with two gloo ranks."""
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "8", "--steps", "2", "--warmup", "1"], env=dict(env, BENCH_SPAWN_DRY_RUN="1"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+    cmd = json.loads(r.stdout.strip().splitlines()[-1])["spawn"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=8" in cmd and "127.0.0.1" in cmd
+    assert cmd[cmd.index(bench):] == [bench, "--gpus", "8", "--steps", "2", "--warmup", "1"]
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--spawn-selftest"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    assert json.loads(line) == {"selftest": 2, "sum": 3}

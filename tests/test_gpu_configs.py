@@ -114,39 +114,42 @@ def test_full_size_whole_frame_both_math_modes(pa, config):
 
 @pytest.mark.parametrize("config", ["c2", "c3", "c4", "c5"])
 def test_libm_tolerance_at_the_configurations_own_spp(pa, config):
-    """The 1e-4 bar against the reference's own arithmetic (oracle[libm]), MEASURED at the configuration's sample count where the
-    oracle finishes that many samples in the time budget (C2 at 64 spp, C4 at 128 spp, C3 at 256 spp on the GPU box's 256
-    threads), and at the largest sample count that fits otherwise (C5: 8.5 G samples do not).  The whole frame at full
-    resolution; the oracle runs with 16 x 16-pixel jobs (schedule-independent image, tests/_oracle.py JOBS_BLOCKS)."""
+    """The 1e-4 bar against the reference's own arithmetic (oracle[libm]), MEASURED AT THE CONFIGURATION'S OWN SAMPLE COUNT, and
+    the sample count reached is asserted, not scaled down (a slower host must fail here, not silently lower it):
+      C2 / C3 / C4  the whole 1920 x 1080 frame at 64 / 256 / 128 spp
+      C5            the 3840 x 2160 frame at its 1024 spp on every 64th of the reference's 64 x 64 tiles (tile i % 64 == 0: 32 tiles
+                    spread over the frame, 131 k pixels, 134 M samples; the seeds are the full frame's, (pass << 32) + y * 3840 + x) --
+                    the whole frame is 8.5 G samples, hours of oracle time
+    The oracle runs with 16 x 16-pixel jobs (schedule-independent image, tests/_oracle.py JOBS_BLOCKS).  PBR_TOL_SECONDS (default
+    420) is a guard: if one calibration pass says the oracle would need longer than that, the test FAILS with the figures."""
     import time
-    budget = float(os.environ.get("PBR_TOL_SECONDS", "150"))
+    limit = float(os.environ.get("PBR_TOL_SECONDS", "420"))
     desc = config_desc(config)
     W, H = (3840, 2160) if config == "c5" else (1920, 1080)
-    spp_cfg = {"c2": 64, "c3": 256, "c4": 128, "c5": 1024}[config]
+    spp = {"c2": 64, "c3": 256, "c4": 128, "c5": 1024}[config]
+    world = 64 if config == "c5" else 1   # C5: tiles i % 64 == 0 of the full frame
     sg, so = pa.scene_from_desc(desc), O.oracle_scene_from_desc(desc)
     t0 = time.time()
-    so.render(W, H, 1, threads=THREADS, math_mode=O.MATH_LIBM)                   # calibration: one pass of the frame
+    so.render(W, H, 1, tile_rank=0, tile_world=world, threads=THREADS, math_mode=O.MATH_LIBM)   # calibration: one pass
     per_pass = max(time.time() - t0, 1e-3)
-    spp = int(max(1, min(spp_cfg, budget // per_pass)))
+    if per_pass * spp > limit:
+        pytest.fail(f"{config}: the oracle needs {per_pass:.2f} s per pass on {THREADS} threads = {per_pass * spp:.0f} s for the configuration's "
+                    f"{spp} spp (limit PBR_TOL_SECONDS = {limit:.0f} s): the bar cannot be measured at the configuration's spp on this host")
     lay = pa.RenderLayer()
-    ok, _ = pa.Render(sg, W, H, spp, layer=lay)
-    assert ok is True and (lay.count == spp).all()
+    ok, _ = pa.Render(sg, W, H, spp, layer=lay, tile_rank=0, tile_world=world)
     t0 = time.time()
-    libm, cnt, _ = so.render(W, H, spp, threads=THREADS, math_mode=O.MATH_LIBM)
+    libm, cnt, _ = so.render(W, H, spp, tile_rank=0, tile_world=world, threads=THREADS, math_mode=O.MATH_LIBM)
     dt = time.time() - t0
-    assert np.array_equal(cnt, lay.count)
-    r = rel_l2(lay.rgba, libm)
+    assert ok is True and np.array_equal(cnt, lay.count)
+    mine = cnt > 0
+    npx = int(mine.sum())
+    assert (cnt[mine] == spp).all() and (npx == W * H if world == 1 else 0 < npx < W * H)
+    r = rel_l2(lay.rgba[mine], libm[mine])
     nl = int((np.abs(lay.rgba[..., :3] - libm[..., :3]).max(axis=2) > 0).sum())
-    if spp == spp_cfg:
-        print(f"{config}: {W}x{H}x{spp} (the configuration's spp): rel L2 vs oracle[libm] {r:.2e} (bar 1e-4), {nl} of {W * H} pixels differ; "
-              f"oracle {W * H * spp / dt / 1e6:.1f} Msamples/s on {THREADS} threads, {dt:.0f} s")
-        assert r < REL_L2_TOL, r
-    else:
-        # fewer samples than the configuration: flipped samples (isolated O(1) differences) average out at least as 1 / sqrt(spp)
-        proj = r * np.sqrt(spp / spp_cfg)
-        print(f"{config}: {W}x{H}x{spp} of {spp_cfg} spp ({budget:.0f} s of oracle time): rel L2 vs oracle[libm] {r:.2e}, {nl} pixels differ; "
-              f"x sqrt({spp}/{spp_cfg}) = {proj:.1e} at the configuration's spp (bar 1e-4); oracle {W * H * spp / dt / 1e6:.1f} Msamples/s")
-        assert proj < REL_L2_TOL, (r, proj)
+    print(f"{config}: {W}x{H} x {spp} spp = the configuration's spp" + (f" on tiles i % {world} == 0" if world > 1 else "") +
+          f" ({npx} pixels, {npx * spp / 1e6:.1f} M samples): rel L2 vs oracle[libm] {r:.2e} (bar 1e-4), {nl} pixels differ; "
+          f"oracle {npx * spp / dt / 1e6:.2f} Msamples/s on {THREADS} threads, {dt:.0f} s")
+    assert r < REL_L2_TOL, r
 
 
 def test_c3_high_pass_indices(pa):
