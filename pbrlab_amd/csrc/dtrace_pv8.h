@@ -108,6 +108,10 @@ __device__ __forceinline__ void trace_pv8(const DScene& sc, uint32_t n, uint32_t
   uint32_t steps = 0;
   bool any_ray = (MODE == 1);
   uint32_t oct = 0u;              // the ray's direction signs: bit a = d[a] < 0
+#ifdef PB_TRAV_TWICE  // diagnostic build: every ray is traversed twice before it is delivered (what does the traversal itself cost?)
+  bool second = false;
+  float tmax0 = 0.f;
+#endif
   uint32_t g_base = 0u, g_bits = 0u;  // what is left of the node the ray is in: first child item | hits in visiting order (8) | present << 8 | leaf << 16
   float4 D0 = make_float4(0, 0, 0, 0), D1 = D0, D2 = D0, D3 = D0, D4 = D0;  // the prefetched item: a Node8 or a TriPair
 
@@ -198,6 +202,9 @@ __device__ __forceinline__ void trace_pv8(const DScene& sc, uint32_t n, uint32_t
         hit.u = 0.f, hit.v = 0.f, hit.slot = kNone;
         sp = 0, steps = 0, g_bits = 0u;
         state = kStNode, cur = 0u, need_load = true;  // item 0: the root node
+#ifdef PB_TRAV_TWICE
+        second = false, tmax0 = hit.t;
+#endif
       }
       batch_cur += taken;
       if (STATS) {
@@ -273,6 +280,12 @@ __device__ __forceinline__ void trace_pv8(const DScene& sc, uint32_t n, uint32_t
         need_load = true;
       }
     }
+#ifdef PB_TRAV_TWICE
+    if ((state == kStDone || state == kStDoneOccluded) && !second) {
+      second = true, hit.t = tmax0, hit.u = 0.f, hit.v = 0.f, hit.slot = kNone, sp = 0, g_bits = 0u;
+      state = kStNode, cur = 0u, need_load = true;
+    }
+#endif
     if (need_load) {
       const float4* g = items + (size_t)cur * kNode8Words;
       D0 = g[0], D1 = g[1], D2 = g[2], D3 = g[3], D4 = g[4];
