@@ -560,18 +560,19 @@ static bool quantise_node8(const QChild* c, const int* slot, int n, Node8* nd) {
   return true;
 }
 
-uint32_t build_q8tree(const std::vector<BvhNode>& N2, const std::function<void(uint32_t, float4*)>& leaf_item, std::vector<float4>* out,
-                      double cost_node, double cost_leaf) {
+uint32_t build_q8tree(const std::vector<BvhNode>& N2, const std::function<int(uint32_t, const float*, const float*, Q8Leaf*)>& split_leaf,
+                      const std::function<int(uint32_t, float4*)>& emit_leaf, std::vector<float4>* out, double cost_node, double cost_leaf) {
   out->clear();
   if (N2.empty()) return 0;
-  // the binary tree as a tree of boxes (a vertex = one child entry of a binary node; vertex 0 = the scene); children follow their parent
+  // the binary tree as a tree of boxes (a vertex = one child entry of a binary node; vertex 0 = the scene); children follow their
+  // parent; a leaf of the binary tree that split_leaf turns into two leaves is an inner vertex with two leaves here
   struct V {
     float lo[3], hi[3];
     int32_t l = -1, r = -1;  // children, or -1: leaf
-    uint32_t ref = 0;        // leaf: the binary tree's leaf reference
+    uint32_t token = 0;      // leaf: what emit_leaf gets
   };
   std::vector<V> T;
-  T.reserve(N2.size() * 2 + 1);
+  T.reserve(N2.size() * 3 + 1);
   {
     struct Todo {
       uint32_t node2;
@@ -589,16 +590,32 @@ uint32_t build_q8tree(const std::vector<BvhNode>& N2, const std::function<void(u
       for (int k = 0; k < 2; k++) {
         const uint32_t ref = k ? b.c1 : b.c0;
         if (ref == kEmptyChild) continue;
+        float lo[3], hi[3];
+        for (int a = 0; a < 3; a++) lo[a] = b.lo[a][k], hi[a] = b.hi[a][k];
         const int32_t v = (int32_t)T.size();
         T.emplace_back();
-        for (int a = 0; a < 3; a++) T[v].lo[a] = b.lo[a][k], T[v].hi[a] = b.hi[a][k];
+        for (int a = 0; a < 3; a++) T[v].lo[a] = lo[a], T[v].hi[a] = hi[a];
         kids[nk++] = v;
         if (!(ref & kLeafBit)) {
           todo.push_back({ref, v});
           continue;
         }
-        if (ref & kCurveBit) return 0;  // (triangle-only scenes)
-        T[v].ref = ref;
+        Q8Leaf c[2];
+        const int m = split_leaf(ref, lo, hi, c);
+        if (m == 1) {
+          T[v].token = c[0].token;
+          for (int a = 0; a < 3; a++) T[v].lo[a] = c[0].lo[a], T[v].hi[a] = c[0].hi[a];
+        } else if (m == 2) {
+          for (int j = 0; j < 2; j++) {
+            const int32_t w = (int32_t)T.size();
+            T.emplace_back();
+            T[w].token = c[j].token;
+            for (int a = 0; a < 3; a++) T[w].lo[a] = c[j].lo[a], T[w].hi[a] = c[j].hi[a];
+            (j ? T[v].r : T[v].l) = w;
+          }
+        } else {
+          return 0;
+        }
       }
       if (nk == 2) T[t.v].l = kids[0], T[t.v].r = kids[1];
       else if (nk == 1) T[t.v].l = kids[0], T[t.v].r = -1;
@@ -683,7 +700,7 @@ uint32_t build_q8tree(const std::vector<BvhNode>& N2, const std::function<void(u
   };
   struct Item {
     int32_t v;
-    uint32_t out, depth;
+    uint32_t out, depth;  // out: the node's word index
   };
   std::vector<Item> work;
   out->resize(kNode8Words);
@@ -730,30 +747,34 @@ uint32_t build_q8tree(const std::vector<BvhNode>& N2, const std::function<void(u
     Node8 nd;
     memset(&nd, 0, sizeof(nd));
     if (!quantise_node8(c, slot, n, &nd)) return out->clear(), 0;
-    // the children's items: contiguous, in slot order
+    // the children's items: contiguous, in slot order; an inner node and a triangle leaf take five words, a curve leaf four
     int order[8], m = 0;
     for (int s2 = 0; s2 < 8; s2++)
       for (int i = 0; i < n; i++)
         if (slot[i] == s2) order[m++] = i;
-    const uint32_t base = (uint32_t)(out->size() / kNode8Words);
-    out->resize(out->size() + (size_t)n * kNode8Words);
-    uint32_t imask = 0, lmask = 0;
+    const uint32_t base = (uint32_t)out->size();
+    uint32_t imask = 0, tmask = 0, cmask = 0;
     for (int k = 0; k < n; k++) {
       const int i = order[k];
       const V& u = T[kids[i]];
+      const size_t at = out->size();
+      out->resize(at + kNode8Words);
       if (u.l < 0) {
-        lmask |= 1u << slot[i];
-        leaf_item(u.ref, out->data() + (size_t)(base + k) * kNode8Words);
+        const int words = emit_leaf(u.token, out->data() + at);
+        if (words == 4) cmask |= 1u << slot[i], out->resize(at + 4);
+        else if (words == 5) tmask |= 1u << slot[i];
+        else return out->clear(), 0;
       } else {
         imask |= 1u << slot[i];
-        work.push_back({kids[i], base + (uint32_t)k, it.depth + 1u});
+        work.push_back({kids[i], (uint32_t)at, it.depth + 1u});
       }
     }
-    nd.base = base, nd.masks = imask | (lmask << 8);
+    nd.base = base, nd.masks = imask | (tmask << 8) | (cmask << 16);
     static_assert(sizeof(Node8) == kNode8Words * sizeof(float4), "Node8 is five words");
-    memcpy(out->data() + (size_t)it.out * kNode8Words, &nd, sizeof(nd));
+    memcpy(out->data() + (size_t)it.out, &nd, sizeof(nd));
   }
-  if (out->size() / kNode8Words >= (1u << 28)) return out->clear(), 0;
+  if (out->size() >= (1u << 30)) return out->clear(), 0;
+  for (int k = 0; k < 4; k++) out->push_back(make_float4(0.f, 0.f, 0.f, 0.f));  // (the load site reads five words of a four-word last item)
   return depth;
 }
 

@@ -158,7 +158,14 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
   const float4* const items = WIDE ? sc.wide : reinterpret_cast<const float4*>(sc.nodes);
   const uint32_t slot0 = sc.num_nodes;  // binary tree: item index of slot 0
 
+  unsigned long long t_turn = STATS ? __builtin_readcyclecounter() : 0ull;  // STATS: the turn's cycles go to what it did
+  int did = -1;
   for (;;) {
+    if (STATS) {
+      const unsigned long long t_now = __builtin_readcyclecounter();
+      if (lane == 0 && did >= 0) st.cyc[did] += t_now - t_turn;
+      t_turn = t_now;
+    }
     // `advance`: the lane needs a new item; `next` is its reference when have_next, else it is popped
     bool advance = false, have_next = false, need_load = false;
     uint32_t next = 0;
@@ -171,6 +178,7 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
     if ((n_idle >= kRefillAt || (Sink::kWalk && n_busy_now == 0)) && (!exhausted || (Sink::kWalk && __ballot(state >= kStDone) != 0ull))) {
       // ---- refill idle lanes from the queue
       const unsigned long long t_refill = STATS ? wall_clock64() : 0ull;
+      did = 3;
       if (!exhausted && batch_cur == batch_end) {
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(head, batch);
@@ -275,6 +283,7 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
       // vote: the phase that advances the most lanes per instruction issued (a node step is cheaper than a primitive step)
       const int w_node = n_node * PB_W_NODE, w_tri = n_tri * PB_W_TRI, w_curve = n_curve * PB_W_CURVE;
       const int phase = (w_node >= w_tri && w_node >= w_curve) ? 0 : ((!CURVES || w_tri >= w_curve) ? 1 : 2);
+      did = phase;
       if (STATS && lane == 0) {
         if (phase == 0) st.it_node++, st.ln_node += n_node;
         else if (phase == 1) st.it_tri++, st.ln_tri += n_tri;
@@ -284,6 +293,22 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
         // ---- NODE phase
         if (WIDE && state == kStNode) {
           if (STATS) (any_ray ? st.anodes : st.nodes)++, steps++;
+#ifdef PB_DIAG_EXTRA_VALU  // diagnostic build: PB_DIAG_EXTRA_VALU dependent fma more per node turn (is the kernel bound by its VALU instructions?)
+          {
+            float x = D0.x;
+#pragma unroll
+            for (int k2 = 0; k2 < PB_DIAG_EXTRA_VALU; k2++) asm volatile("v_fma_f32 %0, %0, %0, %1" : "+v"(x) : "v"(D0.y));
+            if (x == 1.2345e-30f) tmin = x;
+          }
+#endif
+#ifdef PB_DIAG_EXTRA_LOAD  // diagnostic build: one more 16-byte load per lane and node turn (the node's own first word: an L1 hit)
+          {
+            const float4* qd = items + cur;
+            asm volatile("" : "+v"(qd));
+            const float4 x = *qd;
+            if (x.x == 1.2345e-30f) tmin = x.y;
+          }
+#endif
           uint32_t k[4];
           wide_node_keys(D0, D1, D2, D3w, o, inv4, tmin, hit.t, k);
           auto ref_of = [&](uint32_t key) { return wide_ref(D3w, key); };

@@ -20,9 +20,16 @@
 namespace pb {
 
 #ifndef PB_LDS_STACK8
-#define PB_LDS_STACK8 10
+#define PB_LDS_STACK8 13
 #endif
 constexpr int kPv8LdsStack = PB_LDS_STACK8;  // stack entries (8 bytes each) per lane kept in LDS; deeper ones spill to the group's global area
+#ifndef PB_LDS_STACK8_CURVES
+#define PB_LDS_STACK8_CURVES 10
+#endif
+constexpr int kPv8LdsStackCurves = PB_LDS_STACK8_CURVES;  // ... of the kernels of scenes with curves (next to 10 words of ray frame per lane)
+#ifndef PB_W_CURVE8
+#define PB_W_CURVE8 2
+#endif
 #ifndef PB_W_NODE8
 #define PB_W_NODE8 1  // weights of one lane in the phase vote (node : leaf), as PB_W_NODE / PB_W_TRI of dtrace_pv.h
 #endif
@@ -30,7 +37,7 @@ constexpr int kPv8LdsStack = PB_LDS_STACK8;  // stack entries (8 bytes each) per
 #define PB_W_TRI8 2
 #endif
 constexpr int kStackDepth8 = 32;             // entries per ray: one per level of the O tree (a deeper tree is refused at commit)
-static_assert((size_t)(kStackDepth8 - kPv8LdsStack) * 2 <= (size_t)kStackDepth, "the spill area holds kStackDepth words per resident thread");
+static_assert((size_t)(kStackDepth8 - (kPv8LdsStack < kPv8LdsStackCurves ? kPv8LdsStack : kPv8LdsStackCurves)) * 2 <= (size_t)kStackDepth, "the spill area holds kStackDepth words per resident thread");
 
 // The slab test on the eight quantised boxes of a Node8 (its five words w0..w4, dscene.h) against the ray interval [tmin, tmax]:
 // bit s of the result = the box in slot s is hit.  Per pair of slots the arithmetic is box_test4q's, operation for operation: a
@@ -41,27 +48,34 @@ static_assert((size_t)(kStackDepth8 - kPv8LdsStack) * 2 <= (size_t)kStackDepth, 
 __device__ __forceinline__ uint32_t box_test8q(const float4& w0, const float4& w1, const float4& w2, const float4& w3, const float4& w4, float o_x,
                                                float o_y, float o_z, const float4& inv, float tmin, float tmax) {
   const float e = 1.52587890625e-05f;
+  // (the entry / exit bounds are selected by the sign of 1 / d as whole words before the conversion: dtrace.h::box_test4q)
+  const bool nx = (int)__float_as_uint(inv.x) < 0, ny = (int)__float_as_uint(inv.y) < 0, nz = (int)__float_as_uint(inv.z) < 0;
   const f2 sx = {w0.w, w0.w}, sy = {w1.x, w1.x}, sz = {w1.y, w1.y}, gx = {w0.x, w0.x}, gy = {w0.y, w0.y}, gz = {w0.z, w0.z};
   const f2 ox = {o_x, o_x}, oy = {o_y, o_y}, oz = {o_z, o_z}, ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
   uint32_t hits = 0u;
 #pragma unroll
-  for (int h = 0; h < 4; h++) {  // slots 2 h, 2 h + 1: bytes 2 (h & 1), 2 (h & 1) + 1 of word h >> 1 of each bound
-    const uint32_t lx = __float_as_uint(h < 2 ? w2.x : w2.y), ly = __float_as_uint(h < 2 ? w2.z : w2.w), lz = __float_as_uint(h < 2 ? w3.x : w3.y);
-    const uint32_t hx = __float_as_uint(h < 2 ? w3.z : w3.w), hy = __float_as_uint(h < 2 ? w4.x : w4.y), hz = __float_as_uint(h < 2 ? w4.z : w4.w);
-    auto two = [h](uint32_t w) { return (h & 1) ? f2{(float)((w >> 16) & 255u), (float)(w >> 24)} : f2{(float)(w & 255u), (float)((w >> 8) & 255u)}; };
-    f2 p = (__builtin_elementwise_fma(two(lx), sx, gx) - ox) * ix, q = (__builtin_elementwise_fma(two(hx), sx, gx) - ox) * ix;
-    f2 a = __builtin_elementwise_min(p, q), b = __builtin_elementwise_max(p, q);
-    p = (__builtin_elementwise_fma(two(ly), sy, gy) - oy) * iy, q = (__builtin_elementwise_fma(two(hy), sy, gy) - oy) * iy;
-    a = __builtin_elementwise_max(a, __builtin_elementwise_min(p, q)), b = __builtin_elementwise_min(b, __builtin_elementwise_max(p, q));
-    p = (__builtin_elementwise_fma(two(lz), sz, gz) - oz) * iz, q = (__builtin_elementwise_fma(two(hz), sz, gz) - oz) * iz;
-    a = __builtin_elementwise_max(a, __builtin_elementwise_min(p, q)), b = __builtin_elementwise_min(b, __builtin_elementwise_max(p, q));
-    const float a0 = __builtin_fmaf(-fabsf(a.x), e, a.x), a1 = __builtin_fmaf(-fabsf(a.y), e, a.y);
-    const float b0 = __builtin_fmaf(fabsf(b.x), e, b.x), b1 = __builtin_fmaf(fabsf(b.y), e, b.y);
-    // (the comparisons of box_test2 / wide_node_keys, as they are: a NaN entry or exit distance -- a ray with a NaN component -- hits
-    // NO box.  Folding them into max(a, tmin) <= min(b, tmax) lets such a ray hit EVERY box: v_max / v_min drop the NaN, and one NaN
-    // ray then walks all 332 574 items of the C2 tree, 340 ms of a 3 ms launch: measured, profiles/README.md)
-    hits |= ((a0 <= b0 && b0 >= tmin && a0 <= tmax) ? 1u : 0u) << (2 * h);
-    hits |= ((a1 <= b1 && b1 >= tmin && a1 <= tmax) ? 2u : 0u) << (2 * h);
+  for (int hh = 0; hh < 2; hh++) {  // word hh of each bound: slots 4 hh .. 4 hh + 3
+    const uint32_t qlx = __float_as_uint(hh ? w2.y : w2.x), qly = __float_as_uint(hh ? w2.w : w2.z), qlz = __float_as_uint(hh ? w3.y : w3.x);
+    const uint32_t qhx = __float_as_uint(hh ? w3.w : w3.z), qhy = __float_as_uint(hh ? w4.y : w4.x), qhz = __float_as_uint(hh ? w4.w : w4.z);
+    const uint32_t lx = nx ? qhx : qlx, ly = ny ? qhy : qly, lz = nz ? qhz : qlz;
+    const uint32_t hx = nx ? qlx : qhx, hy = ny ? qly : qhy, hz = nz ? qlz : qhz;
+#pragma unroll
+    for (int hl = 0; hl < 2; hl++) {  // slots 4 hh + 2 hl, + 1: bytes 2 hl, 2 hl + 1
+      const int h = 2 * hh + hl;
+      auto two = [hl](uint32_t w) { return hl ? f2{(float)((w >> 16) & 255u), (float)(w >> 24)} : f2{(float)(w & 255u), (float)((w >> 8) & 255u)}; };
+      const f2 px = (__builtin_elementwise_fma(two(lx), sx, gx) - ox) * ix, qx = (__builtin_elementwise_fma(two(hx), sx, gx) - ox) * ix;
+      const f2 py = (__builtin_elementwise_fma(two(ly), sy, gy) - oy) * iy, qy = (__builtin_elementwise_fma(two(hy), sy, gy) - oy) * iy;
+      const f2 pz = (__builtin_elementwise_fma(two(lz), sz, gz) - oz) * iz, qz = (__builtin_elementwise_fma(two(hz), sz, gz) - oz) * iz;
+      const float m0 = __builtin_fmaxf(__builtin_fmaxf(px.x, py.x), pz.x), m1 = __builtin_fmaxf(__builtin_fmaxf(px.y, py.y), pz.y);
+      const float n0 = __builtin_fminf(__builtin_fminf(qx.x, qy.x), qz.x), n1 = __builtin_fminf(__builtin_fminf(qx.y, qy.y), qz.y);
+      const float a0 = __builtin_fmaf(-fabsf(m0), e, m0), a1 = __builtin_fmaf(-fabsf(m1), e, m1);
+      const float b0 = __builtin_fmaf(fabsf(n0), e, n0), b1 = __builtin_fmaf(fabsf(n1), e, n1);
+      // (the comparisons of box_test2 / wide_node_keys, as they are: a NaN entry or exit distance -- a ray with a NaN component -- hits
+      // NO box.  Folding them into max(a, tmin) <= min(b, tmax) lets such a ray hit EVERY box: v_max / v_min drop the NaN, and one NaN
+      // ray then walks all 332 574 items of the C2 tree, 340 ms of a 3 ms launch: measured, profiles/README.md)
+      hits |= ((a0 <= b0 && b0 >= tmin && a0 <= tmax) ? 1u : 0u) << (2 * h);
+      hits |= ((a1 <= b1 && b1 >= tmin && a1 <= tmax) ? 2u : 0u) << (2 * h);
+    }
   }
   return hits;
 }
@@ -74,11 +88,12 @@ __device__ __forceinline__ uint32_t octant_permute(uint32_t x, uint32_t m) {
 }
 
 // Sink, MODE, STATS: as trace_pv (dtrace_pv.h).  stk: this lane's LDS stack (stk[i * stride], 8-byte entries); spill: its global
-// spill entries (spill[(i - kPv8LdsStack) * spill_stride]).
-template <int MODE, bool STATS, typename Sink>
+// spill entries (spill[(i - kPv8LdsStack) * spill_stride]).  CURVES: the scene has curve leaves (frame: 10 words per lane in LDS,
+// frame[k * stride]: the ray's RayFrame, written when the ray is fetched).
+template <int MODE, bool STATS, bool CURVES, typename Sink>
 __device__ __forceinline__ void trace_pv8(const DScene& sc, uint32_t n, uint32_t* head, Sink& sink, uint2* stk, uint32_t stride, uint2* spill,
-                                          uint32_t spill_stride, TravStats& st, uint32_t* overflow) {
-  constexpr int kLds = kPv8LdsStack;
+                                          uint32_t spill_stride, TravStats& st, uint32_t* overflow, float* frame = nullptr) {
+  constexpr int kLds = CURVES ? kPv8LdsStackCurves : kPv8LdsStack;
   const uint32_t lane = __lane_id();
   auto rank_in = [](unsigned long long m) {
     return (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -107,24 +122,32 @@ __device__ __forceinline__ void trace_pv8(const DScene& sc, uint32_t n, uint32_t
   int sp = 0;
   uint32_t steps = 0;
   bool any_ray = (MODE == 1);
-  uint32_t oct = 0u;              // the ray's direction signs: bit a = d[a] < 0
+  uint32_t oct = 0u;                  // the ray's direction signs: bit a = d[a] < 0; CURVES: bit 3 = the second piece of the curve leaf is next
 #ifdef PB_TRAV_TWICE  // diagnostic build: every ray is traversed twice before it is delivered (what does the traversal itself cost?)
   bool second = false;
   float tmax0 = 0.f;
 #endif
-  uint32_t g_base = 0u, g_bits = 0u;  // what is left of the node the ray is in: first child item | hits in visiting order (8) | present << 8 | leaf << 16
-  float4 D0 = make_float4(0, 0, 0, 0), D1 = D0, D2 = D0, D3 = D0, D4 = D0;  // the prefetched item: a Node8 or a TriPair
+  uint32_t g_base = 0u, g_bits = 0u;  // what is left of the node the ray is in: first child word | hits in visiting order (8) | imask << 8 | tmask << 16 | cmask << 24
+  float4 D0 = make_float4(0, 0, 0, 0), D1 = D0, D2 = D0, D3 = D0, D4 = D0;  // the prefetched item: a Node8, a TriPair or a curve leaf
 
+  unsigned long long t_turn = STATS ? __builtin_readcyclecounter() : 0ull;  // STATS: the turn's cycles go to what it did
+  int did = -1;
   for (;;) {
+    if (STATS) {
+      const unsigned long long t_now = __builtin_readcyclecounter();
+      if (lane == 0 && did >= 0) st.cyc[did] += t_now - t_turn;
+      t_turn = t_now;
+    }
     bool advance = false, need_load = false;
     uint32_t cur = 0u;
     unsigned long long idle_mask = __ballot(state == kStIdle || state >= kStDone);
     int n_idle = __popcll(idle_mask);
-    constexpr int kRefillAt = Sink::kWalk ? PB_WALK_REFILL : kPvRefillIdle;
+    constexpr int kRefillAt = Sink::kWalk ? PB_WALK_REFILL : (CURVES ? kPvRefillIdleCurves : kPvRefillIdle);
     const int n_busy_now = 64 - n_idle;
     if ((n_idle >= kRefillAt || (Sink::kWalk && n_busy_now == 0)) && (!exhausted || (Sink::kWalk && __ballot(state >= kStDone) != 0ull))) {
       // ---- refill idle lanes from the queue (trace_pv's protocol)
       const unsigned long long t_refill = STATS ? wall_clock64() : 0ull;
+      did = 3;
       if (!exhausted && batch_cur == batch_end) {
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(head, batch);
@@ -199,9 +222,15 @@ __device__ __forceinline__ void trace_pv8(const DScene& sc, uint32_t n, uint32_t
       if (fresh) {
         inv4 = make_float4(1.0f / d.x, 1.0f / d.y, 1.0f / d.z, 0.f);
         oct = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
+        if (CURVES) {
+          const RayFrame f = ray_frame(d);
+          const float w[10] = {f.dn.x, f.dn.y, f.dn.z, f.bx.x, f.bx.y, f.bx.z, f.by.x, f.by.y, f.by.z, f.inv_len};
+#pragma unroll
+          for (int k = 0; k < 10; k++) frame[(uint32_t)k * stride] = w[k];
+        }
         hit.u = 0.f, hit.v = 0.f, hit.slot = kNone;
         sp = 0, steps = 0, g_bits = 0u;
-        state = kStNode, cur = 0u, need_load = true;  // item 0: the root node
+        state = kStNode, cur = 0u, need_load = true;  // word 0: the root node
 #ifdef PB_TRAV_TWICE
         second = false, tmax0 = hit.t;
 #endif
@@ -214,18 +243,22 @@ __device__ __forceinline__ void trace_pv8(const DScene& sc, uint32_t n, uint32_t
     } else {
       if (n_idle == 64) break;  // queue exhausted and every lane done
       const int n_node = __popcll(__ballot(state == kStNode)), n_tri = __popcll(__ballot(state == kStTri));
-      const int phase = (n_node * PB_W_NODE8 >= n_tri * PB_W_TRI8) ? 0 : 1;
+      const int n_curve = CURVES ? __popcll(__ballot(state == kStCurve)) : 0;
+      const int w_node = n_node * PB_W_NODE8, w_tri = n_tri * PB_W_TRI8, w_curve = n_curve * PB_W_CURVE8;
+      const int phase = (w_node >= w_tri && w_node >= w_curve) ? 0 : ((!CURVES || w_tri >= w_curve) ? 1 : 2);
+      did = phase;
       if (STATS && lane == 0) {
         if (phase == 0) st.it_node++, st.ln_node += n_node;
-        else st.it_tri++, st.ln_tri += n_tri;
+        else if (phase == 1) st.it_tri++, st.ln_tri += n_tri;
+        else st.it_curve++, st.ln_curve += n_curve;
       }
       if (phase == 0) {
         // ---- NODE phase: the eight boxes of the node in D0..D4
         if (state == kStNode) {
           if (STATS) (any_ray ? st.anodes : st.nodes)++, steps++;
-          const uint32_t masks = __float_as_uint(D1.w), present = (masks | (masks >> 8)) & 255u;
+          const uint32_t masks = __float_as_uint(D1.w), present = (masks | (masks >> 8) | (masks >> 16)) & 255u;
           uint32_t hits = box_test8q(D0, D1, D2, D3, D4, o_x, o_y, o_z, inv4, tmin, hit.t) & present;
-          hits = octant_permute(hits, oct);
+          hits = octant_permute(hits, oct & 7u);
           if (hits) {
             if (g_bits & 255u) {  // the rest of the node above goes on the stack: one entry
               const uint2 e = make_uint2(g_base, g_bits);
@@ -234,20 +267,45 @@ __device__ __forceinline__ void trace_pv8(const DScene& sc, uint32_t n, uint32_t
               else *overflow = 1u;
             }
             g_base = __float_as_uint(D1.z);
-            g_bits = hits | (present << 8) | ((masks >> 8) << 16);
+            g_bits = hits | (masks << 8);
           }
           advance = true;
         }
-      } else if (state == kStTri) {
-        // ---- TRI phase: the leaf's one or two triangles in ONE packed test (TriPair; dtrace.h::tri_pair_accept)
-        if (STATS) steps++;
-        uint32_t nt = 0u;
-        const bool occ = tri_pair_accept_s<MODE == 1, STATS>(sc, D0, D1, D2, D3, D4, o_x, o_y, o_z, d.x, d.y, d.z, inv4.x, inv4.y, inv4.z, tmin, any_ray, hit, nt);
-        if (STATS) (any_ray ? st.atris : st.tris) += nt;
-        if (occ) {
-          state = kStDoneOccluded;
+      } else if (phase == 1) {
+        if (state == kStTri) {
+          // ---- TRI phase: the leaf's one or two triangles in ONE packed test (TriPair; dtrace.h::tri_pair_accept)
+          if (STATS) steps++;
+          uint32_t nt = 0u;
+          const bool occ = tri_pair_accept_s<MODE == 1, STATS>(sc, D0, D1, D2, D3, D4, o_x, o_y, o_z, d.x, d.y, d.z, inv4.x, inv4.y, inv4.z, tmin, any_ray, hit, nt);
+          if (STATS) (any_ray ? st.atris : st.tris) += nt;
+          if (occ) {
+            state = kStDoneOccluded;
+            if (STATS) st.ahist[steps <= 16u ? 0 : (28 - __clz(steps - 1u) > 7 ? 7 : 28 - __clz(steps - 1u))]++, st.amax_steps = steps > st.amax_steps ? steps : st.amax_steps;
+          } else {
+            advance = true;
+          }
+        }
+      } else if (CURVES && state == kStCurve) {
+        // ---- CURVE phase: one linear piece of the leaf (D0 D1 D2 = P0 P1 P2, D3 = codes | piece indices | count): piece 0 = P0 P1,
+        // then -- a second turn -- piece 1 = P1 P2
+        if (STATS) steps++, (any_ray ? st.acurves : st.curves)++;
+        const bool two = (oct & 8u) != 0u;  // this turn tests the leaf's second piece
+        const uint32_t meta = __float_as_uint(D3.z);
+        RayFrame f;
+        f.dn = V3(frame[0], frame[stride], frame[2 * stride]), f.bx = V3(frame[3 * stride], frame[4 * stride], frame[5 * stride]);
+        f.by = V3(frame[6 * stride], frame[7 * stride], frame[8 * stride]), f.inv_len = frame[9 * stride];
+        float t, u, v;
+        bool ok = segment_test(two ? D1 : D0, two ? D2 : D1, two ? ((meta >> 8) & 255u) : (meta & 255u), V3(o_x, o_y, o_z), f, V3(inv4.x, inv4.y, inv4.z), tmin, hit.t, t, u, v);
+        const uint32_t code = __float_as_uint(two ? D3.y : D3.x);
+        if (ok && !any_ray && t == hit.t && hit.slot != kNone) ok = q_gid(sc, code) < q_gid(sc, hit.slot);  // tie: the smaller canonical id wins
+        if (ok) hit.t = t, hit.u = u, hit.v = v, hit.slot = code;
+        if (any_ray && ok) {
+          state = kStDoneOccluded, oct &= 7u;
           if (STATS) st.ahist[steps <= 16u ? 0 : (28 - __clz(steps - 1u) > 7 ? 7 : 28 - __clz(steps - 1u))]++, st.amax_steps = steps > st.amax_steps ? steps : st.amax_steps;
+        } else if (!two && (meta >> 16) != 0u) {
+          oct |= 8u;  // the second piece of the same leaf: no load
         } else {
+          oct &= 7u;
           advance = true;
         }
       }
@@ -273,10 +331,10 @@ __device__ __forceinline__ void trace_pv8(const DScene& sc, uint32_t n, uint32_t
       if (advance) {
         const uint32_t k = (uint32_t)__builtin_ctz(g_bits);  // (the low byte is not empty)
         g_bits &= g_bits - 1u;
-        const uint32_t s = k ^ oct;
-        const uint32_t present = (g_bits >> 8) & 255u;
-        cur = g_base + (uint32_t)__builtin_popcount(present & ((1u << s) - 1u));
-        state = ((g_bits >> (16u + s)) & 1u) ? kStTri : kStNode;
+        const uint32_t s = k ^ (oct & 7u), below = (1u << s) - 1u;
+        const uint32_t five = ((g_bits >> 8) | (g_bits >> 16)) & below & 255u, four = (g_bits >> 24) & below;
+        cur = g_base + 5u * (uint32_t)__builtin_popcount(five) + (CURVES ? 4u * (uint32_t)__builtin_popcount(four) : 0u);
+        state = ((g_bits >> (16u + s)) & 1u) ? kStTri : ((CURVES && ((g_bits >> (24u + s)) & 1u)) ? kStCurve : kStNode);
         need_load = true;
       }
     }
@@ -287,8 +345,9 @@ __device__ __forceinline__ void trace_pv8(const DScene& sc, uint32_t n, uint32_t
     }
 #endif
     if (need_load) {
-      const float4* g = items + (size_t)cur * kNode8Words;
-      D0 = g[0], D1 = g[1], D2 = g[2], D3 = g[3], D4 = g[4];
+      const float4* g = items + cur;
+      D0 = g[0], D1 = g[1], D2 = g[2], D3 = g[3];
+      if (!CURVES || state != kStCurve) D4 = g[4];
     }
   }
   if constexpr (!Sink::kWalk) {

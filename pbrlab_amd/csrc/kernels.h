@@ -80,7 +80,9 @@ enum : uint32_t {
   kStatTailClosestRays, kStatTailShadowRays, kStatPrunedRays,
   kStatStepHist0, kStatStepHistLast = kStatStepHist0 + 7, kStatMaxSteps, kStatMaxWaveIters,
   kStatWalkNodes, kStatWalkTris, kStatWalkTurns, kStatWalkSteps,
-  kStatAnyHist0, kStatAnyHistLast = kStatAnyHist0 + 7, kStatAnyMaxSteps, kStatNum
+  kStatAnyHist0, kStatAnyHistLast = kStatAnyHist0 + 7, kStatAnyMaxSteps,
+  kStatCycNode, kStatCycTri, kStatCycCurve, kStatCycRefill,  // shader-clock cycles of the phase-voting waves' loop turns by what the turn did (lane 0 of every wave)
+  kStatNum
 };
 
 // Resident 256-thread blocks per CU of the persistent traversal kernel = waves per SIMD (VGPR budget 512 / waves).
@@ -104,45 +106,11 @@ constexpr uint32_t trace_blocks_per_cu(bool curves, bool wide) {
   return wide ? (curves ? kTraceBlocksPerCUWideCurves : kTraceBlocksPerCUWide) : (curves ? kTraceBlocksPerCUCurves : kTraceBlocksPerCU);
 }
 constexpr uint32_t kTraceGridCap = 256 * (kTraceBlocksPerCU > kTraceBlocksPerCUCurves ? kTraceBlocksPerCU : kTraceBlocksPerCUCurves);  // persistent traversal: at most the resident blocks (sizes the spill area)
-// The two-rays-per-lane traversal (dtrace_pv2.h, Q tree): blocks per CU (each wave carries 128 rays) and the LDS part of a ray's stack
-#ifndef PB_TRACE2_BLOCKS
-#define PB_TRACE2_BLOCKS 5
-#endif
-#ifndef PB_TRACE2_BLOCKS_CURVES
-#define PB_TRACE2_BLOCKS_CURVES 3
-#endif
-#ifndef PB_LDS_STACK2
-#define PB_LDS_STACK2 12
-#endif
-constexpr int kPv2LdsStack = PB_LDS_STACK2;  // stack entries per RAY kept in LDS
-constexpr uint32_t trace2_blocks_per_cu(bool curves) { return curves ? PB_TRACE2_BLOCKS_CURVES : PB_TRACE2_BLOCKS; }
-constexpr uint32_t kTrace2GridCap = 256 * (PB_TRACE2_BLOCKS > PB_TRACE2_BLOCKS_CURVES ? PB_TRACE2_BLOCKS : PB_TRACE2_BLOCKS_CURVES);
 // words of traversal-stack spill area one path group (or one hook call) needs: every resident thread of the largest traversal
-// grid x the entries of its stack(s) that do not live in LDS (the one-ray-per-lane kernels -- k_tail, the simple hooks -- run
-// smaller grids: (kStackDepth - kSimpleLdsStack) x 4096 x 256 and x PB_TAIL_BLOCKS x 256)
-constexpr size_t kSpillWordsPv = (size_t)kStackDepth * kTraceGridCap * 256;
-constexpr size_t kSpillWordsPv2 = (size_t)2 * (kStackDepth - kPv2LdsStack) * kTrace2GridCap * 256;
-// The wave-pooled traversal (dtrace_wp.h): rays per wave, stack entries per ray in LDS, blocks of four waves per CU, and the
-// number of finished / free slots at which a wave delivers and fetches
-#ifndef PB_WP_RAYS
-#define PB_WP_RAYS 152
-#endif
-#ifndef PB_WP_STACK
-#define PB_WP_STACK 8
-#endif
-#ifndef PB_WP_BLOCKS
-#define PB_WP_BLOCKS 3
-#endif
-#ifndef PB_WP_REFILL
-#define PB_WP_REFILL 64
-#endif
-constexpr uint32_t kWpRays = PB_WP_RAYS;        // rays per wave (<= 256: tickets are bytes)
-constexpr int kWpStack = PB_WP_STACK;           // stack entries per ray in LDS (deeper ones: the global spill area)
-constexpr uint32_t kWpRefillAt = PB_WP_REFILL;  // deliver / fetch when this many slots are finished or free
-
-constexpr size_t kSpillWordsWp = (size_t)(kStackDepth - kWpStack) * 256 * PB_WP_BLOCKS * 4 * kWpRays;
-constexpr size_t kSpillWords0 = kSpillWordsPv > kSpillWordsPv2 ? kSpillWordsPv : kSpillWordsPv2;
-constexpr size_t kSpillWords = kSpillWords0 > kSpillWordsWp ? kSpillWords0 : kSpillWordsWp;
+// grid x the entries of its stack that do not live in LDS (the one-ray-per-lane kernels -- k_tail, the simple hooks -- run
+// smaller grids: (kStackDepth - kSimpleLdsStack) x 4096 x 256 and x PB_TAIL_BLOCKS x 256; the O tree's kernels keep 8-byte
+// entries, at most kStackDepth words per thread: dtrace_pv8.h)
+constexpr size_t kSpillWords = (size_t)kStackDepth * kTraceGridCap * 256;
 static_assert((size_t)(kStackDepth - kSimpleLdsStack) * 4096 * 256 <= kSpillWords, "spill area of the one-ray-per-lane hook grids (grid_for(n, 4096))");
 constexpr uint32_t kShadeGridCap = 256 * 8;
 constexpr int kMaxGroups = 8;

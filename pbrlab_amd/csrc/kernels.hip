@@ -20,8 +20,6 @@
 #include "kernels.h"
 #include "dtrace_pv.h"
 #include "dtrace_pv8.h"
-#include "dtrace_pv2.h"
-#include "dtrace_wp.h"
 #include "dtrace_quad.h"
 
 namespace pb {
@@ -147,22 +145,6 @@ struct TraceSinkT {
     tag |= 0x80000000u;
     return true;
   }
-  // the wave-pooled traversal (dtrace_wp.h): the direction again, a new nearest hit written through, the end of the ray
-  static constexpr bool kKeepUV = false;
-  __device__ __forceinline__ V3 dir(uint32_t tag) const {
-    const uint32_t p = tag & 0x7FFFFFFFu;
-    return ld3((tag & 0x80000000u) ? P.sh_d[p] : P.ray_d[p]);
-  }
-  __device__ __forceinline__ void accept(uint32_t tag, float t, float u, float v, uint32_t code) const {
-    P.hit[tag & 0x7FFFFFFFu] = make_float4(t, u, v, __uint_as_float(code));
-  }
-  __device__ __forceinline__ void finish(uint32_t tag, const Hit& h, bool occluded) const {
-    if (!(tag & 0x80000000u)) {
-      if (h.slot == kNone) P.hit[tag] = make_float4(h.t, 0.f, 0.f, __uint_as_float(kNone));  // (a hit is in the record already: accept)
-      return;
-    }
-    done(tag, h, occluded);
-  }
   __device__ __forceinline__ void done(uint32_t tag, const Hit& h, bool occluded) const {
     const uint32_t p = tag & 0x7FFFFFFFu;
     if (!(tag & 0x80000000u)) {
@@ -205,6 +187,9 @@ __device__ __forceinline__ void trace_stats_out(const PathState& P, const TravSt
     }
     atomicMax(&P.stats[kStatAnyMaxSteps], (unsigned long long)st.amax_steps);
     atomicMax(&P.stats[kStatMaxSteps], (unsigned long long)st.max_steps);
+    if (__lane_id() == 0)
+      for (int i = 0; i < 4; i++)
+        if (st.cyc[i]) atomicAdd(&P.stats[kStatCycNode + i], st.cyc[i]);
     if (__lane_id() == 0) atomicMax(&P.stats[kStatMaxWaveIters], (unsigned long long)(st.it_node + st.it_tri + st.it_curve + st.it_refill));
     if (threadIdx.x == 0 && blockIdx.x == 0) {
       atomicAdd(&P.stats[kStatClosestRays], (unsigned long long)n_closest);
@@ -247,23 +232,28 @@ __global__ __launch_bounds__(kBlock, trace_blocks_per_cu(CURVES, WIDE) - (FIRST 
   if (STATS) trace_stats_out(P, st, n_closest, n_shadow);
 }
 
-// The same launch over the O tree (dtrace_pv8.h: eight children per node, 80-byte items, octant-ordered visits, one stack entry
-// per node): triangle-only scenes whose tree was built on the host (DScene::wide8).  PBRHIP_WIDE8=0 selects the Q tree (read per launch).
+// The same launch over the O tree (dtrace_pv8.h: eight children per node, nodes and leaves in one array, octant-ordered visits, one
+// stack entry per node): scenes whose tree was built on the host (DScene::wide8).  PBRHIP_WIDE8 selects it (read per launch).
 #ifndef PB_TRACE_BLOCKS_WIDE8
-#define PB_TRACE_BLOCKS_WIDE8 6
+#define PB_TRACE_BLOCKS_WIDE8 5  // (A/B on C2, 16 spp: 6 blocks per CU with 10 LDS stack entries 13.4 ms -- the tree is deeper than that and the spill path is slow --, 5 blocks with 13: 11.3-11.5, 4: 11.6)
 #endif
-constexpr uint32_t kTraceBlocksPerCUWide8 = PB_TRACE_BLOCKS_WIDE8;
-static_assert(kTraceBlocksPerCUWide8 * 256u <= kTraceGridCap, "the O tree's k_trace grid fits the spill area sized by kTraceGridCap");
-template <bool STATS, bool FIRST = false>
-__global__ __launch_bounds__(kBlock, kTraceBlocksPerCUWide8 - (FIRST ? 1 : 0)) void k_trace8(PathState P, DScene sc) {
-  __shared__ uint2 stk[kPv8LdsStack * kBlock];
+#ifndef PB_TRACE_BLOCKS_WIDE8_CURVES
+#define PB_TRACE_BLOCKS_WIDE8_CURVES 5
+#endif
+constexpr uint32_t trace8_blocks_per_cu(bool curves) { return curves ? PB_TRACE_BLOCKS_WIDE8_CURVES : PB_TRACE_BLOCKS_WIDE8; }
+static_assert(trace8_blocks_per_cu(false) * 256u <= kTraceGridCap && trace8_blocks_per_cu(true) * 256u <= kTraceGridCap, "the O tree's k_trace grids fit the spill area sized by kTraceGridCap");
+template <bool STATS, bool CURVES, bool FIRST = false>
+__global__ __launch_bounds__(kBlock, trace8_blocks_per_cu(CURVES) - (FIRST ? 1 : 0)) void k_trace8(PathState P, DScene sc) {
+  __shared__ uint2 stk[(CURVES ? kPv8LdsStackCurves : kPv8LdsStack) * kBlock];
+  __shared__ float frm[CURVES ? 10 * kBlock : 1];
   const uint32_t n_closest = P.counts[kCntIn], n_shadow = P.counts[kCntShadowIn];
   TravStats st = {};
   uint32_t overflow = 0u;
-  TraceSinkT<false, FIRST> sink = {P, n_closest};
+  TraceSinkT<CURVES, FIRST> sink = {P, n_closest};
   const unsigned long long t_start = P.wave_log ? wall_clock64() : 0ull;
-  trace_pv8<FIRST ? 0 : 2, STATS>(sc, n_closest + (FIRST ? 0u : n_shadow), &P.counts[kCntHead], sink, stk + threadIdx.x, kBlock,
-                                  reinterpret_cast<uint2*>(P.spill) + blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, st, &overflow);
+  trace_pv8<FIRST ? 0 : 2, STATS, CURVES>(sc, n_closest + (FIRST ? 0u : n_shadow), &P.counts[kCntHead], sink, stk + threadIdx.x, kBlock,
+                                          reinterpret_cast<uint2*>(P.spill) + blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, st, &overflow,
+                                          CURVES ? frm + threadIdx.x : nullptr);
   if (overflow) P.counts[kCntOverflow] = 1u;
   if (P.wave_log && __lane_id() == 0 && P.wave_log_launch < kWaveLogLaunches) {
     const uint32_t w = (blockIdx.x * kBlock + threadIdx.x) >> 6;
@@ -300,48 +290,6 @@ __global__ __launch_bounds__(kBlock) void k_trace_quad(PathState P, DScene sc) {
   if (STATS) {
     TravStats st = {};
     trace_stats_out(P, st, n_closest, n_shadow);
-  }
-}
-
-// The same launch on the two-rays-per-lane traversal (dtrace_pv2.h; Q tree only): fewer waves per SIMD, each carrying 128 rays.
-template <bool STATS, bool CURVES>
-__global__ __launch_bounds__(kBlock, trace2_blocks_per_cu(CURVES)) void k_trace2(PathState P, DScene sc) {
-  __shared__ uint32_t stk[2 * kPv2LdsStack * kBlock];
-  __shared__ float frm[CURVES ? 20 * kBlock : 1];
-  constexpr bool kStageTop = !CURVES && kTopNodesWide > 0;
-  __shared__ float4 top[kStageTop ? kTopNodesWide * 4 : 1];
-  const uint32_t ntop = kStageTop ? (sc.wide_top_nodes < (uint32_t)kTopNodesWide ? sc.wide_top_nodes : (uint32_t)kTopNodesWide) : 0u;
-  if (kStageTop) {
-    for (uint32_t i = threadIdx.x; i < ntop * 4u; i += kBlock) top[i] = sc.wide[i];
-    __syncthreads();
-  }
-  const uint32_t n_closest = P.counts[kCntIn], n_shadow = P.counts[kCntShadowIn];
-  TravStats st = {};
-  uint32_t overflow = 0u;
-  TraceSinkT<CURVES> sink = {P, n_closest};
-  trace_pv2<2, STATS, CURVES>(sc, n_closest + n_shadow, &P.counts[kCntHead], sink, stk + threadIdx.x, kBlock,
-                              P.spill + blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, st, &overflow,
-                              CURVES ? frm + threadIdx.x : nullptr, top, ntop);
-  if (overflow) P.counts[kCntOverflow] = 1u;
-  if (STATS) trace_stats_out(P, st, n_closest, n_shadow);
-}
-
-// The same launch on the wave-pooled traversal (dtrace_wp.h; Q tree, triangle-only scenes): every wave owns kWpRays rays in
-// its slice of LDS and steps them in full batches of one phase.
-static_assert((size_t)(kStackDepth - kWpStack) * 256 * PB_WP_BLOCKS * 4 * kWpRays <= kSpillWords, "spill area of the wave-pooled traversal");
-static_assert(sizeof(WavePool<false>) * 4 * PB_WP_BLOCKS <= 160 * 1024, "PB_WP_BLOCKS blocks of four wave pools per CU");
-__global__ __launch_bounds__(kBlock, PB_WP_BLOCKS) void k_trace_wp(PathState P, DScene sc) {
-  __shared__ WavePool<false> pools[kBlock / 64];
-  const uint32_t n_closest = P.counts[kCntIn], n_shadow = P.counts[kCntShadowIn];
-  uint32_t overflow = 0u;
-  TraceSinkT<false> sink = {P, n_closest};
-  const uint32_t wave = threadIdx.x >> 6, gwave = blockIdx.x * (kBlock / 64) + wave, nwaves = gridDim.x * (kBlock / 64);
-  trace_wp<2, false>(sc, n_closest + n_shadow, &P.counts[kCntHead], sink, pools[wave], P.spill + (size_t)gwave * kWpRays, nwaves * kWpRays,
-                     &overflow, P.stats);
-  if (overflow) P.counts[kCntOverflow] = overflow;
-  if (P.stats && threadIdx.x == 0 && blockIdx.x == 0) {
-    atomicAdd(&P.stats[kStatClosestRays], (unsigned long long)n_closest);
-    atomicAdd(&P.stats[kStatShadowRays], (unsigned long long)n_shadow);
   }
 }
 
@@ -1238,16 +1186,18 @@ __global__ __launch_bounds__(kBlock, PB_WALK_WAVES) void k_sss_walk(PathState P,
 }
 
 // ... and over the O tree (dtrace_pv8.h)
-template <bool STATS>
+template <bool STATS, bool CURVES>
 __global__ __launch_bounds__(kBlock, PB_WALK_WAVES) void k_sss_walk8(PathState P, DScene sc, uint64_t rng_inc) {
-  __shared__ uint2 stk[kPv8LdsStack * kBlock];
+  __shared__ uint2 stk[(CURVES ? kPv8LdsStackCurves : kPv8LdsStack) * kBlock];
+  __shared__ float frm[CURVES ? 10 * kBlock : 1];
   __shared__ float walk[kWalkWords * kBlock];
   const uint32_t n = P.counts[kCntSss];
   TravStats st = {};
   uint32_t overflow = 0u;
   WalkSink sink = {P, rng_inc, walk + threadIdx.x, 0u};
-  trace_pv8<0, STATS>(sc, n, &P.counts[kCntWalkHead], sink, stk + threadIdx.x, kBlock,
-                      reinterpret_cast<uint2*>(P.spill) + blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, st, &overflow);
+  trace_pv8<0, STATS, CURVES>(sc, n, &P.counts[kCntWalkHead], sink, stk + threadIdx.x, kBlock,
+                              reinterpret_cast<uint2*>(P.spill) + blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, st, &overflow,
+                              CURVES ? frm + threadIdx.x : nullptr);
   if (overflow) P.counts[kCntOverflow] = 1u;
   if (STATS) {
     const uint32_t a = wave_sum(sink.n_rays), nn = wave_sum(st.nodes), nt = wave_sum(st.tris + st.curves);
@@ -1492,11 +1442,6 @@ struct HookSink {
     if (occ) occ[i] = occluded ? 1 : 0;
     else hits[i] = hook_result(sc, ld3(rays[2 * i]), ld3(rays[2 * i + 1]), h);
   }
-  // the wave-pooled traversal (dtrace_wp.h) keeps this sink's (u, v) and hands over the whole hit at the end
-  static constexpr bool kKeepUV = true;
-  __device__ __forceinline__ V3 dir(uint32_t i) const { return ld3(rays[2 * i + 1]); }
-  __device__ __forceinline__ void accept(uint32_t, float, float, float, uint32_t) const {}
-  __device__ __forceinline__ void finish(uint32_t i, const Hit& h, bool occluded) const { done(i, h, occluded); }
 };
 template <bool ANY, bool CURVES, bool WIDE>  // CURVES / WIDE: the variant k_trace runs for this scene (the Q tree, with or without curves)
 __global__ __launch_bounds__(kBlock) void k_hook_pv(DScene sc, const float4* __restrict__ rays, uint32_t n, HookHit* hits,
@@ -1510,26 +1455,17 @@ __global__ __launch_bounds__(kBlock) void k_hook_pv(DScene sc, const float4* __r
                              spill + blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, st, &overflow, CURVES ? frm + threadIdx.x : nullptr);
   if (overflow) counts[kCntOverflow] = 1u;
 }
-template <bool ANY>  // the O tree (dtrace_pv8.h): the variant k_trace8 runs
+template <bool ANY, bool CURVES>  // the O tree (dtrace_pv8.h): the variant k_trace8 runs
 __global__ __launch_bounds__(kBlock) void k_hook_pv8(DScene sc, const float4* __restrict__ rays, uint32_t n, HookHit* hits, uint8_t* occ, uint32_t* counts,
                                                      uint32_t* spill) {
-  __shared__ uint2 stk[kPv8LdsStack * kBlock];
+  __shared__ uint2 stk[(CURVES ? kPv8LdsStackCurves : kPv8LdsStack) * kBlock];
+  __shared__ float frm[CURVES ? 10 * kBlock : 1];
   TravStats st = {};
   uint32_t overflow = 0u;
   HookSink sink = {sc, rays, hits, occ};
-  trace_pv8<ANY ? 1 : 0, false>(sc, n, &counts[kCntHead], sink, stk + threadIdx.x, kBlock, reinterpret_cast<uint2*>(spill) + blockIdx.x * kBlock + threadIdx.x,
-                                gridDim.x * kBlock, st, &overflow);
+  trace_pv8<ANY ? 1 : 0, false, CURVES>(sc, n, &counts[kCntHead], sink, stk + threadIdx.x, kBlock, reinterpret_cast<uint2*>(spill) + blockIdx.x * kBlock + threadIdx.x,
+                                        gridDim.x * kBlock, st, &overflow, CURVES ? frm + threadIdx.x : nullptr);
   if (overflow) counts[kCntOverflow] = 1u;
-}
-template <bool ANY>
-__global__ __launch_bounds__(kBlock, 2) void k_hook_wp(DScene sc, const float4* __restrict__ rays, uint32_t n, HookHit* hits, uint8_t* occ,
-                                                      uint32_t* counts, uint32_t* spill) {
-  __shared__ WavePool<true> pools[kBlock / 64];
-  uint32_t overflow = 0u;
-  HookSink sink = {sc, rays, hits, occ};
-  const uint32_t wave = threadIdx.x >> 6, gwave = blockIdx.x * (kBlock / 64) + wave, nwaves = gridDim.x * (kBlock / 64);
-  trace_wp<ANY ? 1 : 0, true>(sc, n, &counts[kCntHead], sink, pools[wave], spill + (size_t)gwave * kWpRays, nwaves * kWpRays, &overflow);
-  if (overflow) counts[kCntOverflow] = overflow;
 }
 // One ray per thread, plain stack traversal (dtrace.h): an independent second implementation, selected with
 // PBRHIP_SIMPLE_TRAVERSAL=1, that must agree with the production traversal bit for bit.
@@ -1610,23 +1546,18 @@ static inline bool use_wide(const DScene& sc) {
     else hipLaunchKernelGGL((KERNEL<PRE, false, false>), __VA_ARGS__);                          \
   } while (0)
 bool trace_uses_wide(const DScene& sc) { return use_wide(sc); }
-// the O tree (8-wide, dtrace_pv8.h) serves k_trace, k_sss_walk and the phase-voting hooks of the triangle-only scenes that have one (PBRHIP_WIDE8=0: never; read per launch)
+// the O tree (8-wide, dtrace_pv8.h) serves k_trace, k_sss_walk and the phase-voting hooks of the scenes that have one (PBRHIP_WIDE8=0 / 1: never / always; read per launch)
+#ifndef PB_WIDE8_DEFAULT
+#define PB_WIDE8_DEFAULT 0         // triangle-only scenes: measured equal to the Q tree (profiles/README.md)
+#endif
+#ifndef PB_WIDE8_DEFAULT_CURVES
+#define PB_WIDE8_DEFAULT_CURVES 0  // scenes with curves: measured 11 % slower than the Q tree on C4 (10.0 instead of 14.2 node visits per ray, but 1.5x the instructions per visit and 7.2 instead of 6.6 piece tests)
+#endif
 static inline bool use_wide8(const DScene& sc) {
   const char* e = getenv("PBRHIP_WIDE8");
-  return sc.wide8 != nullptr && sc.num_curves == 0 && use_wide(sc) && !(e && atoi(e) == 0);
+  return sc.wide8 != nullptr && use_wide(sc) && (e ? atoi(e) != 0 : (sc.num_curves != 0 ? PB_WIDE8_DEFAULT_CURVES != 0 : PB_WIDE8_DEFAULT != 0));
 }
 bool trace_uses_wide8(const DScene& sc) { return use_wide8(sc); }
-// the two-rays-per-lane traversal (dtrace_pv2.h) serves the Q tree; PBRHIP_TRACE2=0: one ray per lane (read per launch)
-#ifndef PB_TRACE2_DEFAULT
-#define PB_TRACE2_DEFAULT 0
-#endif
-#ifndef PB_TRACE2_DEFAULT_CURVES
-#define PB_TRACE2_DEFAULT_CURVES 0
-#endif
-// the wave-pooled traversal (dtrace_wp.h): PBRHIP_TRACEWP=0/1 (read per launch)
-#ifndef PB_TRACEWP_DEFAULT
-#define PB_TRACEWP_DEFAULT 0
-#endif
 #ifndef PB_TRACE_SMALL1_RAYS
 #define PB_TRACE_SMALL1_RAYS 16000000u  // launches of at most this many rays (upper bound): PB_TRACE_SMALL1_BLOCKS blocks per CU
 #define PB_TRACE_SMALL1_BLOCKS 4u
@@ -1643,14 +1574,6 @@ static inline uint32_t quad_rays() {
 static inline bool use_quad() {
   const char* e = getenv("PBRHIP_QUAD");
   return e && e[0] == '1';
-}
-static inline bool use_wave_pool() {
-  const char* e = getenv("PBRHIP_TRACEWP");
-  return e ? atoi(e) != 0 : PB_TRACEWP_DEFAULT != 0;
-}
-static inline bool use_two_rays(bool curves) {
-  const char* e = getenv("PBRHIP_TRACE2");
-  return e ? atoi(e) != 0 : (curves ? PB_TRACE2_DEFAULT_CURVES != 0 : PB_TRACE2_DEFAULT != 0);
 }
 static inline uint32_t grid_for(uint32_t n, uint32_t cap) {
   uint32_t g = (n + kBlock - 1) / kBlock;
@@ -1692,19 +1615,25 @@ void launch_trace(hipStream_t s, const PathState& P, const DScene& sc, uint32_t 
     if (n_upper <= PB_TRACE_SMALL2_RAYS) cap = std::min(cap, 256u * PB_TRACE_SMALL2_BLOCKS);
     else if (n_upper <= PB_TRACE_SMALL1_RAYS) cap = std::min(cap, 256u * PB_TRACE_SMALL1_BLOCKS);
   }
-  const bool wide8 = use_wide8(sc) && !use_wave_pool() && !use_two_rays(false) && (P.first || n_upper > quad_rays());
+  const bool wide8 = use_wide8(sc) && (P.first || curves || n_upper > quad_rays());
   if (wide8) {
-    // (the resident-block rules of the Q tree's kernel; its launch bounds allow kTraceBlocksPerCUWide8)
-    cap = std::min(cap, 256u * kTraceBlocksPerCUWide8);
+    // (the resident-block rules of the Q tree's kernel; its launch bounds allow trace8_blocks_per_cu)
+    cap = std::min(cap, 256u * trace8_blocks_per_cu(curves));
     if (P.first) cap = std::max(cap, 512u) - 256u;
     const dim3 g8(blocks < 1u ? 1u : (blocks < cap ? blocks : cap));
+#define PB_LAUNCH8(ST, FI)                                                                       \
+  do {                                                                                           \
+    if (curves) hipLaunchKernelGGL((k_trace8<ST, true, FI>), g8, dim3(kBlock), 0, s, P, sc);     \
+    else hipLaunchKernelGGL((k_trace8<ST, false, FI>), g8, dim3(kBlock), 0, s, P, sc);           \
+  } while (0)
     if (P.first) {
-      if (stats) hipLaunchKernelGGL((k_trace8<true, true>), g8, dim3(kBlock), 0, s, P, sc);
-      else hipLaunchKernelGGL((k_trace8<false, true>), g8, dim3(kBlock), 0, s, P, sc);
+      if (stats) PB_LAUNCH8(true, true);
+      else PB_LAUNCH8(false, true);
     } else {
-      if (stats) hipLaunchKernelGGL((k_trace8<true, false>), g8, dim3(kBlock), 0, s, P, sc);
-      else hipLaunchKernelGGL((k_trace8<false, false>), g8, dim3(kBlock), 0, s, P, sc);
+      if (stats) PB_LAUNCH8(true, false);
+      else PB_LAUNCH8(false, false);
     }
+#undef PB_LAUNCH8
     return;
   }
   if (P.first) {
@@ -1728,26 +1657,6 @@ void launch_trace(hipStream_t s, const PathState& P, const DScene& sc, uint32_t 
     const dim3 gq(quad_grid(n_upper));
     if (stats) hipLaunchKernelGGL((k_trace_quad<true>), gq, dim3(kBlock), 0, s, P, sc);
     else hipLaunchKernelGGL((k_trace_quad<false>), gq, dim3(kBlock), 0, s, P, sc);
-    return;
-  }
-  if (wide && !curves && use_wave_pool()) {
-    const uint32_t nb = (n_upper + 4u * rays_per_wave - 1u) / (4u * rays_per_wave), capw = 256u * PB_WP_BLOCKS;
-    hipLaunchKernelGGL(k_trace_wp, dim3(nb < 1u ? 1u : (nb < capw ? nb : capw)), dim3(kBlock), 0, s, P, sc);
-    return;
-  }
-  if (wide && use_two_rays(curves)) {
-    // two rays per lane: a wave carries 128 rays (dtrace_pv2.h)
-    blocks = (n_upper + 8u * rays_per_wave - 1u) / (8u * rays_per_wave);
-    cap = 256u * trace2_blocks_per_cu(curves);
-    if (const char* b = getenv("PBRHIP_TRACE2_BLOCKS")) {
-      const uint32_t k = (uint32_t)strtoul(b, nullptr, 10);
-      if (k >= 1u && 256u * k < cap) cap = 256u * k;
-    }
-    dim3 g2(blocks < 1u ? 1u : (blocks < cap ? blocks : cap));
-    if (stats && curves) hipLaunchKernelGGL((k_trace2<true, true>), g2, dim3(kBlock), 0, s, P, sc);
-    else if (stats) hipLaunchKernelGGL((k_trace2<true, false>), g2, dim3(kBlock), 0, s, P, sc);
-    else if (curves) hipLaunchKernelGGL((k_trace2<false, true>), g2, dim3(kBlock), 0, s, P, sc);
-    else hipLaunchKernelGGL((k_trace2<false, false>), g2, dim3(kBlock), 0, s, P, sc);
     return;
   }
   dim3 g(blocks < 1u ? 1u : (blocks < cap ? blocks : cap));
@@ -1785,8 +1694,10 @@ void launch_sss_walk(hipStream_t s, const PathState& P, const DScene& sc, uint32
   const char* ww = getenv("PBRHIP_WIDE_WALK");
   const bool wide = use_wide(sc) && !(ww && atoi(ww) == 0);
   if (wide && use_wide8(sc)) {
-    if (stats) hipLaunchKernelGGL((k_sss_walk8<true>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
-    else hipLaunchKernelGGL((k_sss_walk8<false>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
+    if (stats && curves) hipLaunchKernelGGL((k_sss_walk8<true, true>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
+    else if (stats) hipLaunchKernelGGL((k_sss_walk8<true, false>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
+    else if (curves) hipLaunchKernelGGL((k_sss_walk8<false, true>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
+    else hipLaunchKernelGGL((k_sss_walk8<false, false>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
     return;
   }
   if (stats) PB_LAUNCH_TRAV(k_sss_walk, true, curves, wide, g, dim3(kBlock), 0, s, P, sc, rng_inc);
@@ -1840,14 +1751,10 @@ void launch_hook_closest(hipStream_t s, const DScene& sc, const float4* rays, ui
     hipLaunchKernelGGL((k_hook_quad<false>), dim3(quad_grid(n)), dim3(kBlock), 0, s, sc, rays, n, out, (uint8_t*)nullptr, counts + kCntOverflow, spill);
     return;
   }
-  if (wide && !curves && use_wave_pool()) {
-    const uint32_t nb = (n + 255u) / 256u;
-    hipLaunchKernelGGL((k_hook_wp<false>), dim3(nb < 1u ? 1u : (nb < 512u ? nb : 512u)), dim3(kBlock), 0, s, sc, rays, n, out, (uint8_t*)nullptr, counts, spill);
-    return;
-  }
   const dim3 g(grid_for(n, kTraceGridCap));
   if (use_wide8(sc)) {
-    hipLaunchKernelGGL((k_hook_pv8<false>), g, dim3(kBlock), 0, s, sc, rays, n, out, (uint8_t*)nullptr, counts, spill);
+    if (sc.num_curves) hipLaunchKernelGGL((k_hook_pv8<false, true>), g, dim3(kBlock), 0, s, sc, rays, n, out, (uint8_t*)nullptr, counts, spill);
+    else hipLaunchKernelGGL((k_hook_pv8<false, false>), g, dim3(kBlock), 0, s, sc, rays, n, out, (uint8_t*)nullptr, counts, spill);
     return;
   }
   if (wide && curves) hipLaunchKernelGGL((k_hook_pv<false, true, true>), g, dim3(kBlock), 0, s, sc, rays, n, out, (uint8_t*)nullptr, counts, spill);
@@ -1867,14 +1774,10 @@ void launch_hook_any(hipStream_t s, const DScene& sc, const float4* rays, uint32
     hipLaunchKernelGGL((k_hook_quad<true>), dim3(quad_grid(n)), dim3(kBlock), 0, s, sc, rays, n, (HookHit*)nullptr, out, counts + kCntOverflow, spill);
     return;
   }
-  if (wide && !curves && use_wave_pool()) {
-    const uint32_t nb = (n + 255u) / 256u;
-    hipLaunchKernelGGL((k_hook_wp<true>), dim3(nb < 1u ? 1u : (nb < 512u ? nb : 512u)), dim3(kBlock), 0, s, sc, rays, n, (HookHit*)nullptr, out, counts, spill);
-    return;
-  }
   const dim3 g(grid_for(n, kTraceGridCap));
   if (use_wide8(sc)) {
-    hipLaunchKernelGGL((k_hook_pv8<true>), g, dim3(kBlock), 0, s, sc, rays, n, (HookHit*)nullptr, out, counts, spill);
+    if (sc.num_curves) hipLaunchKernelGGL((k_hook_pv8<true, true>), g, dim3(kBlock), 0, s, sc, rays, n, (HookHit*)nullptr, out, counts, spill);
+    else hipLaunchKernelGGL((k_hook_pv8<true, false>), g, dim3(kBlock), 0, s, sc, rays, n, (HookHit*)nullptr, out, counts, spill);
     return;
   }
   if (wide && curves) hipLaunchKernelGGL((k_hook_pv<true, true, true>), g, dim3(kBlock), 0, s, sc, rays, n, (HookHit*)nullptr, out, counts, spill);

@@ -637,16 +637,16 @@ def test_triangle_soup_and_ties(pa, seed, extra_slivers):
                 os.environ.pop("PBRHIP_SIMPLE_TRAVERSAL", None)
 
 
-@pytest.mark.parametrize("which", ["PBRHIP_TRACE2", "PBRHIP_TRACEWP", "PBRHIP_QUAD", "PBRHIP_WIDE8"])
+@pytest.mark.parametrize("which", ["PBRHIP_QUAD", "PBRHIP_WIDE8"])
 def test_alternative_traversals_bit_exact(pa, pairs, which):
-    """The two traversal kernels of round 4 that were measured and not selected -- two rays per lane (dtrace_pv2.h) and the
-    wave-pooled traversal (dtrace_wp.h) -- stay in the library behind PBRHIP_TRACE2 / PBRHIP_TRACEWP (read per launch): hits
-    do not depend on the visiting order, so soups (ties, slivers, tmax == hit distance) and whole renders are bit-identical.
-    PBRHIP_QUAD: one ray per quad of lanes (dtrace_quad.h) -- k_tail runs it by default once a wave has at most eight paths
-    left (the tail_paths=3000 renders below and every small render of this suite); here the hooks and every k_trace launch
+    """Alternative traversals behind environment switches (read per launch): hits do not depend on the visiting order, so soups (ties,
+    slivers, tmax == hit distance) and whole renders are bit-identical.
+    PBRHIP_QUAD: one ray per quad of lanes (dtrace_quad.h) -- k_tail runs it by default once a wave has at most eight paths left
+    (the tail_paths=3000 renders below and every small render of this suite); here the hooks and every k_trace launch
     (PBRHIP_QUAD_RAYS) run it as well.
-    PBRHIP_WIDE8 = 0 (round 5): k_trace, k_sss_walk and the hooks of triangle-only scenes on the 4-wide Q tree (dtrace_pv.h) instead of
-    the 8-wide O tree (dtrace_pv8.h) that is their default now -- every other test of this suite runs the O tree."""
+    PBRHIP_WIDE8 = 1 (round 5): k_trace, k_sss_walk and the hooks on the 8-wide O tree (dtrace_pv8.h: 80-byte nodes, octant-ordered
+    visits, one stack entry per node) instead of the 4-wide Q tree -- built, measured equal (triangles) or slower (hair) and left
+    off by default (profiles/README.md).  (Round 4's two-rays-per-lane and wave-pooled traversals were removed in round 5.)"""
     import _soups
     desc, so, rays = _soups.triangle_soup(2, 30)
     hb = so.trace_closest(rays, brute_force=True)
@@ -654,13 +654,13 @@ def test_alternative_traversals_bit_exact(pa, pairs, which):
     short["tmax"] = np.where(np.isfinite(hb["t"]) & (hb["instance_id"] != 0xFFFFFFFF), hb["t"], 1.0)
     ob = so.trace_any(short, brute_force=True)
     sg = pa.scene_from_desc(desc)
-    os.environ[which] = "0" if which == "PBRHIP_WIDE8" else "1"
+    os.environ[which] = "1"
     if which == "PBRHIP_QUAD":
         os.environ["PBRHIP_QUAD_RAYS"] = str(1 << 30)
     try:
         assert_hits_equal(sg.trace_closest(rays), hb)
         assert np.array_equal(sg.trace_any(short), ob)
-        for name in ("ggx", "sss") + (("hair",) if which == "PBRHIP_TRACE2" else ()):
+        for name in ("ggx", "sss") + (("hair",) if which == "PBRHIP_WIDE8" else ()):
             _, g, o = pairs[name]
             rgba, cnt, _ = o.render(96, 64, 4, threads=4, math_mode=O.MATH_F64R)
             for tail in (0xFFFFFFFF, 3000):

@@ -41,6 +41,10 @@ BUDGETS = {
     "k_tail<1, false, true, true>": (168, 184),    # media + curves (C5); 168 -> 184 B with the interleaved path-state records (round 4: C3 frame 327 -> 311 ms with them)
     "k_tail<2, false, false, true>": (168, 244),   # textured materials
     "k_trace_quad<false>": (128, 0),             # one ray per quad of lanes (small launches; off by default)
+    # the O tree's kernels (round 5, off by default): five blocks per CU (96 VGPRs), nothing spilled
+    "k_trace8<false, false, false>": (96, 0),
+    "k_trace8<false, true, false>": (96, 0),
+    "k_sss_walk8<false, false>": (168, 0),
     "k_shade_hair": (136, 0),
     "k_sss_step": (208, 0),  # 156 -> 201 VGPRs with the packed light pretest (round 4): 3.55 ms per 64 spp of C3 before and after
     "k_classify": (64, 0),
@@ -72,6 +76,33 @@ def kernel_table():
             cur[m.group(1)] = int(m.group(2))
     demangled = subprocess.run(["c++filt"] + list(table), check=True, capture_output=True, text=True).stdout.split("\n")
     return {d.replace("void pb::", "").replace("pb::", "").split("(")[0]: v for d, v in zip(demangled, table.values())}
+
+
+# Occupancy classes ("pin occupancy classes, not only raw numbers"): waves per SIMD a kernel's VGPR count allows on
+# gfx950 (512 registers per lane and SIMD, allocation granule 8: MI355X_MICROARCH.md) must not drop below what its launch bounds and
+# the measurements behind them assume -- a raised VGPR budget that crosses one of these lines is an occupancy regression, not a tweak.
+MIN_WAVES_PER_SIMD = {
+    "k_trace<false, false, false, false>": 7, "k_trace<false, true, false, false>": 6, "k_trace<false, false, true, false>": 6,
+    "k_trace<false, true, true, false>": 6, "k_trace<false, false, true, true>": 5, "k_trace<false, true, true, true>": 5,
+    "k_sss_walk<false, false, true>": 3, "k_shade_principled<0>": 3, "k_shade_principled<1>": 3, "k_shade_principled<2>": 3,
+    "k_tail<0, false, false, true>": 3, "k_tail<1, false, false, true>": 3, "k_shade_hair": 3,
+    # k_sss_step runs at TWO waves per SIMD since round 4 (201 VGPRs with the packed light pretest): measured equal to the 156-VGPR
+    # kernel (3.55 ms per 64 spp of C3 before and after, profiles/README.md round 4) -- it waits on path-state gathers, not on issue
+    "k_sss_step": 2,
+    "k_classify": 8, "k_compact": 5,
+}
+
+
+def waves_per_simd(vgprs):
+    alloc = -(-vgprs // 8) * 8
+    return min(8, 512 // alloc)
+
+
+def test_hot_kernels_keep_their_occupancy_class():
+    table = kernel_table()
+    for name, waves in MIN_WAVES_PER_SIMD.items():
+        assert name in table, name
+        assert waves_per_simd(table[name]["vgpr_count"]) >= waves, (name, table[name], waves)
 
 
 def test_hot_kernels_stay_within_their_budgets():
