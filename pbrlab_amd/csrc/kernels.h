@@ -81,7 +81,7 @@ enum : uint32_t {
   kStatStepHist0, kStatStepHistLast = kStatStepHist0 + 7, kStatMaxSteps, kStatMaxWaveIters,
   kStatWalkNodes, kStatWalkTris, kStatWalkTurns, kStatWalkSteps,
   kStatAnyHist0, kStatAnyHistLast = kStatAnyHist0 + 7, kStatAnyMaxSteps,
-  kStatCycNode, kStatCycTri, kStatCycCurve, kStatCycRefill,  // shader-clock cycles of the phase-voting waves' loop turns by what the turn did (lane 0 of every wave)
+  kStatCycNode, kStatCycTri, kStatCycCurve, kStatCycRefill, kStatWalkCycTrav, kStatWalkCycStep,  // shader-clock cycles of the phase-voting waves' loop turns by what the turn did (lane 0 of every wave)
   kStatNum
 };
 

@@ -1181,6 +1181,7 @@ __global__ __launch_bounds__(kBlock, PB_WALK_WAVES) void k_sss_walk(PathState P,
       atomicAdd(&P.stats[kStatWalkNodes], (unsigned long long)nn), atomicAdd(&P.stats[kStatWalkTris], (unsigned long long)nt);
       atomicAdd(&P.stats[kStatWalkTurns], (unsigned long long)(st.it_node + st.it_tri + st.it_curve));
       atomicAdd(&P.stats[kStatWalkSteps], (unsigned long long)st.it_refill);
+      atomicAdd(&P.stats[kStatWalkCycTrav], st.cyc[0] + st.cyc[1] + st.cyc[2]), atomicAdd(&P.stats[kStatWalkCycStep], st.cyc[3]);
     }
   }
 }
@@ -1206,6 +1207,7 @@ __global__ __launch_bounds__(kBlock, PB_WALK_WAVES) void k_sss_walk8(PathState P
       atomicAdd(&P.stats[kStatWalkNodes], (unsigned long long)nn), atomicAdd(&P.stats[kStatWalkTris], (unsigned long long)nt);
       atomicAdd(&P.stats[kStatWalkTurns], (unsigned long long)(st.it_node + st.it_tri + st.it_curve));
       atomicAdd(&P.stats[kStatWalkSteps], (unsigned long long)st.it_refill);
+      atomicAdd(&P.stats[kStatWalkCycTrav], st.cyc[0] + st.cyc[1] + st.cyc[2]), atomicAdd(&P.stats[kStatWalkCycStep], st.cyc[3]);
     }
   }
 }

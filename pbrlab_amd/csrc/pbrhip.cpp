@@ -1463,8 +1463,10 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
         fprintf(stderr, "pv steps per shadow ray:");
         for (int i = 0; i < 8; i++) fprintf(stderr, " %llu", hs[kStatAnyHist0 + i]);
         fprintf(stderr, " | max %llu\n", hs[kStatAnyMaxSteps]);
-        fprintf(stderr, "walk: nodes %llu prims %llu | wave turns: traversal %llu, step / refill %llu\n", hs[kStatWalkNodes], hs[kStatWalkTris],
-                hs[kStatWalkTurns], hs[kStatWalkSteps]);
+        fprintf(stderr, "walk: nodes %llu prims %llu | wave turns: traversal %llu, step / refill %llu | cycles per traversal turn %.0f, per step / refill turn %.0f (share %.3f)\n", hs[kStatWalkNodes], hs[kStatWalkTris],
+                hs[kStatWalkTurns], hs[kStatWalkSteps], hs[kStatWalkCycTrav] / (double)std::max<unsigned long long>(1, hs[kStatWalkTurns]),
+                hs[kStatWalkCycStep] / (double)std::max<unsigned long long>(1, hs[kStatWalkSteps]),
+                hs[kStatWalkCycStep] / (double)std::max<unsigned long long>(1, hs[kStatWalkCycStep] + hs[kStatWalkCycTrav]));
       }
     }
   } else {

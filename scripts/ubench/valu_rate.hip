@@ -705,10 +705,10 @@ int main() {
         if (mode == 0) cyc_fma = cyc;
       }
     }
-  if (!(cyc_fma > 1.4 && cyc_fma < 2.6)) {
+  if (!(cyc_fma > 1.4 && cyc_fma < 3.2)) {  // (2.3-2.6 at the clock the chip sustains, up to 2.9 under the profiler's lower clock; 4 would be a SIMD-16)
     printf("ASSERT: v_fma_f32 expected at 2 cycles per wave64 instruction (SIMD-32), measured %.2f\n", cyc_fma);
     return 1;
   }
-  printf("ok: a wave64 v_fma_f32 issues over %.2f cycles (guide: 2)\n", cyc_fma);
+  printf("ok: a wave64 v_fma_f32 issues over %.2f cycles at the nominal clock (guide: 2); every other class measured here needs 4 or more\n", cyc_fma);
   return 0;
 }

@@ -26,6 +26,7 @@ __global__ __launch_bounds__(256) void gather(const float4* __restrict__ tab, fl
   float4 acc = make_float4(0, 0, 0, 0);
   unsigned s = (threadIdx.x + blockIdx.x * 256u) * 2654435761u + 12345u;
   unsigned item = (s >> 7) & mask;
+  const unsigned salt = s * 747796405u + 2891336453u;
 #pragma unroll 1
   for (int i = 0; i < iters; ++i) {
     const float4* g = tab + (size_t)item * W;
@@ -35,7 +36,8 @@ __global__ __launch_bounds__(256) void gather(const float4* __restrict__ tab, fl
 #pragma unroll
     for (int k = 0; k < W; k++) acc.x += v[k].y, acc.y += v[k].z;
     if (DEP) {
-      item = (__float_as_uint(v[0].x) + i) & mask;  // the next address needs this item (word 0 holds a random index)
+      item = (((__float_as_uint(v[0].x) ^ salt) * 2654435761u) >> 7) & mask;  // the next address needs this item (word 0 holds a random index; the
+                                                                              // per-lane salt keeps the lanes' chains apart: without it they merge into a few cycles of the random map)
     } else {
       s = s * 1664525u + 1013904223u;
       item = (s >> 7) & mask;
