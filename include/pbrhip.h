@@ -118,8 +118,16 @@ typedef struct {
  * changes whenever one of them changes (3 -> 4: pbrhip_render_stats grew by curve_bytes).  The library writes whole structs
  * (n of them for pbrhip_render_multi), so a caller compiled against another version must not call it: check
  * pbrhip_abi_version() == PBRHIP_ABI_VERSION once after loading (include/pbrlab_hip.hpp and pbrlab_amd/api.py do). */
-#define PBRHIP_ABI_VERSION 4u
+#define PBRHIP_ABI_VERSION 5u
 uint32_t pbrhip_abi_version(void);
+/* Which implementation of cos / sin / exp / log -- the reference's std::cos ... on float, sampler/sampling-utils.h:10-14,
+ * closure/microfacet-ggx.h:55-118, shader/random-walk-sss.h:116,183,192-194 -- this build of the library computes with:
+ * PBRHIP_MATH_GLIBCF: GNU libc's float functions restated bit for bit (include/pbr_glibcf.h; the default since round 5: the
+ * reference's own arithmetic wherever its libm is glibc 2.28+ on x86-64 with FMA); PBRHIP_MATH_F64R: the double-precision value
+ * rounded once (include/pbr_f64r.h; a library built with -DPBR_MATH_F64R). */
+#define PBRHIP_MATH_F64R 1u
+#define PBRHIP_MATH_GLIBCF 2u
+uint32_t pbrhip_math_mode(void);
 size_t pbrhip_sizeof_render_stats(void); /* == sizeof(pbrhip_render_stats) of the library's build */
 
 const char* pbrhip_last_error(void);

@@ -27,6 +27,7 @@
 
 #define ORC_MATH_LIBM 0
 #define ORC_MATH_F64R 1
+#define ORC_MATH_GLIBCF 2 /* include/pbr_glibcf.h: glibc's own float functions restated (what the HIP kernels compute since round 5) */
 
 extern int g_orc_math_mode;
 
@@ -36,12 +37,13 @@ extern int g_orc_math_mode;
 #define ORC_EPS 1e-3f
 #define ORC_INF 1.844E18f
 
-#include "../include/pbr_f64r.h" /* the fixed f64r implementation, compiled verbatim by the HIP kernels too */
+#include "../include/pbr_f64r.h"   /* the fixed f64r implementation (correctly rounded), compiled verbatim by the HIP kernels' f64r build too */
+#include "../include/pbr_glibcf.h" /* glibc's flt-32 functions restated bit for bit, compiled verbatim by the HIP kernels */
 
-static inline float orc_cosf(float x) { return g_orc_math_mode == ORC_MATH_LIBM ? cosf(x) : f64r_cosf(x); }
-static inline float orc_sinf(float x) { return g_orc_math_mode == ORC_MATH_LIBM ? sinf(x) : f64r_sinf(x); }
-static inline float orc_expf(float x) { return g_orc_math_mode == ORC_MATH_LIBM ? expf(x) : f64r_expf(x); }
-static inline float orc_logf(float x) { return g_orc_math_mode == ORC_MATH_LIBM ? logf(x) : f64r_logf(x); }
+static inline float orc_cosf(float x) { return g_orc_math_mode == ORC_MATH_LIBM ? cosf(x) : (g_orc_math_mode == ORC_MATH_GLIBCF ? glibcf_cosf(x) : f64r_cosf(x)); }
+static inline float orc_sinf(float x) { return g_orc_math_mode == ORC_MATH_LIBM ? sinf(x) : (g_orc_math_mode == ORC_MATH_GLIBCF ? glibcf_sinf(x) : f64r_sinf(x)); }
+static inline float orc_expf(float x) { return g_orc_math_mode == ORC_MATH_LIBM ? expf(x) : (g_orc_math_mode == ORC_MATH_GLIBCF ? glibcf_expf(x) : f64r_expf(x)); }
+static inline float orc_logf(float x) { return g_orc_math_mode == ORC_MATH_LIBM ? logf(x) : (g_orc_math_mode == ORC_MATH_GLIBCF ? glibcf_logf(x) : f64r_logf(x)); }
 
 /* std::max(a,b) / std::min(a,b) exactly as libstdc++ defines them (NaN behaviour included). */
 static inline float orc_max(float a, float b) { return (a < b) ? b : a; }

@@ -17,7 +17,25 @@
 #include "orc_math.h"
 
 int g_orc_math_mode = ORC_MATH_LIBM;
-void orc_set_math_mode(int mode) { g_orc_math_mode = mode ? ORC_MATH_F64R : ORC_MATH_LIBM; }
+void orc_set_math_mode(int mode) { g_orc_math_mode = mode == ORC_MATH_GLIBCF ? ORC_MATH_GLIBCF : (mode ? ORC_MATH_F64R : ORC_MATH_LIBM); }
+/* Is the host's libm the one include/pbr_glibcf.h restates?  Compares cosf / sinf / expf / logf of the host libm with the
+ * restatement on every `stride`-th float bit pattern (stride 1: all 2^32 arguments of each function) and returns the number of
+ * differing results (two NaNs count as equal).  tests/test_glibcf.py; the GPU tests use it to decide whether "equal to oracle[libm]"
+ * may be asserted as bits. */
+unsigned long long orc_glibcf_vs_libm(uint32_t stride, uint32_t first) {
+  unsigned long long bad = 0;
+  if (stride == 0) stride = 1;
+  for (uint64_t i = first; i < (1ull << 32); i += stride) {
+    const uint32_t u = (uint32_t)i;
+    float x;
+    memcpy(&x, &u, 4);
+    const float a[4] = {cosf(x), sinf(x), expf(x), logf(x)};
+    const float b[4] = {glibcf_cosf(x), glibcf_sinf(x), glibcf_expf(x), glibcf_logf(x)};
+    for (int k = 0; k < 4; k++)
+      if (orc_f2u(a[k]) != orc_f2u(b[k]) && !(a[k] != a[k] && b[k] != b[k])) bad++;
+  }
+  return bad;
+}
 int orc_get_math_mode(void) { return g_orc_math_mode; }
 
 #define ORC_NONE 0xFFFFFFFFu

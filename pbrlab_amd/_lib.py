@@ -9,11 +9,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PBRHIP_LIB") or os.path.join(HERE, "libpbrhip.so")  # PBRHIP_LIB: A/B builds
 CSRC = os.path.join(HERE, "csrc")
 
-ABI_VERSION = 4  # PBRHIP_ABI_VERSION of include/pbrhip.h (struct layouts of this binding)
+ABI_VERSION = 5  # PBRHIP_ABI_VERSION of include/pbrhip.h (struct layouts of this binding)
 
 # every symbol include/pbrhip.h declares
 EXPORTS = [
-    "pbrhip_abi_version", "pbrhip_sizeof_render_stats", "pbrhip_last_error", "pbrhip_device_count", "pbrhip_set_device", "pbrhip_scene_create", "pbrhip_scene_destroy",
+    "pbrhip_abi_version", "pbrhip_math_mode", "pbrhip_sizeof_render_stats", "pbrhip_last_error", "pbrhip_device_count", "pbrhip_set_device", "pbrhip_scene_create", "pbrhip_scene_destroy",
     "pbrhip_scene_add_triangle_mesh", "pbrhip_scene_add_curve_mesh", "pbrhip_scene_add_principled_material",
     "pbrhip_scene_add_hair_material", "pbrhip_scene_add_texture", "pbrhip_scene_add_area_light", "pbrhip_scene_create_local_scene",
     "pbrhip_scene_add_mesh_to_local_scene", "pbrhip_scene_create_instance", "pbrhip_scene_attach_light_ids",
@@ -46,6 +46,7 @@ def lib():
         _lib = C.CDLL(LIB_PATH)
         _lib.pbrhip_last_error.restype = C.c_char_p
         _lib.pbrhip_abi_version.restype = C.c_uint32
+        _lib.pbrhip_math_mode.restype = C.c_uint32
         _lib.pbrhip_sizeof_render_stats.restype = C.c_size_t
         if _lib.pbrhip_abi_version() != ABI_VERSION:
             v = _lib.pbrhip_abi_version()

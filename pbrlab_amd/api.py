@@ -102,6 +102,11 @@ def make_hair(d):
     return _fill(HairParam(), d)
 
 
+def math_mode():
+    """'glibcf' (glibc's float functions restated bit for bit: the default) or 'f64r' (correctly rounded): pbrhip_math_mode()"""
+    return {1: "f64r", 2: "glibcf"}[int(_lib.lib().pbrhip_math_mode())]
+
+
 def device_count():
     n = C.c_int(0)
     _lib.lib().pbrhip_device_count(C.byref(n))

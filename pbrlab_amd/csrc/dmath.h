@@ -29,19 +29,38 @@ constexpr float kFltMax = 3.40282346638528859812e+38f;
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 
 }  // namespace pb
-// ------------------------------------------------------------------ transcendental policy (f64r)
-// cos / sin / exp / log = the double-precision value rounded once to float, from the fixed implementation the checker
-// compiles too (include/pbr_f64r.h: IEEE double arithmetic and fma only -- no OCML / libm call, no Payne-Hanek branch).
+// ------------------------------------------------------------------ transcendental policy
+// cos / sin / exp / log are the reference's std::cos / std::sin / std::exp / std::log on float, i.e. the host libm's float functions.
+// Default (round 5): include/pbr_glibcf.h -- glibc's own flt-32 functions (2.28+, x86-64 with FMA) restated bit for bit with IEEE
+// double arithmetic, explicit fma and three small tables: the SAME results as the reference's arithmetic on that platform (pinned
+// over all 2^32 arguments of each function, tests/test_glibcf.py), and fewer instructions than the correctly rounded ones.
+// -DPBR_MATH_F64R: include/pbr_f64r.h -- the double-precision value rounded once to float (rounds 1-4; independent of any libm).
+// Both are compiled verbatim by the checker (its "glibcf" / "f64r" arithmetic modes); pbrhip_math_mode() says which one this build uses.
 #ifndef PB_F64R_FN
 #define PB_F64R_FN __host__ __device__ __forceinline__
 #endif
+#ifdef PBR_MATH_F64R
 #define F64R_FN PB_F64R_FN
 #include "../../include/pbr_f64r.h"
 namespace pb {
+constexpr uint32_t kMathMode = 1u;  // PBRHIP_MATH_F64R
 PB_HD float f_cos(float x) { return f64r_cosf(x); }
 PB_HD float f_sin(float x) { return f64r_sinf(x); }
 PB_HD float f_exp(float x) { return f64r_expf(x); }
 PB_HD float f_log(float x) { return f64r_logf(x); }
+#else
+#define GLIBCF_FN PB_F64R_FN
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GLIBCF_TAB static __device__ const  // (the device pass reads its own copy of the tables)
+#endif
+#include "../../include/pbr_glibcf.h"
+namespace pb {
+constexpr uint32_t kMathMode = 2u;  // PBRHIP_MATH_GLIBCF
+PB_HD float f_cos(float x) { return glibcf_cosf(x); }
+PB_HD float f_sin(float x) { return glibcf_sinf(x); }
+PB_HD float f_exp(float x) { return glibcf_expf(x); }
+PB_HD float f_log(float x) { return glibcf_logf(x); }
+#endif
 
 // std::max / std::min as libstdc++ defines them (comparison order matters for NaN)
 PB_HD float smax(float a, float b) { return (a < b) ? b : a; }

@@ -42,6 +42,7 @@ int pb::current_device() { return g_device; }
 
 extern "C" const char* pbrhip_last_error(void) { return g_err.c_str(); }
 extern "C" uint32_t pbrhip_abi_version(void) { return PBRHIP_ABI_VERSION; }
+extern "C" uint32_t pbrhip_math_mode(void) { return pb::kMathMode; }
 extern "C" size_t pbrhip_sizeof_render_stats(void) { return sizeof(pbrhip_render_stats); }
 
 extern "C" int pbrhip_device_count(int* count) {

@@ -10,7 +10,7 @@ from pbrlab_amd import scenes
 W, H, SPP = 160, 90, 8
 for name, desc in (("c3 scene", scenes.cornell_scene("sss", seed=1)), ("c5 scene", scenes.cornell_hair_scene("sss", seed=1))):
     t = time.time(); so = O.oracle_scene_from_desc(desc); print(name, "oracle commit %.1f s" % (time.time() - t), flush=True)
-    t = time.time(); rgba, cnt, ost = so.render(W, H, SPP, threads=os.cpu_count(), math_mode=O.MATH_F64R); print("  oracle render %.1f s" % (time.time() - t), flush=True)
+    t = time.time(); rgba, cnt, ost = so.render(W, H, SPP, threads=os.cpu_count(), math_mode=O.MATH_DEVICE); print("  oracle render %.1f s" % (time.time() - t), flush=True)
     lo, hi = so.FetchSceneAABB()
     rays = scenes.random_rays((lo, hi), 200000, seed=9)
     ho = so.trace_closest(rays)

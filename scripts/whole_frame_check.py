@@ -15,7 +15,7 @@ for name, mk in (("c2", lambda: scenes.cornell_scene("ggx", seed=1)), ("c3", lam
     a = pa.RenderLayer()
     pa.Render(sg, W, H, SPP, layer=a)
     t = time.time()
-    rgba, cnt, _ = so.render(W, H, SPP, threads=O.oracle_threads(), math_mode=O.MATH_F64R)
+    rgba, cnt, _ = so.render(W, H, SPP, threads=O.oracle_threads(), math_mode=O.MATH_DEVICE)
     d = (a.rgba.view(np.uint32) != rgba.view(np.uint32)).any(axis=2)
     rel = np.linalg.norm(a.rgba[..., :3] - rgba[..., :3]) / max(np.linalg.norm(rgba[..., :3]), 1e-30)
     print(f"{name}: {W}x{H}x{SPP} = {W*H*SPP/1e6:.1f} M samples, differing pixels {int(d.sum())}, rel L2 {rel:.3e}, oracle {time.time()-t:.1f} s", flush=True)

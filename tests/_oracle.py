@@ -12,7 +12,9 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_SO = os.environ.get("PBR_ORACLE_SO") or os.path.join(ORACLE_DIR, "libpbr_oracle.so")  # PBR_ORACLE_SO: another build (bench.py)
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libref_leaf.so")
 
-MATH_LIBM, MATH_F64R = 0, 1
+MATH_LIBM, MATH_F64R, MATH_GLIBCF = 0, 1, 2
+# the arithmetic the HIP kernels compute with (pbrhip_math_mode(); tests/test_cabi_cpu.py checks the library says the same)
+MATH_DEVICE = MATH_GLIBCF
 def host_threads():
     """CPUs this process may really use: min(os.cpu_count(), scheduler affinity, the cgroup's CPU quota).  The GPU boxes report 256
     hardware threads and run the job under cpu.max = 16 CPUs: 256 oracle threads then take turns on 16 cores and finish LATER than
@@ -35,6 +37,18 @@ def host_threads():
         except (OSError, ValueError):
             pass
     return n
+
+
+_libm_is_glibcf = None
+
+
+def libm_is_glibcf():
+    """True when the host libm's cosf / sinf / expf / logf are the functions include/pbr_glibcf.h restates (glibc 2.28+ on x86-64 with
+    FMA: this container and the GPU boxes): 4 x 16.7 M sampled arguments, cached.  Then oracle[libm] == oracle[glibcf] == the GPU, bit for bit."""
+    global _libm_is_glibcf
+    if _libm_is_glibcf is None:
+        _libm_is_glibcf = int(lib().orc_glibcf_vs_libm(257, 0)) == 0
+    return _libm_is_glibcf
 
 
 def oracle_threads():
@@ -149,6 +163,8 @@ def lib():
         L.orc_create_tiles.argtypes = [C.c_uint32, C.c_uint32, u32p, u32p]
         L.orc_to_cubic_bezier.argtypes = [fp, fp, C.c_uint32, fp]
         L.orc_set_math_mode.argtypes = [C.c_int]
+        L.orc_glibcf_vs_libm.argtypes = [C.c_uint32, C.c_uint32]
+        L.orc_glibcf_vs_libm.restype = C.c_uint64
         _lib = L
     return _lib
 

@@ -36,6 +36,11 @@ def test_struct_layouts_match_header():
     L = _lib.lib()
     assert L.pbrhip_abi_version() == _lib.ABI_VERSION
     assert L.pbrhip_sizeof_render_stats() == C.sizeof(api.RenderStats)
+    # which restatement of cos / sin / exp / log the kernels were compiled with (include/pbrhip.h PBRHIP_MATH_*): the default build
+    # uses glibc 2.35's x86-64 FMA float functions (include/pbr_glibcf.h), the arithmetic the parity tests' oracle mode must match
+    import pbrlab_amd as pa
+    import _oracle as O
+    assert L.pbrhip_math_mode() == 2 == O.MATH_DEVICE and pa.math_mode() == "glibcf"
 
 
 def test_tiles_host_logic(L):

@@ -1,9 +1,9 @@
 """GPU (-m gpu): parity of the HIP path (through the C ABI of libpbrhip.so) with the oracle.
 
 Bars (BASELINE.json north_star): hit / tile indices bit-exact; radiance within 1e-4 relative L2.
-Measured: against the oracle in f64r mode the images are bit-identical (0 pixels differ on every case
-below); against the reference's libm arithmetic the difference is a handful of last-ulp events
-(tests/test_oracle_golden.py::test_libm_vs_f64r_tolerance)."""
+Measured: against the oracle in the device's math mode (glibcf: glibc 2.35's x86-64 FMA float functions restated,
+include/pbr_glibcf.h, = this image's libm, tests/test_glibcf.py) the images are bit-identical (0 pixels differ on every
+case below), and so they are against the committed libm fixtures."""
 import ctypes as C
 import os
 
@@ -17,7 +17,7 @@ from golden.make_golden import golden_scenes  # noqa: E402
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 REL_L2_TOL = 1e-4       # north_star tolerance for radiance
-MAX_DIVERGENT = 1e-3    # fraction of pixels allowed to differ at all vs oracle[f64r] (measured: 0)
+MAX_DIVERGENT = 1e-3    # fraction of pixels allowed to differ at all vs the oracle (measured: 0)
 
 
 @pytest.fixture(scope="module")
@@ -98,15 +98,16 @@ def test_render_matches_oracle_and_fixture(pa, pairs, name, tail):
     ok, st = pa.Render(sg, 64, 64, 4, layer=layer, flags=pa.api.RENDER_STATS, tail_paths=tail)
     assert (st["n_tail"] == 0) == (tail == 0xFFFFFFFF)
     assert ok is True and (layer.count == 4).all() and np.array_equal(layer.rgba[..., 3], np.full((64, 64), 4, np.float32))
-    rgba, cnt, ost = so.render(64, 64, 4, threads=4, math_mode=O.MATH_F64R)
+    rgba, cnt, ost = so.render(64, 64, 4, threads=4, math_mode=O.MATH_DEVICE)
     ndiff, rel = image_check(layer.rgba, rgba)
     assert (st["closest_rays"] + st["tail_closest_rays"] + st["pruned_rays"], st["shadow_rays"] + st["tail_shadow_rays"]) == (ost["closest_rays"], ost["shadow_rays"])
     fx = np.load(os.path.join(G, "oracle_images.npz"))
-    image_check(layer.rgba, fx[f"{name}_f64r_rgba"])
-    # against the reference's libm arithmetic: tolerance only
-    rel_libm = np.linalg.norm(layer.rgba[..., :3] - fx[f"{name}_libm_rgba"][..., :3]) / np.linalg.norm(fx[f"{name}_libm_rgba"][..., :3])
-    assert rel_libm < REL_L2_TOL
-    print(f"{name}: {ndiff} px differ vs oracle[f64r], rel L2 {rel:.1e}; vs libm fixture rel L2 {rel_libm:.1e}")
+    # the committed fixtures: the oracle with the reference's libm arithmetic (made on this image: glibc 2.35, whose float functions
+    # the device restates, include/pbr_glibcf.h) -- bit for bit -- and with correctly rounded functions -- tolerance only
+    image_check(layer.rgba, fx[f"{name}_libm_rgba"])
+    rel_cr = np.linalg.norm(layer.rgba[..., :3] - fx[f"{name}_f64r_rgba"][..., :3]) / np.linalg.norm(fx[f"{name}_f64r_rgba"][..., :3])
+    assert rel_cr < REL_L2_TOL
+    print(f"{name}: {ndiff} px differ vs oracle[glibcf] and the libm fixture, rel L2 {rel:.1e}; vs the correctly rounded fixture rel L2 {rel_cr:.1e}")
 
 
 def test_render_odd_size_and_larger(pa, pairs):
@@ -114,7 +115,7 @@ def test_render_odd_size_and_larger(pa, pairs):
     for (w, h, spp) in [(130, 70, 3), (1, 1, 5), (65, 63, 2), (200, 150, 6)]:
         layer = pa.RenderLayer()
         pa.Render(sg, w, h, spp, layer=layer, tail_paths=0xFFFFFFFF if w == 130 else 0)
-        rgba, cnt, _ = so.render(w, h, spp, threads=8, math_mode=O.MATH_F64R)
+        rgba, cnt, _ = so.render(w, h, spp, threads=8, math_mode=O.MATH_DEVICE)
         assert np.array_equal(layer.count, cnt)
         image_check(layer.rgba, rgba)
 
@@ -130,7 +131,7 @@ def test_path_order_inside_a_block_does_not_matter(pa, pairs, tile, monkeypatch)
     for (w, h, spp) in [(131, 77, 3), (7, 5, 2)]:
         layer = pa.RenderLayer()
         pa.Render(sg, w, h, spp, layer=layer)
-        rgba, cnt, _ = so.render(w, h, spp, threads=8, math_mode=O.MATH_F64R)
+        rgba, cnt, _ = so.render(w, h, spp, threads=8, math_mode=O.MATH_DEVICE)
         assert np.array_equal(layer.count, cnt) and layer.rgba.tobytes() == rgba.tobytes(), (tile, w, h)
         acc, cacc = np.zeros_like(layer.rgba), np.zeros_like(layer.count)
         for r in range(3):
@@ -225,7 +226,7 @@ def test_material_update_and_errors(pa, pairs):
     d2 = scenes.cornell_scene("lambert", monkey_subdiv=1, lucy_nu=16, lucy_nv=6)
     d2.materials[6]["base_color"] = (0.05, 0.05, 0.6)
     s2 = O.oracle_scene_from_desc(d2)
-    rgba, _, _ = s2.render(48, 48, 2, math_mode=O.MATH_F64R)
+    rgba, _, _ = s2.render(48, 48, 2, math_mode=O.MATH_DEVICE)
     image_check(b.rgba, rgba)
     with pytest.raises(pa.PbrHipError) as e:
         sg.AttachMaterialParamIdsToInstance(0, [np.zeros(5, np.uint32)])
@@ -258,7 +259,7 @@ def test_material_update_switches_on_subsurface(pa):
     assert a.rgba.tobytes() != b.rgba.tobytes()
     d2 = scenes.cornell_scene("ggx", monkey_subdiv=1, lucy_nu=24, lucy_nv=8)
     d2.materials[idx].update(subsurface=1.0, subsurface_radius=(1.0, 0.2, 0.1), subsurface_color=(1.0, 0.8, 0.8))
-    rgba, cnt, _ = O.oracle_scene_from_desc(d2).render(64, 48, 3, threads=4, math_mode=O.MATH_F64R)
+    rgba, cnt, _ = O.oracle_scene_from_desc(d2).render(64, 48, 3, threads=4, math_mode=O.MATH_DEVICE)
     assert b.rgba.tobytes() == rgba.tobytes()
 
 
@@ -424,7 +425,7 @@ def test_full_size_properties(pa, config):
         x, y = int(rng.randint(W)), int(rng.randint(H))
         tot = np.zeros(3, np.float32)
         for p in range(SPP):
-            rad, _, _, _ = so.sample_trace(W, H, x, y, p, math_mode=O.MATH_F64R)
+            rad, _, _, _ = so.sample_trace(W, H, x, y, p, math_mode=O.MATH_DEVICE)
             tot = tot + rad
         assert np.array_equal(tot.view(np.uint32), a.rgba[y, x, :3].view(np.uint32)), (x, y)
 
@@ -441,7 +442,7 @@ def test_whole_frames_on_the_benchmark_scenes(pa, config, monkeypatch):
     W, H, SPP = 480, 270, 4
     a = pa.RenderLayer()
     pa.Render(sg, W, H, SPP, layer=a)
-    rgba, cnt, _ = so.render(W, H, SPP, threads=O.oracle_threads(), math_mode=O.MATH_F64R)
+    rgba, cnt, _ = so.render(W, H, SPP, threads=O.oracle_threads(), math_mode=O.MATH_DEVICE)
     assert np.array_equal(a.count, cnt)
     ndiff, rel = image_check(a.rgba, rgba)
     assert ndiff == 0 and rel == 0.0, (ndiff, rel)
@@ -477,7 +478,7 @@ def test_headline_configuration_spot_parity(pa):
         x, y = int(rng.randint(W)), int(rng.randint(H))
         tot = np.zeros(3, np.float32)
         for p in range(SPP):
-            rad, _, _, _ = so.sample_trace(W, H, x, y, p, math_mode=O.MATH_F64R)
+            rad, _, _, _ = so.sample_trace(W, H, x, y, p, math_mode=O.MATH_DEVICE)
             tot = tot + rad
         assert np.array_equal(tot.view(np.uint32), a.rgba[y, x, :3].view(np.uint32)), (x, y)
 
@@ -501,7 +502,7 @@ def test_gpu_built_bvh_gives_identical_results(pa, pairs, name):
     for tail in (0, 0xFFFFFFFF):
         layer = pa.RenderLayer()
         pa.Render(s2, 64, 64, 4, layer=layer, tail_paths=tail)
-        rgba, cnt, _ = so.render(64, 64, 4, threads=4, math_mode=O.MATH_F64R)
+        rgba, cnt, _ = so.render(64, 64, 4, threads=4, math_mode=O.MATH_DEVICE)
         assert np.array_equal(layer.count, cnt)
         assert np.array_equal(layer.rgba.view(np.uint32), rgba.view(np.uint32))
 
@@ -516,7 +517,7 @@ def test_wide_and_binary_trees_agree(pa, pairs, name, monkeypatch):
     lo, hi = so.FetchSceneAABB()
     rays = scenes.random_rays((lo, hi), 30000, seed=11)
     want_hits, want_any = so.trace_closest(rays), so.trace_any(rays)
-    rgba, cnt, _ = so.render(96, 64, 4, threads=4, math_mode=O.MATH_F64R)
+    rgba, cnt, _ = so.render(96, 64, 4, threads=4, math_mode=O.MATH_DEVICE)
     for wide in ("1", "0"):
         monkeypatch.setenv("PBRHIP_WIDE", wide)
         for simple in (False, True):
@@ -595,7 +596,7 @@ def _random_material_scene(seed, with_hair):
 def test_random_materials_parity(pa, seed):
     desc = _random_material_scene(100 + seed, with_hair=(seed % 2 == 1))
     sg, so = pa.scene_from_desc(desc), O.oracle_scene_from_desc(desc)
-    rgba, cnt, _ = so.render(64, 48, 6, threads=4, math_mode=O.MATH_F64R)
+    rgba, cnt, _ = so.render(64, 48, 6, threads=4, math_mode=O.MATH_DEVICE)
     assert np.isfinite(rgba).all() and rgba[..., :3].max() > 0
     for tail in (0, 0xFFFFFFFF):
         layer = pa.RenderLayer()
@@ -662,7 +663,7 @@ def test_alternative_traversals_bit_exact(pa, pairs, which):
         assert np.array_equal(sg.trace_any(short), ob)
         for name in ("ggx", "sss") + (("hair",) if which == "PBRHIP_WIDE8" else ()):
             _, g, o = pairs[name]
-            rgba, cnt, _ = o.render(96, 64, 4, threads=4, math_mode=O.MATH_F64R)
+            rgba, cnt, _ = o.render(96, 64, 4, threads=4, math_mode=O.MATH_DEVICE)
             for tail in (0xFFFFFFFF, 3000):
                 layer = pa.RenderLayer()
                 pa.Render(g, 96, 64, 4, layer=layer, tail_paths=tail)
@@ -739,7 +740,7 @@ def test_curves_only_scene_on_both_trees(pa):
             os.environ.pop("PBRHIP_SIMPLE_TRAVERSAL", None)
             lay = pa.RenderLayer()
             ok, st = pa.Render(sg, 64, 48, 3, layer=lay, flags=pa.api.RENDER_STATS)
-            rgba, cnt, ost = so.render(64, 48, 3, threads=4, math_mode=O.MATH_F64R)
+            rgba, cnt, ost = so.render(64, 48, 3, threads=4, math_mode=O.MATH_DEVICE)
             assert lay.rgba.tobytes() == rgba.tobytes() and np.array_equal(lay.count, cnt)
             assert st["closest_rays"] + st["tail_closest_rays"] + st["pruned_rays"] == ost["closest_rays"] and st["closest_tris"] == 0
         finally:
@@ -785,7 +786,7 @@ def test_degenerate_scenes_render_parity(pa, case):
         desc = _mini_scene([floor, back, light], [m(base_color=(0, 0, 0), specular=0.0), mats[1]])
     so = O.oracle_scene_from_desc(desc)
     sg = pa.scene_from_desc(desc)
-    rgba, cnt, _ = so.render(48, 40, 5, threads=4, math_mode=O.MATH_F64R)
+    rgba, cnt, _ = so.render(48, 40, 5, threads=4, math_mode=O.MATH_DEVICE)
     for tail in (0, 0xFFFFFFFF):
         layer = pa.RenderLayer()
         pa.Render(sg, 48, 40, 5, layer=layer, tail_paths=tail)
@@ -817,7 +818,7 @@ def test_doomed_path_pruning_around_the_light_limits(pa, nlight, nshapes):
     so = O.oracle_scene_from_desc(desc)
     sg = pa.scene_from_desc(desc)
     W, H, SPP = 56, 40, 6
-    rgba, cnt, ost = so.render(W, H, SPP, threads=4, math_mode=O.MATH_F64R)
+    rgba, cnt, ost = so.render(W, H, SPP, threads=4, math_mode=O.MATH_DEVICE)
     for tail in (0, 0xFFFFFFFF, 300):
         layer = pa.RenderLayer()
         ok, st = pa.Render(sg, W, H, SPP, layer=layer, flags=pa.api.RENDER_STATS, tail_paths=tail)
@@ -861,7 +862,7 @@ def test_instance_transforms(pa, kind):
     rays = scenes.random_rays((lo, hi), 30000, seed=4)
     ho = so.trace_closest(rays)
     assert_hits_equal(ho[:1200], so.trace_closest(rays[:1200], brute_force=True))
-    rgba, cnt, ost = so.render(72, 56, 3, threads=4, math_mode=O.MATH_F64R)
+    rgba, cnt, ost = so.render(72, 56, 3, threads=4, math_mode=O.MATH_DEVICE)
     for builder in (pa.api.BVH_HOST_SAH, pa.api.BVH_GPU_LBVH):
         sg = pa.scene_from_desc(desc, bvh_builder=builder)
         glo, ghi = sg.FetchSceneAABB()
@@ -936,7 +937,7 @@ def test_multi_geometry_instances_and_duplicate_instances(pa):
     assert_hits_equal(hg, ho)
     hit = hg["instance_id"] != 0xFFFFFFFF
     assert hit.sum() > 500 and (hg["instance_id"][hit] == 0).all() and set(hg["geom_id"][hit]) == {0, 1}
-    rgba, cnt, _ = so.render(40, 40, 6, threads=4, math_mode=O.MATH_F64R)
+    rgba, cnt, _ = so.render(40, 40, 6, threads=4, math_mode=O.MATH_DEVICE)
     layer = pa.RenderLayer()
     pa.Render(sg, 40, 40, 6, layer=layer)
     assert np.array_equal(layer.count, cnt) and layer.rgba.tobytes() == rgba.tobytes() and rgba[..., :3].max() > 0
@@ -946,7 +947,7 @@ def test_seeding_corners(pa, pairs):
     """RNG((pass << 32) + y*W + x, seed_seq): very large pass indices, other stream selectors, ranks that own no tile"""
     desc, sg, so = pairs["ggx"]
     for first_pass, seed_seq in [(1 << 20, 1234567890), (0xFFFFFFF0, 1234567890), (3, 1), (0, 0xFFFFFFFFFFFFFFFF), (7, 0x0123456789ABCDEF)]:
-        rgba, cnt, _ = so.render(40, 24, 5, first_pass=first_pass, seed_seq=seed_seq, threads=4, math_mode=O.MATH_F64R)
+        rgba, cnt, _ = so.render(40, 24, 5, first_pass=first_pass, seed_seq=seed_seq, threads=4, math_mode=O.MATH_DEVICE)
         layer = pa.RenderLayer()
         pa.Render(sg, 40, 24, 5, layer=layer, first_pass=first_pass, seed_seq=seed_seq)
         assert np.array_equal(layer.count, cnt) and layer.rgba.tobytes() == rgba.tobytes(), (first_pass, seed_seq)

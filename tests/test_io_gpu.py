@@ -72,7 +72,7 @@ def test_cli_end_to_end(pa, name, with_hair, tmp_path):
     # the oracle renders what the loader produced
     desc = _desc_from_files(files)
     so = O.oracle_scene_from_desc(desc)
-    rgba, count, _ = so.render(W, H, SPP, threads=8, math_mode=O.MATH_F64R)
+    rgba, count, _ = so.render(W, H, SPP, threads=8, math_mode=O.MATH_DEVICE)
     want = io_api.layer_to_srgb8(rgba, count)
     ndiff = int((got != want).any(axis=2).sum())
     assert ndiff == 0, ndiff
