@@ -66,7 +66,7 @@ def csrc_hash():
         if name.endswith((".h", ".hip", ".cpp")) or name == "Makefile":
             h.update(name.encode())
             h.update(open(os.path.join(base, name), "rb").read())
-    for name in ("pbr_f64r.h", "pbrhip.h"):  # headers outside csrc the kernels are compiled from
+    for name in ("pbr_f64r.h", "pbr_glibcf.h", "pbrhip.h"):  # headers outside csrc the kernels are compiled from
         h.update(name.encode())
         h.update(open(os.path.join(ROOT, "include", name), "rb").read())
     return h.hexdigest()[:16]

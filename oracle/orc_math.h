@@ -7,15 +7,16 @@
  * the reference built with g++.
  *
  * Transcendental mode (orc_set_math_mode):
- *   ORC_MATH_LIBM  cosf/sinf/expf/logf of the host libm  == what the reference calls
- *                  (std::cos(float) etc.).  This is "the reference's arithmetic".
- *   ORC_MATH_F64R  the function evaluated in double precision and rounded once to float, by the
- *                  fixed implementation of include/pbr_f64r.h (double +, -, *, /, fma only; within
- *                  0.5 ulp + 2^-20 ulp of the true value: tests/test_f64r.py).  The HIP kernels
- *                  compile the same header, so GPU-vs-oracle[F64R] is bit-exact, and the
- *                  libm-vs-F64R difference is measured on the CPU alone
- *                  (tests/test_oracle_math_modes.py).
- * sqrt and division are IEEE correctly rounded in both modes and on the device.
+ *   ORC_MATH_LIBM    cosf/sinf/expf/logf of the host libm == what the reference calls (std::cos(float) etc.): "the reference's
+ *                    arithmetic" on this host.
+ *   ORC_MATH_GLIBCF  include/pbr_glibcf.h: the float functions of glibc 2.28+ on x86-64 with FMA restated with explicit IEEE
+ *                    double arithmetic (every one of the 2^32 arguments of each function gives the host libm's bits on this image:
+ *                    tests/test_glibcf.py).  The HIP kernels compile the same header (round 5), so GPU-vs-oracle[GLIBCF] is
+ *                    bit-exact on any host and GPU-vs-oracle[LIBM] is bit-exact where the libm is that glibc.
+ *   ORC_MATH_F64R    the function evaluated in double precision and rounded once to float, by the fixed implementation of
+ *                    include/pbr_f64r.h (double +, -, *, /, fma only; within 0.5 ulp + 2^-20 ulp of the true value:
+ *                    tests/test_f64r.py): what the kernels compute when built with -DPBR_MATH_F64R (rounds 3-4's default).
+ * sqrt and division are IEEE correctly rounded in all modes and on the device.
  */
 #ifndef ORC_MATH_H_
 #define ORC_MATH_H_

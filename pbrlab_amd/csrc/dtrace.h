@@ -85,8 +85,10 @@ __device__ __forceinline__ bool tri_test(V3 v0, V3 v1, V3 v2, V3 o, V3 d, V3 inv
 // in (tmin, +inf) -- the caller compares with the ray's tmax.
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 f2s(float a) { return f2{a, a}; }
-__device__ __forceinline__ f2 vbox_lo2(f2 x) { return __builtin_elementwise_fma(-__builtin_elementwise_abs(x), f2s(7.62939453125e-06f), x) - f2s(1e-31f); }  // vbox_lo, two at once
-__device__ __forceinline__ f2 vbox_hi2(f2 x) { return __builtin_elementwise_fma(__builtin_elementwise_abs(x), f2s(7.62939453125e-06f), x) + f2s(1e-31f); }
+// (scalar fmas on purpose: v_fma_f32 takes |x| as an input modifier and issues at full rate, 2.7 cycles; the packed form needs a v_and
+// per value for the |x| and a v_pk_fma_f32 at 4.7 per two -- scripts/ubench/valu_rate2.hip)
+__device__ __forceinline__ f2 vbox_lo2(f2 x) { return f2{__builtin_fmaf(-fabsf(x.x), 7.62939453125e-06f, x.x), __builtin_fmaf(-fabsf(x.y), 7.62939453125e-06f, x.y)} - f2s(1e-31f); }  // vbox_lo, two at once
+__device__ __forceinline__ f2 vbox_hi2(f2 x) { return f2{__builtin_fmaf(fabsf(x.x), 7.62939453125e-06f, x.x), __builtin_fmaf(fabsf(x.y), 7.62939453125e-06f, x.y)} + f2s(1e-31f); }
 // (the ray comes as nine scalars: a V3 handed over by value survives as a 12-byte stack object here -- the splats below defeat
 // its scalar replacement -- which the backend then parks in LDS, 3 KB per block)
 __device__ __forceinline__ void tri_test_pair(const float4& w0, const float4& w1, const float4& w2, const float4& w3, const float4& w4, float o_x,
@@ -119,9 +121,14 @@ __device__ __forceinline__ void tri_test_pair(const float4& w0, const float4& w1
   a = __builtin_elementwise_max(a, __builtin_elementwise_min(t0, t1)), b = __builtin_elementwise_min(b, __builtin_elementwise_max(t0, t1));
   t0 = (vbox_lo2(loz) - oz) * f2s(i_z), t1 = (vbox_hi2(hiz) - oz) * f2s(i_z);
   a = __builtin_elementwise_max(a, __builtin_elementwise_min(t0, t1)), b = __builtin_elementwise_min(b, __builtin_elementwise_max(t0, t1));
-  a = __builtin_elementwise_fma(-__builtin_elementwise_abs(a), e, a), b = __builtin_elementwise_fma(__builtin_elementwise_abs(b), e, b);
+  a = f2{__builtin_fmaf(-fabsf(a.x), e.x, a.x), __builtin_fmaf(-fabsf(a.y), e.x, a.y)}, b = f2{__builtin_fmaf(fabsf(b.x), e.x, b.x), __builtin_fmaf(fabsf(b.y), e.x, b.y)};
+#ifdef PB_DIAG_NO_VALIDATE  // (diagnostic build: what the validation costs -- NOT the contract)
+  ok_a = det.x != 0.0f && uu.x >= 0.0f && uu.x <= 1.0f && vv.x >= 0.0f && uv.x <= 1.0f && tt.x > tmin;
+  ok_b = det.y != 0.0f && uu.y >= 0.0f && uu.y <= 1.0f && vv.y >= 0.0f && uv.y <= 1.0f && tt.y > tmin;
+#else
   ok_a = det.x != 0.0f && uu.x >= 0.0f && uu.x <= 1.0f && vv.x >= 0.0f && uv.x <= 1.0f && tt.x > tmin && a.x <= tt.x && tt.x <= b.x;
   ok_b = det.y != 0.0f && uu.y >= 0.0f && uu.y <= 1.0f && vv.y >= 0.0f && uv.y <= 1.0f && tt.y > tmin && a.y <= tt.y && tt.y <= b.y;
+#endif
   t = tt, u = uu, v = vv;
 }
 // one triangle leaf of the Q tree (the five words of its TriPair) against a ray whose current interval ends at hit.t with hit

@@ -2,8 +2,7 @@
 i.e. these, wherever its libm is glibc) that the HIP kernels compute with since round 5 -- against the HOST's libm.
 
 Pin status: on glibc 2.28 ... 2.35+ / x86-64 / FMA (this container, the GPU boxes) every one of the 2^32 arguments of each of the four
-functions gives the same bits (exhaustive run: PBR_GLIBCF_EXHAUSTIVE=1, ~2 minutes on 8 threads; recorded in profiles/README.md).  The
-default run samples every 61st bit pattern (4 x 70 M arguments, a few seconds) and all arguments of the ranges the path uses.
+functions gives the same bits, and the test below checks exactly that: all 4 x 2^32 (20 s on 8 threads).
 On a host whose libm is another one the comparison is reported and the test SKIPS: the functions are then still what the GPU
 computes (GPU == oracle[glibcf] is asserted by the -m gpu tests on any host), only "equal to the reference's own arithmetic" is
 about another platform."""
@@ -16,14 +15,22 @@ import _oracle as O
 
 
 def test_glibcf_equals_the_host_libm():
+    """ALL 2^32 bit patterns of each of the four functions (17.2 G comparisons, ~20 s on 8 threads; PBR_GLIBCF_QUICK=1 samples every
+    61st instead).  On the image this project is built and run on (glibc 2.35, x86-64) any difference FAILS; elsewhere it skips."""
+    import platform
     L = O.lib()
-    stride = 1 if os.environ.get("PBR_GLIBCF_EXHAUSTIVE") else 61
-    bad = int(L.orc_glibcf_vs_libm(stride, 0))
-    if bad and not os.environ.get("PBR_GLIBCF_EXHAUSTIVE"):
-        import platform
-        pytest.skip(f"the host libm is not the one include/pbr_glibcf.h restates ({bad} of {4 * (2**32 // stride)} sampled results differ; "
-                    f"{platform.libc_ver()}, {platform.machine()}): parity with oracle[libm] is a tolerance here, not bits")
-    assert bad == 0
+    if os.environ.get("PBR_GLIBCF_QUICK"):
+        stride, bad = 61, int(L.orc_glibcf_vs_libm(61, 0))
+    else:  # interleaved over the host's threads (ctypes releases the GIL)
+        from concurrent.futures import ThreadPoolExecutor
+        stride, n = 1, O.oracle_threads()
+        with ThreadPoolExecutor(n) as ex:
+            bad = sum(ex.map(lambda k: int(L.orc_glibcf_vs_libm(n, k)), range(n)))
+    here = (platform.libc_ver(), platform.machine())
+    if bad and here != (("glibc", "2.35"), "x86_64"):
+        pytest.skip(f"the host libm is not the one include/pbr_glibcf.h restates ({bad} of {4 * (2**32 // stride)} results differ; {here}): "
+                    f"parity with oracle[libm] is a tolerance here, not bits")
+    assert bad == 0, (bad, here)
     print(f"glibcf == libm on {4 * (2**32 // stride)} arguments (stride {stride})")
 
 
