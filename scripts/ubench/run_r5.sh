@@ -1,15 +1,16 @@
 #!/bin/bash
 # Round-5 calibration of the `k_trace` ceilings.  On the GPU box:
-#   bash scripts/ubench/run_r5.sh            -> gpurun_out/profiles/r5_valu_rate.txt, r5_gather2.txt, r5_ubench_pmc.txt
+#   bash scripts/ubench/run_r5.sh            -> gpurun_out/profiles/r5_valu_rate.txt, r5_valu_rate2.txt, r5_gather2.txt, r5_ubench_pmc.txt
 # 1. builds the micro-benchmarks (the binaries are git-ignored; nothing else builds them)
 # 2. runs them plainly (events)
 # 3. runs them under rocprofv3 --pmc, counters only, one pass per counter group (never next to a trace flag), the program itself after `--`
 cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:-/root/repo}
 out=gpurun_out/profiles; mkdir -p $out
-for b in valu_rate vmem_gather2 exec_halves vmem_quads; do
+for b in valu_rate valu_rate2 vmem_gather2 exec_halves vmem_quads; do
   [ -x scripts/ubench/$b ] && [ scripts/ubench/$b -nt scripts/ubench/$b.hip ] || hipcc --offload-arch=gfx950 -O3 scripts/ubench/$b.hip -o scripts/ubench/$b 2>&1 | grep -v hip-link
 done
 timeout 300 scripts/ubench/valu_rate > $out/r5_valu_rate.txt 2>&1; echo "valu_rate rc $?" >> $out/r5_valu_rate.txt
+timeout 300 scripts/ubench/valu_rate2 > $out/r5_valu_rate2.txt 2>&1; echo "valu_rate2 rc $?" >> $out/r5_valu_rate2.txt
 timeout 900 scripts/ubench/vmem_gather2 > $out/r5_gather2.txt 2>&1; echo "vmem_gather2 rc $?" >> $out/r5_gather2.txt
 # counters, per kernel (summed over its dispatches): one rocprofv3 run per group
 pmc() {  # pmc <label> <binary + args> -- <counters...>
