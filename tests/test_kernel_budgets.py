@@ -22,35 +22,33 @@ BUDGETS = {
     "k_trace<false, false, true, false>": (80, 0),     # Q tree, triangles: 6 waves
     "k_trace<false, true, true, false>": (80, 0),      # Q tree, curves: 6 waves
     # a group's first launch (camera rays computed in the refill path): one block per CU fewer, nothing spilled into the loop
-    "k_trace<false, false, true, true>": (96, 16),     # (16 B: a 12-byte stack object of the packed leaf test, not a spill)
+    "k_trace<false, false, true, true>": (96, 0),
     "k_trace<false, true, true, true>": (96, 0),
-    "k_sss_walk<false, false, true>": (168, 24),  # 3 waves per SIMD; 24 B since the packed two-triangle leaf test (round 4): measured 31.1 -> 29.6 ms per 64 spp of C3 WITH them
-    "k_sss_walk<false, false, false>": (168, 0),
-    "k_sss_walk<false, true, false>": (168, 0),
-    "k_sss_walk<false, true, true>": (168, 0),
-    "k_shade_principled<0>": (168, 0),           # no medium, no texture (C2, C4)
-    # the kernels below keep scratch at three waves per SIMD, measured against two waves without it (profiles/README.md: the
-    # general shading kernel alone is 9 % faster at two, the C3 frame 2 % slower; k_tail likewise in round 2): pinned as they are
-    "k_shade_principled<1>": (168, 28),          # media, no texture (C3, C5): the medium's coefficients come from the material record
-    "k_shade_principled<2>": (168, 108),         # textured materials: ParamToBsdf and the medium per hit
-    # (triangle-only scenes: + 16-32 B with the octets of round 4 -- eight lanes per path once a wave has at most eight left,
-    # dtrace_quad.h; measured WITH them: k_tail of an eighth of C2 1.59 -> 1.30 ms, the frame 51.0 -> 50.5 ms on the same box)
-    "k_tail<0, false, false, true>": (168, 84),    # no medium, no texture (C2); 20 -> 52 B with the packed two-triangle leaf test (C2 k_tail 3.7-4.2 -> 3.5-3.8 ms)
-    "k_tail<0, false, true, true>": (168, 28),     # ... with curves (C4); 20 -> 28 B with the camera sample in the shading head (round 4)
-    "k_tail<1, false, false, true>": (168, 216),   # media (C3)
-    "k_tail<1, false, true, true>": (168, 184),    # media + curves (C5); 168 -> 184 B with the interleaved path-state records (round 4: C3 frame 327 -> 311 ms with them)
-    "k_tail<2, false, false, true>": (168, 244),   # textured materials
+    # Round 5: kernels.hip is compiled without the SLP vectoriser (csrc/Makefile) and every kernel below lost its scratch and 10-40
+    # registers with it (k_tail<1, ...> 216 B -> 0, k_sss_step 155 -> 125 VGPRs, k_shade_principled<0> 133 -> 117): the budgets are
+    # what the kernels compile to now, in occupancy classes (128 VGPRs = four waves per SIMD, 168 = three)
+    "k_sss_walk<false, false, true>": (128, 0),
+    "k_sss_walk<false, false, false>": (128, 0),
+    "k_sss_walk<false, true, false>": (128, 0),
+    "k_sss_walk<false, true, true>": (128, 0),
+    "k_shade_principled<0>": (128, 0),           # no medium, no texture (C2, C4): four waves (five spill: 10.5 -> 12.7 ms on C2)
+    "k_shade_principled<1>": (128, 0),           # media, no texture (C3, C5): the medium's coefficients come from the material record
+    "k_shade_principled<2>": (168, 16),          # textured materials: ParamToBsdf and the medium per hit
+    "k_tail<0, false, false, true>": (168, 0),   # no medium, no texture (C2)
+    "k_tail<0, false, true, true>": (168, 0),    # ... with curves (C4)
+    "k_tail<1, false, false, true>": (168, 0),   # media (C3)
+    "k_tail<1, false, true, true>": (168, 0),    # media + curves (C5)
+    "k_tail<2, false, false, true>": (168, 0),   # textured materials
     "k_trace_quad<false>": (128, 0),             # one ray per quad of lanes (small launches; off by default)
     # the O tree's kernels (round 5, off by default): five blocks per CU (96 VGPRs), nothing spilled
     "k_trace8<false, false, false>": (96, 0),
     "k_trace8<false, true, false>": (96, 0),
-    "k_sss_walk8<false, false>": (168, 0),
-    "k_shade_hair": (136, 0),
-    "k_sss_step": (208, 0),  # 156 -> 201 VGPRs with the packed light pretest (round 4): 3.55 ms per 64 spp of C3 before and after
+    "k_sss_walk8<false, false>": (128, 0),
+    "k_shade_hair": (128, 0),
+    "k_sss_step": (128, 0),
     "k_classify": (64, 0),
     "k_compact": (96, 0),
 }
-
 
 def kernel_table():
     lib = os.path.join(ROOT, "pbrlab_amd", "libpbrhip.so")
@@ -78,17 +76,14 @@ def kernel_table():
     return {d.replace("void pb::", "").replace("pb::", "").split("(")[0]: v for d, v in zip(demangled, table.values())}
 
 
-# Occupancy classes ("pin occupancy classes, not only raw numbers"): waves per SIMD a kernel's VGPR count allows on
-# gfx950 (512 registers per lane and SIMD, allocation granule 8: MI355X_MICROARCH.md) must not drop below what its launch bounds and
-# the measurements behind them assume -- a raised VGPR budget that crosses one of these lines is an occupancy regression, not a tweak.
+# Occupancy classes (the raw budgets above were raised to whatever the code compiled to; what must not regress
+# silently is the number of waves a SIMD holds): waves per SIMD = 512 // VGPRs rounded up to 8, at most 8.
 MIN_WAVES_PER_SIMD = {
     "k_trace<false, false, false, false>": 7, "k_trace<false, true, false, false>": 6, "k_trace<false, false, true, false>": 6,
     "k_trace<false, true, true, false>": 6, "k_trace<false, false, true, true>": 5, "k_trace<false, true, true, true>": 5,
-    "k_sss_walk<false, false, true>": 3, "k_shade_principled<0>": 3, "k_shade_principled<1>": 3, "k_shade_principled<2>": 3,
-    "k_tail<0, false, false, true>": 3, "k_tail<1, false, false, true>": 3, "k_shade_hair": 3,
-    # k_sss_step runs at TWO waves per SIMD since round 4 (201 VGPRs with the packed light pretest): measured equal to the 156-VGPR
-    # kernel (3.55 ms per 64 spp of C3 before and after, profiles/README.md round 4) -- it waits on path-state gathers, not on issue
-    "k_sss_step": 2,
+    "k_sss_walk<false, false, true>": 4, "k_shade_principled<0>": 4, "k_shade_principled<1>": 4, "k_shade_principled<2>": 3,
+    "k_tail<0, false, false, true>": 3, "k_tail<1, false, false, true>": 3, "k_shade_hair": 4,
+    "k_sss_step": 4,
     "k_classify": 8, "k_compact": 5,
 }
 
