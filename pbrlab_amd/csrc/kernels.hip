@@ -197,10 +197,12 @@ __device__ __forceinline__ void trace_stats_out(const PathState& P, const TravSt
     }
 }
 
-// FIRST: one block per CU fewer -- the camera sample (64-bit multiplies of the generator, a square root, two divisions) lives in
-// the refill path and would spill 16 dwords into the traversal loop's register budget
+// FIRST, scenes with curves (and the statistics instances): one block per CU fewer -- the camera sample (64-bit multiplies of the generator, a
+// square root, two divisions) lives in the refill path and would spill into the traversal loop's register budget.  Triangle-only
+// scenes: the same blocks per CU as the other launches since round 5 (79 VGPRs, nothing spilled: first launch of C2 5.66 -> 5.50 ms)
+constexpr uint32_t trace_first_less(bool stats, bool curves) { return (stats || curves) ? 1u : 0u; }
 template <bool STATS, bool CURVES, bool WIDE = false, bool FIRST = false>
-__global__ __launch_bounds__(kBlock, trace_blocks_per_cu(CURVES, WIDE) - (FIRST ? 1 : 0)) void k_trace(PathState P, DScene sc) {
+__global__ __launch_bounds__(kBlock, trace_blocks_per_cu(CURVES, WIDE) - (FIRST ? trace_first_less(STATS, CURVES) : 0u)) void k_trace(PathState P, DScene sc) {
   __shared__ uint32_t stk[pv_lds_stack<CURVES, WIDE>() * kBlock];
   __shared__ float frm[CURVES ? 10 * kBlock : 1];
   // the top of the tree in LDS (triangle-only scenes: with the ribbon frames of curve scenes it would cost a block per CU)
@@ -1159,10 +1161,14 @@ struct WalkSink {
   __device__ __forceinline__ void done(uint32_t, const Hit&, bool) const {}
 };
 #ifndef PB_WALK_WAVES
-#define PB_WALK_WAVES 3  // waves per SIMD of k_sss_walk: <= 168 VGPRs, nothing spilled (4 waves = 128 VGPRs + 72 B of scratch on the 4-wide tree: C3 353 -> 347 ms at 3)
+#define PB_WALK_WAVES 3  // waves per SIMD of k_sss_walk: <= 168 VGPRs, nothing spilled
 #endif
+#ifndef PB_WALK_WAVES_TRI
+#define PB_WALK_WAVES_TRI 4  // ... on the Q tree of a triangle-only scene (C3): 116-120 VGPRs, nothing spilled, 37.9 KB of LDS since round 5: four blocks per CU, 26.8 -> 25.9 ms per 64 spp of C3
+#endif
+constexpr uint32_t walk_blocks_per_cu(bool curves, bool wide) { return (!curves && wide) ? PB_WALK_WAVES_TRI : PB_WALK_WAVES; }
 template <bool STATS, bool CURVES, bool WIDE = false>
-__global__ __launch_bounds__(kBlock, PB_WALK_WAVES) void k_sss_walk(PathState P, DScene sc, uint64_t rng_inc) {
+__global__ __launch_bounds__(kBlock, STATS ? PB_WALK_WAVES : walk_blocks_per_cu(CURVES, WIDE)) void k_sss_walk(PathState P, DScene sc, uint64_t rng_inc) {
   __shared__ uint32_t stk[pv_lds_stack<CURVES, WIDE>() * kBlock];
   __shared__ float frm[CURVES ? 10 * kBlock : 1];
   __shared__ float walk[kWalkWords * kBlock];
@@ -1640,7 +1646,7 @@ void launch_trace(hipStream_t s, const PathState& P, const DScene& sc, uint32_t 
   }
   if (P.first) {
     // a group's first launch: camera rays only, computed by the sink (TraceSinkT<.., FIRST>); always the phase-voting kernel
-    cap = std::max(cap, 512u) - 256u;  // (its launch bounds: one block per CU fewer; never below one block per CU -- PBRHIP_TRACE_BLOCKS=1 used to make this 0)
+    if (trace_first_less(stats, curves)) cap = std::max(cap, 512u) - 256u;  // (its launch bounds: one block per CU fewer; never below one block per CU -- PBRHIP_TRACE_BLOCKS=1 used to make this 0)
     dim3 g(blocks < 1u ? 1u : (blocks < cap ? blocks : cap));
 #define PB_LAUNCH_FIRST(ST)                                                                                      \
   do {                                                                                                           \
@@ -1689,12 +1695,13 @@ void launch_sss_step(hipStream_t s, const PathState& P, const DScene& sc, uint32
   hipLaunchKernelGGL(k_sss_step, dim3(grid_for(n_upper, kShadeGridCap)), dim3(kBlock), 0, s, P, sc, rng_inc);
 }
 void launch_sss_walk(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc, bool stats) {
-  const uint32_t cap = 256u * PB_WALK_WAVES;  // persistent: the resident blocks (<= kTraceGridCap: the walk shares k_trace's spill area)
-  const uint32_t blocks = (n_upper + 15u) / 16u;
-  dim3 g(blocks < 1u ? 1u : (blocks < cap ? blocks : cap));
   const bool curves = sc.num_curves != 0;
   const char* ww = getenv("PBRHIP_WIDE_WALK");
   const bool wide = use_wide(sc) && !(ww && atoi(ww) == 0);
+  // persistent: the resident blocks (<= kTraceGridCap: the walk shares k_trace's spill area)
+  const uint32_t cap = 256u * ((stats || (wide && use_wide8(sc))) ? (uint32_t)PB_WALK_WAVES : walk_blocks_per_cu(curves, wide));
+  const uint32_t blocks = (n_upper + 15u) / 16u;
+  dim3 g(blocks < 1u ? 1u : (blocks < cap ? blocks : cap));
   if (wide && use_wide8(sc)) {
     if (stats && curves) hipLaunchKernelGGL((k_sss_walk8<true, true>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
     else if (stats) hipLaunchKernelGGL((k_sss_walk8<true, false>), g, dim3(kBlock), 0, s, P, sc, rng_inc);

@@ -22,7 +22,7 @@ BUDGETS = {
     "k_trace<false, false, true, false>": (80, 0),     # Q tree, triangles: 6 waves
     "k_trace<false, true, true, false>": (80, 0),      # Q tree, curves: 6 waves
     # a group's first launch (camera rays computed in the refill path): one block per CU fewer, nothing spilled into the loop
-    "k_trace<false, false, true, true>": (96, 0),
+    "k_trace<false, false, true, true>": (80, 0),      # (triangle-only scenes: the same six blocks as the other launches since round 5)
     "k_trace<false, true, true, true>": (96, 0),
     # Round 5: kernels.hip is compiled without the SLP vectoriser (csrc/Makefile) and every kernel below lost its scratch and 10-40
     # registers with it (k_tail<1, ...> 216 B -> 0, k_sss_step 155 -> 125 VGPRs, k_shade_principled<0> 133 -> 117): the budgets are
@@ -80,7 +80,7 @@ def kernel_table():
 # silently is the number of waves a SIMD holds): waves per SIMD = 512 // VGPRs rounded up to 8, at most 8.
 MIN_WAVES_PER_SIMD = {
     "k_trace<false, false, false, false>": 7, "k_trace<false, true, false, false>": 6, "k_trace<false, false, true, false>": 6,
-    "k_trace<false, true, true, false>": 6, "k_trace<false, false, true, true>": 5, "k_trace<false, true, true, true>": 5,
+    "k_trace<false, true, true, false>": 6, "k_trace<false, false, true, true>": 6, "k_trace<false, true, true, true>": 5,
     "k_sss_walk<false, false, true>": 4, "k_shade_principled<0>": 4, "k_shade_principled<1>": 4, "k_shade_principled<2>": 3,
     "k_tail<0, false, false, true>": 3, "k_tail<1, false, false, true>": 3, "k_shade_hair": 4,
     "k_sss_step": 4,
