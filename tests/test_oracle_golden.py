@@ -28,12 +28,25 @@ def kat():
     return np.load(os.path.join(G, "ref_leaf_kats.npz"))
 
 
+@pytest.fixture(params=["libm", "glibcf"], autouse=False)
+def leaf_math(request):
+    """The reference's leaf functions were compiled against this image's libm (glibc 2.35) when the vectors were made: the checker has
+    to reproduce them with the host libm (where that is this glibc) AND with include/pbr_glibcf.h -- the arithmetic the HIP kernels
+    compute with -- on any host: the device's cos / sin / exp / log sit under the very closures the reference's headers define."""
+    L = O.lib()
+    if request.param == "libm" and not O.libm_is_glibcf():
+        pytest.skip("the vectors were made with glibc 2.35's libm; this host has another one")
+    L.orc_set_math_mode(O.MATH_GLIBCF if request.param == "glibcf" else O.MATH_LIBM)
+    yield request.param
+    L.orc_set_math_mode(O.MATH_LIBM)
+
+
 @pytest.fixture(scope="module")
 def img():
     return np.load(os.path.join(G, "oracle_images.npz"))
 
 
-def test_reference_leaf_vectors(kat):
+def test_reference_leaf_vectors(kat, leaf_math):
     L = O.lib()
     for s, want in zip(kat["rng_seeds"], kat["rng_draws"]):
         a = np.zeros(16, np.float32)
@@ -56,7 +69,7 @@ def test_reference_leaf_vectors(kat):
     assert eq([L.orc_kat_power_heuristic(a, b) for a, b in kat["mis_in"]], kat["mis"])
 
 
-def test_reference_ggx_vectors(kat):
+def test_reference_ggx_vectors(kat, leaf_math):
     L = O.lib()
     wo, wi, al, u = kat["ggx_wo"], kat["ggx_wi"], kat["ggx_alpha"], kat["u2"]
     for distrib in (1, 2):
@@ -78,7 +91,7 @@ def test_reference_hair_vectors(kat):
     assert eq(ev, kat["hair_eval"]) and eq(sm, kat["hair_sample"])
 
 
-def test_reference_misc_vectors(kat):
+def test_reference_misc_vectors(kat, leaf_math):
     L = O.lib()
     for i, want in enumerate(kat["sphere_from_rng"]):   # first draw -> u2 (random-walk-sss.h:296 under g++)
         d, got = np.zeros(2, np.float32), np.zeros(3, np.float32)
