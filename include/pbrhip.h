@@ -263,6 +263,25 @@ int pbrhip_comm_gather_layer(pbrhip_comm*, pbrhip_scene*, const pbrhip_render_de
 int pbrhip_trace_closest(pbrhip_scene*, const pbrhip_ray* rays, size_t n, pbrhip_hit* hits);
 int pbrhip_trace_any(pbrhip_scene*, const pbrhip_ray* rays, size_t n, uint8_t* occluded);
 
+/* The device's leaf functions on arrays of inputs -- a test hook like the two above: what the kernels compute for the generator
+ * (src/random/rng.h), the fast math of the hair BSDF (src/pbrlab_math.h:135-344), Fresnel and the MIS weight (closure-util.h,
+ * sampling-utils.h), the Lambert / sphere / triangle samplers (closure/lambert.h, sampler/sampling-utils.h), GGX eval and sample
+ * (closure/microfacet-ggx.h:164-286) and the hair BSDF (closure/energy-conserving-hair-bsdf.h:295-572), so that they can be compared
+ * with outputs of the reference's own headers.  n items; item i reads in_words floats at in + i * in_words and writes out_words at
+ * out + i * out_words (host memory; integers travel as their bits):
+ *   RNG          in: initstate lo, hi, initseq lo, hi            out: out_words draws
+ *   FASTMATH     in: function (0 sin 1 cos 2 exp 3 log 4 atan2(x, y) 5 asin 6 exp2 7 log2 8 / 9 sincos' sine / cosine), x, y   out: 1
+ *   FRESNEL      in: cos, eta -> 1        MIS: sampled pdf, other pdf -> 1
+ *   LAMBERT      in: u0, u1 -> wi[3], f, pdf     SPHERE: u1, u2 -> v[3]     TRIANGLE: u1, u2 -> a, b
+ *   GGX_EVAL     in: wi[3], wo[3], ax, ay, distrib -> f, pdf        GGX_SAMPLE: wo[3], ax, ay, u0, u1, distrib -> wi[3], f, pdf
+ *   HAIR_EVAL    in: wi[3], wo[3], params[23] -> f[3], pdf           HAIR_SAMPLE: wo[3], params[23], us[4] -> wi[3], f[3], pdf
+ *   (params: h, v[4], s, sigma_a[3], eta, alpha, tints[4][3], transparent_scale) */
+enum {
+  PBRHIP_LEAF_RNG = 0, PBRHIP_LEAF_FASTMATH = 1, PBRHIP_LEAF_FRESNEL = 2, PBRHIP_LEAF_MIS = 3, PBRHIP_LEAF_LAMBERT = 4, PBRHIP_LEAF_SPHERE = 5,
+  PBRHIP_LEAF_TRIANGLE = 6, PBRHIP_LEAF_GGX_EVAL = 7, PBRHIP_LEAF_GGX_SAMPLE = 8, PBRHIP_LEAF_HAIR_EVAL = 9, PBRHIP_LEAF_HAIR_SAMPLE = 10
+};
+int pbrhip_leaf_eval(uint32_t op, const float* in, size_t n, uint32_t in_words, float* out, uint32_t out_words);
+
 /* CreateTiles (src/render-tile.cc:29-41): out = sx,tx,sy,ty per tile (may be NULL to query the count) */
 int pbrhip_create_tiles(uint32_t width, uint32_t height, uint32_t* out_sx_tx_sy_ty, uint32_t* num_tiles);
 

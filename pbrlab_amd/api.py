@@ -102,6 +102,21 @@ def make_hair(d):
     return _fill(HairParam(), d)
 
 
+LEAF_RNG, LEAF_FASTMATH, LEAF_FRESNEL, LEAF_MIS, LEAF_LAMBERT, LEAF_SPHERE, LEAF_TRIANGLE, LEAF_GGX_EVAL, LEAF_GGX_SAMPLE, LEAF_HAIR_EVAL, LEAF_HAIR_SAMPLE = range(11)
+
+
+def leaf_eval(op, inputs, out_words):
+    """pbrhip_leaf_eval (include/pbrhip.h): the device's leaf functions on an (n, in_words) array of float32 inputs (integers as their
+    bits) -> (n, out_words) float32.  A test hook."""
+    a = np.ascontiguousarray(inputs, np.float32)
+    if a.ndim != 2:
+        raise ValueError("inputs: (n, in_words)")
+    out = np.zeros((a.shape[0], out_words), np.float32)
+    _chk(_lib.lib().pbrhip_leaf_eval(C.c_uint32(op), C.c_void_p(a.ctypes.data), C.c_size_t(a.shape[0]), C.c_uint32(a.shape[1]),
+                                     C.c_void_p(out.ctypes.data), C.c_uint32(out_words)))
+    return out
+
+
 def math_mode():
     """'glibcf' (glibc's float functions restated bit for bit: the default) or 'f64r' (correctly rounded): pbrhip_math_mode()"""
     return {1: "f64r", 2: "glibcf"}[int(_lib.lib().pbrhip_math_mode())]

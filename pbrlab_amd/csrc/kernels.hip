@@ -1395,6 +1395,93 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(PathState P, const uint32
   }
 }
 
+// ------------------------------------------------------------------ leaf functions as a test hook (pbrhip_leaf_eval)
+// One item per thread: `in` = in_words floats per item, `out` = out_words per item; op = PBRHIP_LEAF_* (include/pbrhip.h).  The device's
+// generator, fast math, samplers and closures on the inputs the committed vectors of the REFERENCE's own leaf code were taken at
+// (tests/golden/ref_leaf_kats.npz): the -m gpu test compares the two directly, bit for bit.
+__global__ __launch_bounds__(kBlock) void k_leaf_eval(uint32_t op, const float* __restrict__ in, uint32_t n, uint32_t in_words, float* __restrict__ out,
+                                                      uint32_t out_words) {
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const float* a = in + (size_t)i * in_words;
+    float* o = out + (size_t)i * out_words;
+    switch (op) {
+      case 0: {  // PCG32: (initstate lo, hi, initseq lo, hi as bits) -> out_words draws
+        const uint64_t st = (uint64_t)__float_as_uint(a[0]) | ((uint64_t)__float_as_uint(a[1]) << 32);
+        const uint64_t sq = (uint64_t)__float_as_uint(a[2]) | ((uint64_t)__float_as_uint(a[3]) << 32);
+        Rng r = rng_seed(st, sq);
+        for (uint32_t k = 0; k < out_words; k++) o[k] = draw(r);
+      } break;
+      case 1: {  // fast math: (function as bits, x, y)
+        const uint32_t f = __float_as_uint(a[0]);
+        float sn, cs;
+        fastm::fsincos(a[1], sn, cs);
+        o[0] = f == 0 ? fastm::fsin(a[1]) : f == 1 ? fastm::fcos(a[1]) : f == 2 ? fastm::fexp(a[1]) : f == 3 ? fastm::flog(a[1]) : f == 4 ? fastm::fatan2(a[1], a[2])
+             : f == 5 ? fastm::fasin(a[1]) : f == 6 ? fastm::fexp2(a[1]) : f == 7 ? fastm::flog2(a[1]) : f == 8 ? sn : cs;
+      } break;
+      case 2: o[0] = fresnel_dielectric_cos(a[0], a[1]); break;
+      case 3: o[0] = power_heuristic(a[0], a[1]); break;
+      case 4: {  // Lambert sample: (u0, u1) -> wi, f, pdf
+        V3 wi(0.f);
+        float pdf = 0.f;
+        const float f = lambert_sample(a[0], a[1], wi, pdf);
+        o[0] = wi.x, o[1] = wi.y, o[2] = wi.z, o[3] = f, o[4] = pdf;
+      } break;
+      case 5: {
+        const V3 v = uniform_sample_sphere(a[0], a[1]);
+        o[0] = v.x, o[1] = v.y, o[2] = v.z;
+      } break;
+      case 6: triangle_uniform_sampler(a[0], a[1], o[0], o[1]); break;
+      case 7: {  // GGX eval: (wi, wo, ax, ay, distrib as bits) -> f, pdf
+        float pdf = 0.f;
+        o[0] = ggx_eval(V3(a[0], a[1], a[2]), V3(a[3], a[4], a[5]), a[6], a[7], (int)__float_as_uint(a[8]), pdf);
+        o[1] = pdf;
+      } break;
+      case 8: {  // GGX sample: (wo, ax, ay, u0, u1, distrib as bits) -> wi, f, pdf (microfacet-ggx.h:247-286: eval of the sampled direction)
+        const V3 wo(a[0], a[1], a[2]);
+        V3 wi(0.f);
+        float pdf = 0.f, f = 0.f;
+        if (wo.z > 0.f) {
+          const V3 m = microfacet_sample_stretched(wo, a[3], a[4], a[5], a[6]);
+          const float cos_mo = dot(m, wo);
+          if (cos_mo > 0) {
+            wi = 2 * cos_mo * m - wo;
+            f = ggx_eval(wi, wo, a[3], a[4], (int)__float_as_uint(a[7]), pdf);
+          }
+        }
+        o[0] = wi.x, o[1] = wi.y, o[2] = wi.z, o[3] = f, o[4] = pdf;
+      } break;
+      case 9:
+      case 10: {  // hair: (wi, wo, params[23]) -> f, pdf   /   (wo, params[23], us[4]) -> wi, f, pdf
+        const float* p = a + (op == 9 ? 6 : 3);
+        HairBsdf b;
+        b.h = p[0];
+        for (int k = 0; k < 4; k++) b.v[k] = p[1 + k];
+        b.s = p[5], b.sigma_a = V3(p[6], p[7], p[8]), b.eta = p[9], b.alpha = p[10];
+        for (int k = 0; k < 4; k++) b.tints[k] = V3(p[11 + 3 * k], p[12 + 3 * k], p[13 + 3 * k]);
+        b.transparent_scale = p[22];
+        HairSetup S;
+        float pdf = 0.f;
+        if (op == 9) {
+          hair_prepare(V3(a[3], a[4], a[5]), b, S);
+          const V3 f = hair_eval(S, V3(a[0], a[1], a[2]), b, pdf);
+          o[0] = f.x, o[1] = f.y, o[2] = f.z, o[3] = pdf;
+        } else {
+          hair_prepare(V3(a[0], a[1], a[2]), b, S);
+          const float us[4] = {a[26], a[27], a[28], a[29]};
+          V3 wi(0.f);
+          const V3 f = hair_sample(S, b, us, wi, pdf);
+          o[0] = wi.x, o[1] = wi.y, o[2] = wi.z, o[3] = f.x, o[4] = f.y, o[5] = f.z, o[6] = pdf;
+        }
+      } break;
+      default: break;
+    }
+  }
+}
+void launch_leaf_eval(hipStream_t s, uint32_t op, const float* in, uint32_t n, uint32_t in_words, float* out, uint32_t out_words) {
+  const uint32_t blocks = (n + kBlock - 1u) / kBlock;
+  hipLaunchKernelGGL(k_leaf_eval, dim3(blocks < 1u ? 1u : (blocks > 1024u ? 1024u : blocks)), dim3(kBlock), 0, s, op, in, n, in_words, out, out_words);
+}
+
 // ------------------------------------------------------------------ RenderLayer shards (multi-GPU exchange, multi.cpp)
 // A rank's share of the frame is the pixel list `pix` (the blocks dealt to it).  pack: shard = [rgba of every listed
 // pixel | count of every listed pixel]; unpack_add: layer[pix[i]] += shard[i] (the receiving layer holds zeros there, so

@@ -1515,6 +1515,25 @@ extern "C" int pbrhip_render(pbrhip_scene* s, const pbrhip_render_desc* d, const
 }
 
 // ------------------------------------------------------------------ test hooks
+extern "C" int pbrhip_leaf_eval(uint32_t op, const float* in, size_t n, uint32_t in_words, float* out, uint32_t out_words) {
+  return guarded([&]() -> int {
+    if ((!in || !out) && n) return fail(PBRHIP_EINVAL, "leaf_eval: NULL argument");
+    if (op > 10u || in_words == 0 || out_words == 0 || n > (1u << 24)) return fail(PBRHIP_EINVAL, "leaf_eval: bad operation or sizes");
+    static const uint32_t need_in[11] = {4, 3, 2, 2, 2, 2, 2, 9, 8, 29, 30}, need_out[11] = {1, 1, 1, 1, 5, 3, 2, 2, 5, 4, 7};
+    if (in_words < need_in[op] || out_words < need_out[op]) return fail(PBRHIP_EINVAL, "leaf_eval: operation %u needs %u words in, %u out", op, need_in[op], need_out[op]);
+    if (!n) return PBRHIP_OK;
+    DevBuf<float> d_in, d_out;
+    HIPCHK(d_in.reserve(n * in_words));
+    HIPCHK(d_out.reserve(n * out_words));
+    HIPCHK(hipMemcpy(d_in.p, in, n * in_words * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(d_out.p, 0, n * out_words * sizeof(float)));
+    launch_leaf_eval(nullptr, op, d_in.p, (uint32_t)n, in_words, d_out.p, out_words);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(out, d_out.p, n * out_words * sizeof(float), hipMemcpyDeviceToHost));
+    return PBRHIP_OK;
+  });
+}
+
 extern "C" int pbrhip_trace_closest(pbrhip_scene* s, const pbrhip_ray* rays, size_t n, pbrhip_hit* hits) {
   return guarded([&]() -> int {
   if (!s || (!rays && n) || (!hits && n)) return fail(PBRHIP_EINVAL, "trace_closest: NULL argument");
