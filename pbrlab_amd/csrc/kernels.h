@@ -57,6 +57,11 @@ struct PathState {
   Camera cam;
   const uint32_t* pix_index;
   uint32_t npix, width, first_pass, slot0;
+  // Path order inside a group (round 5).  pass_run = R >= 1: runs of R passes of ONE pixel are adjacent -- path j of the group is pixel
+  // pix_index[(j / R) % npix], pass first_pass + (j / R / npix) * R + j % R.  R = 1: a wave's 64 paths are an 8 x 8 pixel patch of one pass
+  // (scenes of surfaces: the order does not matter to them); scenes with curves: R = the largest power of two <= 64 that divides the
+  // group's passes -- thin geometry likes a pixel's samples in one wave (hair k_trace -3 to -5 %).  A permutation: images do not change.
+  uint32_t pass_run;
   uint64_t seed_seq;
   uint32_t no_medium;  // no material of the scene can enter a medium: every shadow ray is an ordinary one (kShNormal), so an occluded one has nothing to deliver
 };

@@ -39,8 +39,9 @@ __device__ __forceinline__ float4 mk4(V3 v, float w) { return make_float4(v.x, v
 // state after them.  A function of j: the first k_trace (TraceSinkT<.., FIRST>) and the first shading (path_head) evaluate it;
 // nothing of it is stored.
 __device__ __forceinline__ void camera_sample(const PathState& P, uint32_t j, V3& dir, uint64_t& rng_state) {
-  const uint32_t pass = P.first_pass + j / P.npix;
-  const uint32_t gpix = P.pix_index[j % P.npix];
+  const uint32_t R = P.pass_run, q = j / R;  // (PathState::pass_run: runs of R passes of one pixel are adjacent)
+  const uint32_t pass = P.first_pass + (q / P.npix) * R + j % R;
+  const uint32_t gpix = P.pix_index[q % P.npix];
   const uint32_t x = gpix % P.width, y = gpix / P.width;
   Rng rng = rng_seed(((uint64_t)pass << 32) + (uint64_t)gpix, P.seed_seq);
   const float jx = draw(rng);
@@ -1381,14 +1382,31 @@ __global__ __launch_bounds__(kBlock, PB_TAIL_WAVES) void k_tail(PathState P, DSc
 __global__ __launch_bounds__(kBlock) void k_accumulate(PathState P, const uint32_t* __restrict__ pix_index, uint32_t npix,
                                                        uint32_t npass, float* __restrict__ rgba,
                                                        uint32_t* __restrict__ count) {
+  const uint32_t R = P.pass_run;
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < npix; i += gridDim.x * kBlock) {
     uint32_t g = pix_index[i];
     float4 acc = reinterpret_cast<float4*>(rgba)[g];
     uint32_t c = count[g];
-    for (uint32_t k = 0; k < npass; k++) {
-      float4 L = P.L[(size_t)k * npix + i];
-      acc.x += L.x, acc.y += L.y, acc.z += L.z, acc.w += 1.0f;
-      c++;
+    if (R == 1u) {
+      for (uint32_t k = 0; k < npass; k++) {
+        float4 L = P.L[(size_t)k * npix + i];
+        acc.x += L.x, acc.y += L.y, acc.z += L.z, acc.w += 1.0f;
+        c++;
+      }
+    } else {
+      // runs of R passes of this pixel are adjacent (PathState::pass_run): a thread streams its own runs, eight radiances = one
+      // 128-byte line per batch of loads; the sums stay in ascending pass order
+      for (uint32_t k0 = 0; k0 < npass; k0 += R) {
+        const float4* run = P.L + ((size_t)(k0 / R) * npix + i) * R;
+        for (uint32_t r0 = 0; r0 < R; r0 += 8u) {
+          float4 L[8];
+#pragma unroll
+          for (uint32_t r = 0; r < 8u; r++) L[r] = (r0 + r < R) ? run[r0 + r] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (uint32_t r = 0; r < 8u; r++)
+            if (r0 + r < R) acc.x += L[r].x, acc.y += L[r].y, acc.z += L[r].z, acc.w += 1.0f, c++;
+        }
+      }
     }
     reinterpret_cast<float4*>(rgba)[g] = acc;
     count[g] = c;

@@ -1106,6 +1106,15 @@ static int ensure_paths(pbrhip_scene* s, size_t n) {
   return PBRHIP_OK;
 }
 
+// PathState::pass_run of a group of `npass` passes: 1 for scenes of surfaces; scenes with curves: the largest power of two <= 64 that
+// divides npass.  PBRHIP_PASS_RUN=R forces a run length (when it divides npass; 1 = off): A/B and tests.
+static uint32_t pass_run_for(uint32_t npass, bool curves) {
+  uint32_t want = curves ? 64u : 1u;
+  if (const char* e = getenv("PBRHIP_PASS_RUN")) want = std::max(1u, (uint32_t)strtoul(e, nullptr, 10));
+  uint32_t r = 1u;
+  while (r * 2u <= want && npass % (r * 2u) == 0u) r *= 2u;
+  return r;
+}
 static uint32_t env_u32(const char* name, uint32_t dflt) {
   const char* e = getenv(name);
   return e ? (uint32_t)strtoul(e, nullptr, 10) : dflt;
@@ -1206,6 +1215,7 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
       chunk_passes = (uint32_t)(s->hit.n / npix);
     if (int rc = ensure_paths(s, (size_t)chunk_passes * npix)) return rc;
     PathState P;
+    P.pass_run = 1u;
     P.ray_o.base = s->rec.p, P.ray_d.base = s->rec.p + 1, P.thr.base = s->rec.p + 2, P.L = s->L.p, P.hit = s->hit.p;
     P.rng.base = reinterpret_cast<uint64_t*>(s->rec.p + 3);
     P.sss_sigt.base = s->ssrec.p, P.sss_sigs.base = s->ssrec.p + 1, P.sss_thr.base = s->ssrec.p + 2;
@@ -1270,6 +1280,7 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
         for (int k = 0; k < 3; k++) gr.P.cam_org[k] = cam.org[k];
         gr.P.cam = cam, gr.P.pix_index = s->path_pix.p, gr.P.npix = npix, gr.P.width = d->width, gr.P.first_pass = gr.first_pass;
         gr.P.slot0 = gr.slot0, gr.P.seed_seq = d->seed_seq;
+        gr.P.pass_run = pass_run_for(gr.npass, sc.num_curves != 0);
         gr.tm = Timer{s, want_timing, nullptr};
       }
       bool lane_busy[kMaxGroups] = {};
@@ -1405,7 +1416,7 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
         while (acc_prefix < ng && G[acc_prefix].finished) {
           const Group& gr = G[acc_prefix];
           PathState PA = P;
-          PA.L = P.L + gr.slot0;
+          PA.L = P.L + gr.slot0, PA.pass_run = gr.P.pass_run;
           Timer tm{s, want_timing, st};
           HIPCHK(tm.begin(&S.ms_accumulate));
           launch_accumulate(st, PA, s->path_pix.p, npix, gr.npass, d_rgba, d_count);

@@ -142,6 +142,22 @@ def test_path_order_inside_a_block_does_not_matter(pa, pairs, tile, monkeypatch)
         assert acc.tobytes() == rgba.tobytes() and np.array_equal(cacc, cnt), (tile, w, h)
 
 
+@pytest.mark.parametrize("run", ["1", "2", "4", "8", "64"])
+@pytest.mark.parametrize("name", ["hair", "ggx"])
+def test_pass_runs_do_not_matter(pa, pairs, name, run, monkeypatch):
+    """PathState::pass_run (round 5): runs of R passes of one pixel adjacent in the path order (scenes with curves: the largest power of
+    two <= 64 that divides a group's passes; PBRHIP_PASS_RUN forces R).  A permutation of the paths: the image is the oracle's for any
+    R, with pass counts R does and does not divide, in one group, two groups, chunked, and resumed from a later pass."""
+    desc, sg, so = pairs[name]
+    monkeypatch.setenv("PBRHIP_PASS_RUN", run)
+    for (w, h, spp, first) in [(61, 37, 8, 0), (33, 20, 12, 5), (16, 9, 7, 0)]:
+        rgba, cnt, _ = so.render(w, h, spp, first_pass=first, threads=8, math_mode=O.MATH_DEVICE)
+        for kw in ({}, {"num_streams": 2}, {"max_paths_in_flight": w * h * 4}):
+            layer = pa.RenderLayer()
+            pa.Render(sg, w, h, spp, layer=layer, first_pass=first, **kw)
+            assert np.array_equal(layer.count, cnt) and layer.rgba.tobytes() == rgba.tobytes(), (run, w, h, spp, kw)
+
+
 def test_chunking_and_progressive_are_exact(pa, pairs):
     """results must not depend on how passes are chunked (max_paths_in_flight) and a resumed render
     (first_pass + NO_CLEAR) equals the one-shot render bit for bit"""
