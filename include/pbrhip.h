@@ -281,6 +281,9 @@ enum {
   PBRHIP_LEAF_TRIANGLE = 6, PBRHIP_LEAF_GGX_EVAL = 7, PBRHIP_LEAF_GGX_SAMPLE = 8, PBRHIP_LEAF_HAIR_EVAL = 9, PBRHIP_LEAF_HAIR_SAMPLE = 10
 };
 int pbrhip_leaf_eval(uint32_t op, const float* in, size_t n, uint32_t in_words, float* out, uint32_t out_words);
+/* Texture::FetchFloat3 (src/texture.cc:43-68 -> BilinearFilter, src/image-utils.cc:99-167) of texture `texture_id` of a committed
+ * scene at n coordinates uv[2 * i], uv[2 * i + 1] -> rgb[3 * i ..]: the fetch of the textured shading kernels, as a test hook */
+int pbrhip_texture_fetch(pbrhip_scene*, uint32_t texture_id, const float* uv, size_t n, float* rgb);
 
 /* CreateTiles (src/render-tile.cc:29-41): out = sx,tx,sy,ty per tile (may be NULL to query the count) */
 int pbrhip_create_tiles(uint32_t width, uint32_t height, uint32_t* out_sx_tx_sy_ty, uint32_t* num_tiles);

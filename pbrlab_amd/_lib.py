@@ -19,7 +19,7 @@ EXPORTS = [
     "pbrhip_scene_add_mesh_to_local_scene", "pbrhip_scene_create_instance", "pbrhip_scene_attach_light_ids",
     "pbrhip_scene_attach_material_ids", "pbrhip_scene_commit", "pbrhip_scene_set_bvh_builder", "pbrhip_scene_aabb",
     "pbrhip_scene_update_principled_material", "pbrhip_scene_update_hair_material", "pbrhip_scene_info",
-    "pbrhip_render", "pbrhip_render_device", "pbrhip_trace_closest", "pbrhip_trace_any", "pbrhip_leaf_eval", "pbrhip_create_tiles",
+    "pbrhip_render", "pbrhip_render_device", "pbrhip_trace_closest", "pbrhip_trace_any", "pbrhip_leaf_eval", "pbrhip_texture_fetch", "pbrhip_create_tiles",
     "pbrhip_render_multi", "pbrhip_scene_replicate", "pbrhip_comm_unique_id", "pbrhip_comm_create", "pbrhip_comm_destroy",
     "pbrhip_comm_reduce_layer", "pbrhip_comm_gather_layer",
 ]

@@ -287,6 +287,13 @@ class Scene:
                                          C.c_void_p(hits.ctypes.data)))
         return hits
 
+    def texture_fetch(self, texture_id, uv):
+        """pbrhip_texture_fetch: Texture::FetchFloat3 of a texture of this committed scene at (n, 2) coordinates -> (n, 3).  A test hook."""
+        uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
+        rgb = np.zeros((len(uv), 3), np.float32)
+        _chk(self.L.pbrhip_texture_fetch(self.h, C.c_uint32(texture_id), C.c_void_p(uv.ctypes.data), C.c_size_t(len(uv)), C.c_void_p(rgb.ctypes.data)))
+        return rgb
+
     def trace_any(self, rays):
         rays = np.ascontiguousarray(rays, RAY_DT)
         occ = np.zeros(len(rays), np.uint8)

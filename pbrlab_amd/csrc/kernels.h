@@ -141,6 +141,7 @@ void launch_sss_walk(hipStream_t s, const PathState& P, const DScene& sc, uint32
 void launch_accumulate(hipStream_t s, const PathState& P, const uint32_t* pix_index, uint32_t npix, uint32_t npass,
                        float* rgba, uint32_t* count);
 void launch_advance(hipStream_t s, const PathState& P);
+void launch_texture_fetch(hipStream_t s, const DScene& sc, uint32_t tex_id, const float* uv, uint32_t n, float* rgb);  // test hook: Texture::FetchFloat3
 void launch_leaf_eval(hipStream_t s, uint32_t op, const float* in, uint32_t n, uint32_t in_words, float* out, uint32_t out_words);  // test hook: the device's leaf functions
 // RenderLayer shard of a pixel list: shard = npix x rgba (16 B) followed by npix x count (4 B); 16-byte aligned
 void launch_layer_pack(hipStream_t s, const uint32_t* pix, uint32_t npix, const float* rgba, const uint32_t* count, float* shard);

@@ -1495,6 +1495,17 @@ __global__ __launch_bounds__(kBlock) void k_leaf_eval(uint32_t op, const float* 
     }
   }
 }
+// Texture::FetchFloat3 on an array of (u, v) (test hook pbrhip_texture_fetch): the fetch the textured shading kernels run
+__global__ __launch_bounds__(kBlock) void k_texture_fetch(DScene sc, uint32_t tex_id, const float* __restrict__ uv, uint32_t n, float* __restrict__ rgb) {
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const V3 c = texture_fetch3(sc, tex_id, uv[2 * i], uv[2 * i + 1]);
+    rgb[3 * i] = c.x, rgb[3 * i + 1] = c.y, rgb[3 * i + 2] = c.z;
+  }
+}
+void launch_texture_fetch(hipStream_t s, const DScene& sc, uint32_t tex_id, const float* uv, uint32_t n, float* rgb) {
+  const uint32_t blocks = (n + kBlock - 1u) / kBlock;
+  hipLaunchKernelGGL(k_texture_fetch, dim3(blocks < 1u ? 1u : (blocks > 1024u ? 1024u : blocks)), dim3(kBlock), 0, s, sc, tex_id, uv, n, rgb);
+}
 void launch_leaf_eval(hipStream_t s, uint32_t op, const float* in, uint32_t n, uint32_t in_words, float* out, uint32_t out_words) {
   const uint32_t blocks = (n + kBlock - 1u) / kBlock;
   hipLaunchKernelGGL(k_leaf_eval, dim3(blocks < 1u ? 1u : (blocks > 1024u ? 1024u : blocks)), dim3(kBlock), 0, s, op, in, n, in_words, out, out_words);

@@ -1526,6 +1526,26 @@ extern "C" int pbrhip_render(pbrhip_scene* s, const pbrhip_render_desc* d, const
 }
 
 // ------------------------------------------------------------------ test hooks
+extern "C" int pbrhip_texture_fetch(pbrhip_scene* s, uint32_t texture_id, const float* uv, size_t n, float* rgb) {
+  return guarded([&]() -> int {
+    if (!s || ((!uv || !rgb) && n)) return fail(PBRHIP_EINVAL, "texture_fetch: NULL argument");
+    if (!s->committed) return fail(PBRHIP_ESTATE, "scene not committed");
+    if (texture_id >= s->tex_descs.size()) return fail(PBRHIP_EINVAL, "texture_fetch: texture id %u out of range", texture_id);
+    if (n > (1u << 24)) return fail(PBRHIP_EINVAL, "texture_fetch: too many coordinates");
+    if (!n) return PBRHIP_OK;
+    HIPCHK(hipSetDevice(s->device));
+    DevBuf<float> d_uv, d_rgb;
+    HIPCHK(d_uv.reserve(2 * n));
+    HIPCHK(d_rgb.reserve(3 * n));
+    HIPCHK(hipMemcpyAsync(d_uv.p, uv, 2 * n * sizeof(float), hipMemcpyHostToDevice, s->stream));
+    launch_texture_fetch(s->stream, s->dscene, texture_id, d_uv.p, (uint32_t)n, d_rgb.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(rgb, d_rgb.p, 3 * n * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return PBRHIP_OK;
+  });
+}
+
 extern "C" int pbrhip_leaf_eval(uint32_t op, const float* in, size_t n, uint32_t in_words, float* out, uint32_t out_words) {
   return guarded([&]() -> int {
     if ((!in || !out) && n) return fail(PBRHIP_EINVAL, "leaf_eval: NULL argument");
