@@ -1152,8 +1152,10 @@ static std::vector<uint32_t> plan_groups(uint32_t np, uint32_t npix, uint32_t wa
   // k_tail overlap the other's bulk work); one group below that (a half / quarter / eighth of the frame: 32.6 / 19.7 /
   // 12.1 ms with one group against 32.2 / 19.9 / 12.8 with two -- every extra group adds its own latency-bound launches)
   // Round 4, after the shading kernels got faster: two groups also pay for a half and a quarter of the frame (27.1-27.2 / 16.0-16.4 ms
-  // against 27.9-28.2 / 16.6-16.7 with one), not for an eighth (10.0-10.2 either way): the threshold is 24 Mi paths now.
-  if ((uint64_t)np * npix >= (24ull << 20) && np >= 2) g.push_back(np / 2), g.push_back(np - np / 2);
+  // against 27.9-28.2 / 16.6-16.7 with one), not for an eighth (10.0-10.2 either way): the threshold was 24 Mi paths.
+  // Round 5 (kernels 5-8 % faster, the launches' drains the same): an eighth of the frame (15.8 Mi paths) 9.50-9.57 ms with one group,
+  // 9.13-9.15 with two, 9.19-9.33 with three: the threshold is 12 Mi paths.
+  if ((uint64_t)np * npix >= (12ull << 20) && np >= 2) g.push_back(np / 2), g.push_back(np - np / 2);
   else g.push_back(np);
   return g;
 }
