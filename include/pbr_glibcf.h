@@ -1,6 +1,6 @@
 /*
  * pbr_glibcf.h -- cosf / sinf / expf / logf AS THE REFERENCE COMPUTES THEM on the platform this project runs on: bit for bit the
- * float functions of GNU libc 2.28 ... 2.35+ on x86-64 hardware with FMA, restated with explicit IEEE double arithmetic so that
+ * float functions of GNU libc (the algorithms it ships since 2.28; the build pinned is Ubuntu 22.04's 2.35) on x86-64 hardware with FMA, restated with explicit IEEE double arithmetic so that
  * gcc on the host and hipcc on gfx950 produce the same bits.  The HIP kernels (pbrlab_amd/csrc/dmath.h) and the CPU checker (its
  * "glibcf" arithmetic mode) compile this file verbatim.
  *

@@ -123,7 +123,7 @@ uint32_t pbrhip_abi_version(void);
 /* Which implementation of cos / sin / exp / log -- the reference's std::cos ... on float, sampler/sampling-utils.h:10-14,
  * closure/microfacet-ggx.h:55-118, shader/random-walk-sss.h:116,183,192-194 -- this build of the library computes with:
  * PBRHIP_MATH_GLIBCF: GNU libc's float functions restated bit for bit (include/pbr_glibcf.h; the default since round 5: the
- * reference's own arithmetic wherever its libm is glibc 2.28+ on x86-64 with FMA); PBRHIP_MATH_F64R: the double-precision value
+ * reference's own arithmetic where its libm is glibc 2.35 as Ubuntu 22.04 builds it, x86-64 with FMA: tests/test_glibcf.py); PBRHIP_MATH_F64R: the double-precision value
  * rounded once (include/pbr_f64r.h; a library built with -DPBR_MATH_F64R). */
 #define PBRHIP_MATH_F64R 1u
 #define PBRHIP_MATH_GLIBCF 2u

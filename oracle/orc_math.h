@@ -9,7 +9,7 @@
  * Transcendental mode (orc_set_math_mode):
  *   ORC_MATH_LIBM    cosf/sinf/expf/logf of the host libm == what the reference calls (std::cos(float) etc.): "the reference's
  *                    arithmetic" on this host.
- *   ORC_MATH_GLIBCF  include/pbr_glibcf.h: the float functions of glibc 2.28+ on x86-64 with FMA restated with explicit IEEE
+ *   ORC_MATH_GLIBCF  include/pbr_glibcf.h: the float functions of glibc (Ubuntu 22.04's 2.35 build) on x86-64 with FMA restated with explicit IEEE
  *                    double arithmetic (every one of the 2^32 arguments of each function gives the host libm's bits on this image:
  *                    tests/test_glibcf.py).  The HIP kernels compile the same header (round 5), so GPU-vs-oracle[GLIBCF] is
  *                    bit-exact on any host and GPU-vs-oracle[LIBM] is bit-exact where the libm is that glibc.

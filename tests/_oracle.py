@@ -43,7 +43,7 @@ _libm_is_glibcf = None
 
 
 def libm_is_glibcf():
-    """True when the host libm's cosf / sinf / expf / logf are the functions include/pbr_glibcf.h restates (glibc 2.28+ on x86-64 with
+    """True when the host libm's cosf / sinf / expf / logf are the functions include/pbr_glibcf.h restates (glibc 2.35 as built by Ubuntu 22.04, x86-64 with
     FMA: this container and the GPU boxes): 4 x 16.7 M sampled arguments, cached.  Then oracle[libm] == oracle[glibcf] == the GPU, bit for bit."""
     global _libm_is_glibcf
     if _libm_is_glibcf is None:

@@ -1,7 +1,7 @@
 """CPU: include/pbr_glibcf.h -- the restatement of GNU libc's cosf / sinf / expf / logf (the reference calls std::cos ... on float,
 i.e. these, wherever its libm is glibc) that the HIP kernels compute with since round 5 -- against the HOST's libm.
 
-Pin status: on glibc 2.28 ... 2.35+ / x86-64 / FMA (this container, the GPU boxes) every one of the 2^32 arguments of each of the four
+Pin status: on Ubuntu 22.04's glibc 2.35 / x86-64 / FMA (this container, the GPU boxes) every one of the 2^32 arguments of each of the four
 functions gives the same bits, and the test below checks exactly that: all 4 x 2^32 (20 s on 8 threads).
 On a host whose libm is another one the comparison is reported and the test SKIPS: the functions are then still what the GPU
 computes (GPU == oracle[glibcf] is asserted by the -m gpu tests on any host), only "equal to the reference's own arithmetic" is
