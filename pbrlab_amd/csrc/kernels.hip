@@ -773,17 +773,20 @@ __device__ __forceinline__ uint32_t shade_principled_path(const PathState& P, co
   }
 }
 #ifndef PB_SHADE_WAVES
-#define PB_SHADE_WAVES 3  // min waves per SIMD: <= 168 VGPRs (A/B on C2: 1 -> 20.5 ms, 2 -> 20.3, 3 -> 19.3, 4 spills -> 25.5)
+#define PB_SHADE_WAVES 4  // min waves per SIMD of the plain kernel: <= 128 VGPRs (round 5: 117-119 by itself since kernels.hip is compiled without the SLP vectoriser; five waves spill: 10.5 -> 12.7 ms on C2.  Rounds 2-4, 133-168 VGPRs: 3)
 #endif
 #ifndef PB_LDS_MATS
 #define PB_LDS_MATS 64
 #endif
 constexpr uint32_t kLdsMats = PB_LDS_MATS;  // closure sets staged in LDS by the plain shading kernel (96 B each)
 #ifndef PB_SHADE_WAVES_FULL
-#define PB_SHADE_WAVES_FULL 3  // the same for the general kernel (media, textured materials)
+#define PB_SHADE_WAVES_FULL 3  // the same for the kernel of textured materials
+#endif
+#ifndef PB_SHADE_WAVES_MEDIA
+#define PB_SHADE_WAVES_MEDIA 4  // ... of scenes with media and no textures (C3, C5): 128-130 VGPRs by itself, pinned to the class it sits at the edge of
 #endif
 template <int MODE>
-__global__ __launch_bounds__(kBlock, MODE == kShadePlain ? PB_SHADE_WAVES : PB_SHADE_WAVES_FULL) void k_shade_principled(PathState P, DScene sc, uint64_t rng_inc) {
+__global__ __launch_bounds__(kBlock, MODE == kShadePlain ? PB_SHADE_WAVES : (MODE == kShadeMedia ? PB_SHADE_WAVES_MEDIA : PB_SHADE_WAVES_FULL)) void k_shade_principled(PathState P, DScene sc, uint64_t rng_inc) {
   __shared__ PrincipledBsdf lds_bsdf[kLdsMats ? kLdsMats : 1];
   __shared__ float lds_lights[kLdsMats ? kLdsLightWords : 1];
   const bool lights_staged = kLdsMats && stage_light_tables(sc, lds_lights);
