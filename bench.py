@@ -313,17 +313,17 @@ def main():
         print(json.dumps(cpu_baseline_run(args.cpu_baseline_child, 0, args.cpu_seconds)))
         return
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N rank processes ourselves -- torch.distributed.run as a CHILD,
+        # decided here, BEFORE this process imports torch or the library (a process that initialised the GPU must never fork a
+        # launcher or be replaced by another program) -- hand on rank 0's JSON line and the launcher's exit code.
+        sys.exit(spawn_ranks(args.gpus))
+
     import numpy as np
     import torch
     import pbrlab_amd as pa
     from pbrlab_amd import api
     from pbrlab_amd.dist import reduce_layer
-
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # `python bench.py --gpus N` without a launcher: start the N rank processes ourselves -- torch.distributed.run as a CHILD,
-        # decided here, before this process has imported torch or touched the GPU (a process that initialised the GPU must never
-        # be replaced by another program) -- hand on rank 0's JSON line and the launcher's exit code.
-        sys.exit(spawn_ranks(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -474,7 +474,7 @@ def main():
             # counter-based ceilings, from this round's committed PMC passes on these very kernel sources (else null)
             default_cfg = not (args.max_paths or args.streams or args.spp)
             pmc, pmc_note = (None, "non-default configuration")
-            trace_kernel = "pb::k_trace8<false" if node_b == 80 else "pb::k_trace<false"   # the O tree's kernel (80-byte nodes) or the Q / binary tree's
+            trace_kernel = "pb::k_trace<false"
             if default_cfg and world == 1 and not args.no_live_pmc:
                 pmc, pmc_note = pmc_live(args.workload, spp, trace_kernel, args.pmc_budget)
             if pmc is None and default_cfg:
@@ -524,7 +524,7 @@ def main():
                 ok = {k: v for k, v in fracs.items() if v is not None and v <= 1.0}   # a ceiling fraction above 1 is a broken model, never a bound
                 if ok:
                     bound = max(ok, key=ok.get)
-            roofline = {"bound": bound, "kernel": ("k_trace8" if node_b == 80 else "k_trace") + " (closest-hit rays of bounce k + shadow rays of bounce k-1)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            roofline = {"bound": bound, "kernel": "k_trace (closest-hit rays of bounce k + shadow rays of bounce k-1)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                         "note": "achieved / frac = ALGORITHMIC bytes (64 B per node visit -- binary tree or the Q tree's quantised 4-wide node --, 48 B per triangle test, 32 B per curve-piece test on the Q tree (64 on the binary tree), 52 B per ray: SURVEY 8d) / kernel "
                                 "time (HIP events on the launch's own stream, timed region) -- NOT a ceiling: the scene is served from L2 / "

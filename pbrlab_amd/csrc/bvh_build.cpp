@@ -521,261 +521,4 @@ uint32_t build_qtree(const std::vector<BvhNode>& N2, const std::function<int(uin
   return need[0];
 }
 
-
-// ------------------------------------------------------------------ the O tree: eight children per node (dscene.h::Node8)
-// Quantises the boxes of the (up to eight) children of a node, child i in slot slot[i]: per axis org = the node's lower bound,
-// step = extent / 253 rounded up, a child's bounds rounded outwards on that grid and then checked -- and moved out further if
-// need be -- with the expression the traversal evaluates, fmaf(q, s, org) in single precision (quantise_node's rule).
-static bool quantise_node8(const QChild* c, const int* slot, int n, Node8* nd) {
-  uint32_t* qw[6] = {nd->qlo_x, nd->qlo_y, nd->qlo_z, nd->qhi_x, nd->qhi_y, nd->qhi_z};
-  for (int a = 0; a < 3; a++) {
-    float lo = std::numeric_limits<float>::infinity(), hi = -lo;
-    for (int i = 0; i < n; i++) lo = std::min(lo, c[i].lo[a]), hi = std::max(hi, c[i].hi[a]);
-    if (!(lo <= hi) || !std::isfinite(lo) || !std::isfinite(hi)) return false;
-    float sc = std::max(nextafterf((hi - lo) / 253.0f, std::numeric_limits<float>::infinity()), 1.1754944e-38f);
-    for (int tries = 0;; tries++) {
-      if (tries > 40 || !std::isfinite(sc)) return false;
-      const float org = lo;
-      bool ok = true;
-      uint32_t wl[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}, wh[2] = {0u, 0u};  // (an empty slot: bytes nobody reads)
-      for (int i = 0; i < n && ok; i++) {
-        int ql = (int)floor(((double)c[i].lo[a] - (double)org) / (double)sc);
-        int qh = (int)ceil(((double)c[i].hi[a] - (double)org) / (double)sc);
-        ql = std::max(0, std::min(255, ql)), qh = std::max(0, std::min(255, qh));
-        while (ql > 0 && !(fmaf((float)ql, sc, org) <= c[i].lo[a])) ql--;
-        while (qh < 255 && !(fmaf((float)qh, sc, org) >= c[i].hi[a])) qh++;
-        if (!(fmaf((float)ql, sc, org) <= c[i].lo[a] && fmaf((float)qh, sc, org) >= c[i].hi[a])) ok = false;
-        const int s = slot[i], w = s >> 2, sh = 8 * (s & 3);
-        wl[w] = (wl[w] & ~(255u << sh)) | ((uint32_t)ql << sh), wh[w] = (wh[w] & ~(255u << sh)) | ((uint32_t)qh << sh);
-      }
-      if (ok) {
-        nd->org[a] = org;
-        (a == 0 ? nd->sx : (a == 1 ? nd->sy : nd->sz)) = sc;
-        qw[a][0] = wl[0], qw[a][1] = wl[1], qw[3 + a][0] = wh[0], qw[3 + a][1] = wh[1];
-        break;
-      }
-      sc *= tries < 8 ? 1.03125f : 2.0f;
-    }
-  }
-  return true;
-}
-
-uint32_t build_q8tree(const std::vector<BvhNode>& N2, const std::function<int(uint32_t, const float*, const float*, Q8Leaf*)>& split_leaf,
-                      const std::function<int(uint32_t, float4*)>& emit_leaf, std::vector<float4>* out, double cost_node, double cost_leaf) {
-  out->clear();
-  if (N2.empty()) return 0;
-  // the binary tree as a tree of boxes (a vertex = one child entry of a binary node; vertex 0 = the scene); children follow their
-  // parent; a leaf of the binary tree that split_leaf turns into two leaves is an inner vertex with two leaves here
-  struct V {
-    float lo[3], hi[3];
-    int32_t l = -1, r = -1;  // children, or -1: leaf
-    uint32_t token = 0;      // leaf: what emit_leaf gets
-  };
-  std::vector<V> T;
-  T.reserve(N2.size() * 3 + 1);
-  {
-    struct Todo {
-      uint32_t node2;
-      int32_t v;
-    };
-    std::vector<Todo> todo;
-    T.emplace_back();
-    todo.push_back({0u, 0});
-    while (!todo.empty()) {
-      const Todo t = todo.back();
-      todo.pop_back();
-      const BvhNode& b = N2[t.node2];
-      int32_t kids[2] = {-1, -1};
-      int nk = 0;
-      for (int k = 0; k < 2; k++) {
-        const uint32_t ref = k ? b.c1 : b.c0;
-        if (ref == kEmptyChild) continue;
-        float lo[3], hi[3];
-        for (int a = 0; a < 3; a++) lo[a] = b.lo[a][k], hi[a] = b.hi[a][k];
-        const int32_t v = (int32_t)T.size();
-        T.emplace_back();
-        for (int a = 0; a < 3; a++) T[v].lo[a] = lo[a], T[v].hi[a] = hi[a];
-        kids[nk++] = v;
-        if (!(ref & kLeafBit)) {
-          todo.push_back({ref, v});
-          continue;
-        }
-        Q8Leaf c[2];
-        const int m = split_leaf(ref, lo, hi, c);
-        if (m == 1) {
-          T[v].token = c[0].token;
-          for (int a = 0; a < 3; a++) T[v].lo[a] = c[0].lo[a], T[v].hi[a] = c[0].hi[a];
-        } else if (m == 2) {
-          for (int j = 0; j < 2; j++) {
-            const int32_t w = (int32_t)T.size();
-            T.emplace_back();
-            T[w].token = c[j].token;
-            for (int a = 0; a < 3; a++) T[w].lo[a] = c[j].lo[a], T[w].hi[a] = c[j].hi[a];
-            (j ? T[v].r : T[v].l) = w;
-          }
-        } else {
-          return 0;
-        }
-      }
-      if (nk == 2) T[t.v].l = kids[0], T[t.v].r = kids[1];
-      else if (nk == 1) T[t.v].l = kids[0], T[t.v].r = -1;
-      else return 0;
-    }
-    for (int a = 0; a < 3; a++) {
-      T[0].lo[a] = std::numeric_limits<float>::infinity(), T[0].hi[a] = -T[0].lo[a];
-      for (int32_t k : {T[0].l, T[0].r})
-        if (k >= 0) T[0].lo[a] = std::min(T[0].lo[a], T[k].lo[a]), T[0].hi[a] = std::max(T[0].hi[a], T[k].hi[a]);
-    }
-  }
-  auto area = [](const V& v) {
-    const float dx = v.hi[0] - v.lo[0], dy = v.hi[1] - v.lo[1], dz = v.hi[2] - v.lo[2];
-    const float a = dx * dy + dy * dz + dz * dx;
-    return a >= 0.f && std::isfinite(a) ? (double)a : 0.0;
-  };
-  // cost[v][j], j = 1..7: the cheapest way to present the subtree of v as at most j children of one node (each of them a leaf or
-  // the root of an 8-wide node of its own); an inner v as ONE child costs a node visit plus its best eight-way split.
-  //   D(v, j) = min_{0 < k < j} cost[l][k] + cost[r][j - k]           cost[v][1] = area(v) * cost_node + D(v, 8)
-  //   cost[v][j] = min(cost[v][j - 1], D(v, j))
-  // split[v][j] = the k of D(v, j) when that is what cost[v][j] is (0: cost[v][j - 1] is); split[v][8] = the k of the node's own split.
-  const size_t nv = T.size();
-  struct Row {
-    double c[8];       // c[j], j = 1..7 (c[0] unused)
-    uint8_t split[9];  // j = 2..8
-  };
-  std::vector<Row> R(nv);
-  int32_t root = 0;
-  if (T[0].r < 0 && T[T[0].l].l >= 0) root = T[0].l;  // (a scene whose binary root has one inner child: that child is the root)
-  for (size_t vi = nv; vi-- > 0;) {
-    const V& v = T[vi];
-    Row& row = R[vi];
-    memset(&row, 0, sizeof(row));
-    if (v.l < 0) {
-      for (int j = 1; j < 8; j++) row.c[j] = area(v) * cost_leaf;
-      continue;
-    }
-    if (v.r < 0) {  // pass-through (only vertex 0 can be one)
-      for (int j = 1; j < 8; j++) row.c[j] = R[v.l].c[j];
-      continue;
-    }
-    const Row &L = R[v.l], &Rr = R[v.r];
-    double D[9];
-    for (int j = 2; j <= 8; j++) {
-      double best = 1e300;
-      int bk = 1;
-      for (int k = 1; k < j; k++) {
-        if (k > 7 || j - k > 7) continue;
-        const double c = L.c[k] + Rr.c[j - k];
-        if (c < best) best = c, bk = k;
-      }
-      D[j] = best;
-      row.split[j] = (uint8_t)bk;
-    }
-    row.c[1] = area(v) * cost_node + D[8];
-    for (int j = 2; j < 8; j++) {
-      if (D[j] < row.c[j - 1]) row.c[j] = D[j];
-      else row.c[j] = row.c[j - 1], row.split[j] = 0;
-    }
-  }
-  // the children of the node of vertex v
-  std::vector<int32_t> kids;
-  std::function<void(int32_t, int)> collect = [&](int32_t u, int j) {
-    const V& v = T[u];
-    if (v.l < 0 || j == 1) {
-      kids.push_back(u);
-      return;
-    }
-    const int k = R[u].split[j];
-    if (k == 0) collect(u, j - 1);
-    else collect(v.l, k), collect(v.r, j - k);
-  };
-  auto children_of = [&](int32_t u) {
-    kids.clear();
-    const V& v = T[u];
-    if (v.l < 0) kids.push_back(u);            // (a scene of one leaf: the root node holds it)
-    else if (v.r < 0) kids.push_back(v.l);     // (vertex 0 over a single leaf)
-    else {
-      const int k = R[u].split[8];
-      collect(v.l, k), collect(v.r, 8 - k);
-    }
-  };
-  struct Item {
-    int32_t v;
-    uint32_t out, depth;  // out: the node's word index
-  };
-  std::vector<Item> work;
-  out->resize(kNode8Words);
-  work.push_back({root, 0u, 1u});
-  uint32_t depth = 0;
-  while (!work.empty()) {
-    const Item it = work.back();
-    work.pop_back();
-    depth = std::max(depth, it.depth);
-    children_of(it.v);
-    const int n = (int)kids.size();
-    if (n < 1 || n > 8) return out->clear(), 0;
-    QChild c[8];
-    float ctr[3] = {0.f, 0.f, 0.f}, nlo[3], nhi[3];
-    for (int a = 0; a < 3; a++) nlo[a] = std::numeric_limits<float>::infinity(), nhi[a] = -nlo[a];
-    for (int i = 0; i < n; i++) {
-      const V& u = T[kids[i]];
-      c[i].ref = 0u;
-      for (int a = 0; a < 3; a++) c[i].lo[a] = u.lo[a], c[i].hi[a] = u.hi[a], nlo[a] = std::min(nlo[a], u.lo[a]), nhi[a] = std::max(nhi[a], u.hi[a]);
-    }
-    for (int a = 0; a < 3; a++) ctr[a] = 0.5f * (nlo[a] + nhi[a]);
-    // slots: child i towards octant s scores sum_a (centre_i[a] - centre[a]) * (s bit a ? +1 : -1); the best remaining pair first
-    int slot[8];
-    {
-      float score[8][8];
-      for (int i = 0; i < n; i++)
-        for (int s2 = 0; s2 < 8; s2++) {
-          float sc = 0.f;
-          for (int a = 0; a < 3; a++) {
-            const float off = 0.5f * (c[i].lo[a] + c[i].hi[a]) - ctr[a];
-            sc += ((s2 >> a) & 1) ? off : -off;
-          }
-          score[i][s2] = std::isfinite(sc) ? sc : 0.f;
-        }
-      bool child_done[8] = {}, slot_used[8] = {};
-      for (int round = 0; round < n; round++) {
-        int bi = -1, bs = -1;
-        for (int i = 0; i < n; i++)
-          for (int s2 = 0; s2 < 8; s2++)
-            if (!child_done[i] && !slot_used[s2] && (bi < 0 || score[i][s2] > score[bi][bs])) bi = i, bs = s2;
-        slot[bi] = bs, child_done[bi] = true, slot_used[bs] = true;
-      }
-    }
-    Node8 nd;
-    memset(&nd, 0, sizeof(nd));
-    if (!quantise_node8(c, slot, n, &nd)) return out->clear(), 0;
-    // the children's items: contiguous, in slot order; an inner node and a triangle leaf take five words, a curve leaf four
-    int order[8], m = 0;
-    for (int s2 = 0; s2 < 8; s2++)
-      for (int i = 0; i < n; i++)
-        if (slot[i] == s2) order[m++] = i;
-    const uint32_t base = (uint32_t)out->size();
-    uint32_t imask = 0, tmask = 0, cmask = 0;
-    for (int k = 0; k < n; k++) {
-      const int i = order[k];
-      const V& u = T[kids[i]];
-      const size_t at = out->size();
-      out->resize(at + kNode8Words);
-      if (u.l < 0) {
-        const int words = emit_leaf(u.token, out->data() + at);
-        if (words == 4) cmask |= 1u << slot[i], out->resize(at + 4);
-        else if (words == 5) tmask |= 1u << slot[i];
-        else return out->clear(), 0;
-      } else {
-        imask |= 1u << slot[i];
-        work.push_back({kids[i], (uint32_t)at, it.depth + 1u});
-      }
-    }
-    nd.base = base, nd.masks = imask | (tmask << 8) | (cmask << 16);
-    static_assert(sizeof(Node8) == kNode8Words * sizeof(float4), "Node8 is five words");
-    memcpy(out->data() + (size_t)it.out, &nd, sizeof(nd));
-  }
-  if (out->size() >= (1u << 30)) return out->clear(), 0;
-  for (int k = 0; k < 4; k++) out->push_back(make_float4(0.f, 0.f, 0.f, 0.f));  // (the load site reads five words of a four-word last item)
-  return depth;
-}
-
 }  // namespace pb

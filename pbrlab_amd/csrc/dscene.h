@@ -93,34 +93,6 @@ static_assert(sizeof(QNode) == 64, "quantised wide node must be 64 B");
 // triangle stores it twice with code_b = kNone.  80 B per leaf instead of 48 B per triangle: -17 % for a pair, +67 % for a single.
 constexpr uint32_t kTriPairWords = 5;
 
-// The O tree (round 5; every scene whose tree is built on the host): EIGHT children per node, quantised like the Q tree's, in 80
-// bytes.  Nodes and leaves live in ONE array of 16-byte words (DScene::wide8) and the children of a node are CONTIGUOUS:
-//   node (5 words)   w0 = org.x org.y org.z s.x     w1 = s.y s.z base masks     w2 = qlo_x[0..7] qlo_y[0..7]   w3 = qlo_z qhi_x   w4 = qhi_y qhi_z
-//   triangle leaf    one TriPair (5 words, above)
-//   curve leaf       4 words: P0 P1 P2 (xyz + radius: piece 0 = P0 P1, piece 1 = P1 P2 -- one or two NEIGHBOURING linear pieces of a
-//                    strand) | code0 code1 (sub0 | sub1 << 8 | (pieces - 1) << 16) 0 : the complete hit codes and the pieces' indices in their cubics
-// A child sits in one of eight SLOTS (byte s & 3 of word s >> 2 of each bound); masks = imask | tmask << 8 | cmask << 16: slot s holds
-// an inner node (imask bit s), a triangle leaf (tmask), a curve leaf (cmask) or nothing; its first word is
-//   base + 5 popcount((imask | tmask) & below) + 4 popcount(cmask & below),  below = (1 << s) - 1.
-// The bounds of an empty slot are never looked at (the hit mask is ANDed with the three masks).
-// Slots are assigned by the builder so that slot s holds the child lying towards (s & 1 ? +x : -x, s & 2 ? +y : -y, s & 4 ? +z : -z)
-// of the node's centre: a ray with direction signs m (bit a = d[a] < 0) visits the hit children in ascending order of s ^ m --
-// near before far without computing, sorting or storing a distance, and what is left of a node is ONE stack entry (base, masks,
-// remaining hits) instead of up to seven references (Ylitie, Karras, Laine 2017, "Efficient incoherent ray traversal on GPUs through
-// compressed wide BVHs": PAPERS.md; the boxes here keep this repository's exact arithmetic, below).  Hits do not depend on the
-// visiting order (the intersection contract, dtrace.h), so every result stays bit-identical.
-// Box arithmetic: a bound is rebuilt as fma(q, s, org) and tested with the binary tree's operations, as for the Q tree
-// (dtrace_pv8.h::box_test8q; the builder checks the containment with that very expression).
-constexpr uint32_t kNode8Words = 5;
-struct alignas(16) Node8 {
-  float org[3], sx;
-  float sy, sz;
-  uint32_t base, masks;
-  uint32_t qlo_x[2], qlo_y[2];
-  uint32_t qlo_z[2], qhi_x[2];
-  uint32_t qhi_y[2], qhi_z[2];
-};
-static_assert(sizeof(Node8) == 80, "an 8-wide node is one 80-byte item, like a TriPair");
 // during a traversal of the Q tree a curve hit is held as kQPointHit | point index; it becomes the hit code every other
 // stage sees (slot | routing bits, below) through DScene::q_hitcode when the ray is delivered
 constexpr uint32_t kQPointHit = 0x80000000u;
@@ -253,8 +225,6 @@ struct DScene {
   uint32_t wide_nodes;
   uint32_t q_tri0, q_pt0;       // 16-byte index of triangle leaf record 0 / point 0 in `wide`
   const uint32_t* q_hitcode;    // per point p: the hit code of piece p (slot | routing bits)
-  const float4* wide8;          // the O tree (8-wide, quantised: Node8 / TriPair / curve leaves in one array of 16-byte words; word 0 = the root node), or null
-  uint32_t wide8_words;
   uint32_t top_nodes;           // nodes 0 .. top_nodes-1 are the breadth-first top of the tree (<= kTopNodes; 0: not numbered that way)
   uint32_t wide_top_nodes;      // the same for the Q tree
   uint32_t lights_transformed;  // an emissive instance has a transform: lrecs / light_boxes are not what the raytracer sees

@@ -91,24 +91,6 @@ struct QChild {
 uint32_t build_qtree(const std::vector<BvhNode>& nodes, const std::function<int(uint32_t, const float*, const float*, QChild*)>& map_leaf,
                      std::vector<QNode>* out);
 
-// The binary tree collapsed to eight children per node (dscene.h::Node8): one array of 16-byte words holding the nodes (five words)
-// and the leaves -- a triangle leaf = one TriPair (five words), a curve leaf = its one or two neighbouring pieces (four words) --,
-// word 0 = the root node, the children of a node contiguous.  Which descendants become the children of a node is chosen by
-// dynamic programming over the surface-area cost (cost(v, j) = the cheapest way to present the subtree of v as at most j children
-// of some node: Ylitie et al. 2017, section 3.1); children go to the slot whose octant direction matches the offset of their
-// centre from the node's best (greedy assignment).
-// split_leaf turns a leaf reference of the binary tree into one or two leaves of the O tree (a curve leaf whose two pieces are not
-// neighbours in a strand becomes two): it fills token / lo / hi and returns the count.  emit_leaf(token, out) writes the leaf's
-// item and returns its size in words (5: TriPair, 4: curve leaf).  Boxes: PRECONDITION and rounding as for build_qtree.
-// Returns the depth of the tree in nodes (a traversal keeps at most one stack entry per level), 0 if the tree cannot be built.
-// cost_node / cost_leaf: the price of a node visit / of a leaf test in the collapse.
-struct Q8Leaf {
-  uint32_t token;
-  float lo[3], hi[3];
-};
-uint32_t build_q8tree(const std::vector<BvhNode>& nodes, const std::function<int(uint32_t, const float*, const float*, Q8Leaf*)>& split_leaf,
-                      const std::function<int(uint32_t, float4*)>& emit_leaf, std::vector<float4>* items, double cost_node = 1.0, double cost_leaf = 1.0);
-
 // The same tree format built on the GPU (bvh_gpu.hip: Morton-order linear BVH).  nodes_out: DEVICE array of
 // max(n - 1, 1) nodes; order_out: slot -> primitive index; depth_out: traversal stack depth needed.
 hipError_t build_bvh_gpu(hipStream_t st, const std::vector<float>& lo, const std::vector<float>& hi,

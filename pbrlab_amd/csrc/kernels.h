@@ -113,8 +113,7 @@ constexpr uint32_t trace_blocks_per_cu(bool curves, bool wide) {
 constexpr uint32_t kTraceGridCap = 256 * (kTraceBlocksPerCU > kTraceBlocksPerCUCurves ? kTraceBlocksPerCU : kTraceBlocksPerCUCurves);  // persistent traversal: at most the resident blocks (sizes the spill area)
 // words of traversal-stack spill area one path group (or one hook call) needs: every resident thread of the largest traversal
 // grid x the entries of its stack that do not live in LDS (the one-ray-per-lane kernels -- k_tail, the simple hooks -- run
-// smaller grids: (kStackDepth - kSimpleLdsStack) x 4096 x 256 and x PB_TAIL_BLOCKS x 256; the O tree's kernels keep 8-byte
-// entries, at most kStackDepth words per thread: dtrace_pv8.h)
+// smaller grids: (kStackDepth - kSimpleLdsStack) x 4096 x 256 and x PB_TAIL_BLOCKS x 256)
 constexpr size_t kSpillWords = (size_t)kStackDepth * kTraceGridCap * 256;
 static_assert((size_t)(kStackDepth - kSimpleLdsStack) * 4096 * 256 <= kSpillWords, "spill area of the one-ray-per-lane hook grids (grid_for(n, 4096))");
 constexpr uint32_t kShadeGridCap = 256 * 8;
@@ -129,7 +128,6 @@ struct HookHit {  // == pbrhip_hit == TraceResult (raytracer.h:9-17)
 
 void launch_generate(hipStream_t s, const PathState& P, uint32_t npaths);  // clears the radiance of the group's paths (PathState::slot0 ...)
 void launch_trace(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, bool stats);
-bool trace_uses_wide8(const DScene& sc);  // ... the O tree (8-wide; k_trace, k_sss_walk, the phase-voting hooks)
 bool trace_uses_wide(const DScene& sc);  // the traversal kernels walk the 4-wide tree of this scene (now: PBRHIP_WIDE is read per launch)
 void launch_tail(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc, bool stats, bool media, bool textured);
 void launch_classify(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper);

@@ -19,7 +19,6 @@
 #include "dshade.h"
 #include "kernels.h"
 #include "dtrace_pv.h"
-#include "dtrace_pv8.h"
 #include "dtrace_quad.h"
 
 namespace pb {
@@ -224,39 +223,6 @@ __global__ __launch_bounds__(kBlock, trace_blocks_per_cu(CURVES, WIDE) - (FIRST 
   trace_pv<FIRST ? 0 : 2, STATS, CURVES, WIDE>(sc, n_closest + (FIRST ? 0u : n_shadow), &P.counts[kCntHead], sink, stk + threadIdx.x, kBlock,
                              P.spill + blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, st, &overflow,
                              CURVES ? frm + threadIdx.x : nullptr, top, ntop);
-  if (overflow) P.counts[kCntOverflow] = 1u;
-  if (P.wave_log && __lane_id() == 0 && P.wave_log_launch < kWaveLogLaunches) {
-    const uint32_t w = (blockIdx.x * kBlock + threadIdx.x) >> 6;
-    if (w < kWaveLogWaves) {
-      unsigned long long* o = P.wave_log + ((size_t)P.wave_log_launch * kWaveLogWaves + w) * 4;
-      o[0] = t_start, o[1] = wall_clock64(), o[2] = st.it_refill | ((unsigned long long)st.refill_ticks << 32), o[3] = st.it_node + st.it_tri + st.it_curve;
-    }
-  }
-  if (STATS) trace_stats_out(P, st, n_closest, n_shadow);
-}
-
-// The same launch over the O tree (dtrace_pv8.h: eight children per node, nodes and leaves in one array, octant-ordered visits, one
-// stack entry per node): scenes whose tree was built on the host (DScene::wide8).  PBRHIP_WIDE8 selects it (read per launch).
-#ifndef PB_TRACE_BLOCKS_WIDE8
-#define PB_TRACE_BLOCKS_WIDE8 5  // (A/B on C2, 16 spp: 6 blocks per CU with 10 LDS stack entries 13.4 ms -- the tree is deeper than that and the spill path is slow --, 5 blocks with 13: 11.3-11.5, 4: 11.6)
-#endif
-#ifndef PB_TRACE_BLOCKS_WIDE8_CURVES
-#define PB_TRACE_BLOCKS_WIDE8_CURVES 5
-#endif
-constexpr uint32_t trace8_blocks_per_cu(bool curves) { return curves ? PB_TRACE_BLOCKS_WIDE8_CURVES : PB_TRACE_BLOCKS_WIDE8; }
-static_assert(trace8_blocks_per_cu(false) * 256u <= kTraceGridCap && trace8_blocks_per_cu(true) * 256u <= kTraceGridCap, "the O tree's k_trace grids fit the spill area sized by kTraceGridCap");
-template <bool STATS, bool CURVES, bool FIRST = false>
-__global__ __launch_bounds__(kBlock, trace8_blocks_per_cu(CURVES) - (FIRST ? 1 : 0)) void k_trace8(PathState P, DScene sc) {
-  __shared__ uint2 stk[(CURVES ? kPv8LdsStackCurves : kPv8LdsStack) * kBlock];
-  __shared__ float frm[CURVES ? 10 * kBlock : 1];
-  const uint32_t n_closest = P.counts[kCntIn], n_shadow = P.counts[kCntShadowIn];
-  TravStats st = {};
-  uint32_t overflow = 0u;
-  TraceSinkT<CURVES, FIRST> sink = {P, n_closest};
-  const unsigned long long t_start = P.wave_log ? wall_clock64() : 0ull;
-  trace_pv8<FIRST ? 0 : 2, STATS, CURVES>(sc, n_closest + (FIRST ? 0u : n_shadow), &P.counts[kCntHead], sink, stk + threadIdx.x, kBlock,
-                                          reinterpret_cast<uint2*>(P.spill) + blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, st, &overflow,
-                                          CURVES ? frm + threadIdx.x : nullptr);
   if (overflow) P.counts[kCntOverflow] = 1u;
   if (P.wave_log && __lane_id() == 0 && P.wave_log_launch < kWaveLogLaunches) {
     const uint32_t w = (blockIdx.x * kBlock + threadIdx.x) >> 6;
@@ -1196,32 +1162,6 @@ __global__ __launch_bounds__(kBlock, STATS ? PB_WALK_WAVES : walk_blocks_per_cu(
   }
 }
 
-// ... and over the O tree (dtrace_pv8.h)
-template <bool STATS, bool CURVES>
-__global__ __launch_bounds__(kBlock, PB_WALK_WAVES) void k_sss_walk8(PathState P, DScene sc, uint64_t rng_inc) {
-  __shared__ uint2 stk[(CURVES ? kPv8LdsStackCurves : kPv8LdsStack) * kBlock];
-  __shared__ float frm[CURVES ? 10 * kBlock : 1];
-  __shared__ float walk[kWalkWords * kBlock];
-  const uint32_t n = P.counts[kCntSss];
-  TravStats st = {};
-  uint32_t overflow = 0u;
-  WalkSink sink = {P, rng_inc, walk + threadIdx.x, 0u};
-  trace_pv8<0, STATS, CURVES>(sc, n, &P.counts[kCntWalkHead], sink, stk + threadIdx.x, kBlock,
-                              reinterpret_cast<uint2*>(P.spill) + blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, st, &overflow,
-                              CURVES ? frm + threadIdx.x : nullptr);
-  if (overflow) P.counts[kCntOverflow] = 1u;
-  if (STATS) {
-    const uint32_t a = wave_sum(sink.n_rays), nn = wave_sum(st.nodes), nt = wave_sum(st.tris + st.curves);
-    if (__lane_id() == 0 && a) atomicAdd(&P.stats[kStatTailClosestRays], (unsigned long long)a);
-    if (__lane_id() == 0) {
-      atomicAdd(&P.stats[kStatWalkNodes], (unsigned long long)nn), atomicAdd(&P.stats[kStatWalkTris], (unsigned long long)nt);
-      atomicAdd(&P.stats[kStatWalkTurns], (unsigned long long)(st.it_node + st.it_tri + st.it_curve));
-      atomicAdd(&P.stats[kStatWalkSteps], (unsigned long long)st.it_refill);
-      atomicAdd(&P.stats[kStatWalkCycTrav], st.cyc[0] + st.cyc[1] + st.cyc[2]), atomicAdd(&P.stats[kStatWalkCycStep], st.cyc[3]);
-    }
-  }
-}
-
 // ------------------------------------------------------------------ k_tail
 // The tail of a chunk -- few live paths, many bounces left -- is bound by latency, not throughput: every wavefront
 // iteration costs ~0.2 ms of launches and drains however few paths it moves (91 iterations on C2, 70 of them with
@@ -1582,18 +1522,6 @@ __global__ __launch_bounds__(kBlock) void k_hook_pv(DScene sc, const float4* __r
                              spill + blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, st, &overflow, CURVES ? frm + threadIdx.x : nullptr);
   if (overflow) counts[kCntOverflow] = 1u;
 }
-template <bool ANY, bool CURVES>  // the O tree (dtrace_pv8.h): the variant k_trace8 runs
-__global__ __launch_bounds__(kBlock) void k_hook_pv8(DScene sc, const float4* __restrict__ rays, uint32_t n, HookHit* hits, uint8_t* occ, uint32_t* counts,
-                                                     uint32_t* spill) {
-  __shared__ uint2 stk[(CURVES ? kPv8LdsStackCurves : kPv8LdsStack) * kBlock];
-  __shared__ float frm[CURVES ? 10 * kBlock : 1];
-  TravStats st = {};
-  uint32_t overflow = 0u;
-  HookSink sink = {sc, rays, hits, occ};
-  trace_pv8<ANY ? 1 : 0, false, CURVES>(sc, n, &counts[kCntHead], sink, stk + threadIdx.x, kBlock, reinterpret_cast<uint2*>(spill) + blockIdx.x * kBlock + threadIdx.x,
-                                        gridDim.x * kBlock, st, &overflow, CURVES ? frm + threadIdx.x : nullptr);
-  if (overflow) counts[kCntOverflow] = 1u;
-}
 // One ray per thread, plain stack traversal (dtrace.h): an independent second implementation, selected with
 // PBRHIP_SIMPLE_TRAVERSAL=1, that must agree with the production traversal bit for bit.
 template <bool CURVES, bool WIDE>
@@ -1673,18 +1601,6 @@ static inline bool use_wide(const DScene& sc) {
     else hipLaunchKernelGGL((KERNEL<PRE, false, false>), __VA_ARGS__);                          \
   } while (0)
 bool trace_uses_wide(const DScene& sc) { return use_wide(sc); }
-// the O tree (8-wide, dtrace_pv8.h) serves k_trace, k_sss_walk and the phase-voting hooks of the scenes that have one (PBRHIP_WIDE8=0 / 1: never / always; read per launch)
-#ifndef PB_WIDE8_DEFAULT
-#define PB_WIDE8_DEFAULT 0         // triangle-only scenes: measured equal to the Q tree (profiles/README.md)
-#endif
-#ifndef PB_WIDE8_DEFAULT_CURVES
-#define PB_WIDE8_DEFAULT_CURVES 0  // scenes with curves: measured 11 % slower than the Q tree on C4 (10.0 instead of 14.2 node visits per ray, but 1.5x the instructions per visit and 7.2 instead of 6.6 piece tests)
-#endif
-static inline bool use_wide8(const DScene& sc) {
-  const char* e = getenv("PBRHIP_WIDE8");
-  return sc.wide8 != nullptr && use_wide(sc) && (e ? atoi(e) != 0 : (sc.num_curves != 0 ? PB_WIDE8_DEFAULT_CURVES != 0 : PB_WIDE8_DEFAULT != 0));
-}
-bool trace_uses_wide8(const DScene& sc) { return use_wide8(sc); }
 #ifndef PB_TRACE_SMALL1_RAYS
 #define PB_TRACE_SMALL1_RAYS 16000000u  // launches of at most this many rays (upper bound): PB_TRACE_SMALL1_BLOCKS blocks per CU
 #define PB_TRACE_SMALL1_BLOCKS 4u
@@ -1742,27 +1658,6 @@ void launch_trace(hipStream_t s, const PathState& P, const DScene& sc, uint32_t 
     if (n_upper <= PB_TRACE_SMALL2_RAYS) cap = std::min(cap, 256u * PB_TRACE_SMALL2_BLOCKS);
     else if (n_upper <= PB_TRACE_SMALL1_RAYS) cap = std::min(cap, 256u * PB_TRACE_SMALL1_BLOCKS);
   }
-  const bool wide8 = use_wide8(sc) && (P.first || curves || n_upper > quad_rays());
-  if (wide8) {
-    // (the resident-block rules of the Q tree's kernel; its launch bounds allow trace8_blocks_per_cu)
-    cap = std::min(cap, 256u * trace8_blocks_per_cu(curves));
-    if (P.first) cap = std::max(cap, 512u) - 256u;
-    const dim3 g8(blocks < 1u ? 1u : (blocks < cap ? blocks : cap));
-#define PB_LAUNCH8(ST, FI)                                                                       \
-  do {                                                                                           \
-    if (curves) hipLaunchKernelGGL((k_trace8<ST, true, FI>), g8, dim3(kBlock), 0, s, P, sc);     \
-    else hipLaunchKernelGGL((k_trace8<ST, false, FI>), g8, dim3(kBlock), 0, s, P, sc);           \
-  } while (0)
-    if (P.first) {
-      if (stats) PB_LAUNCH8(true, true);
-      else PB_LAUNCH8(false, true);
-    } else {
-      if (stats) PB_LAUNCH8(true, false);
-      else PB_LAUNCH8(false, false);
-    }
-#undef PB_LAUNCH8
-    return;
-  }
   if (P.first) {
     // a group's first launch: camera rays only, computed by the sink (TraceSinkT<.., FIRST>); always the phase-voting kernel
     if (trace_first_less(stats, curves)) cap = std::max(cap, 512u) - 256u;  // (its launch bounds: one block per CU fewer; never below one block per CU -- PBRHIP_TRACE_BLOCKS=1 used to make this 0)
@@ -1818,16 +1713,9 @@ void launch_sss_walk(hipStream_t s, const PathState& P, const DScene& sc, uint32
   const char* ww = getenv("PBRHIP_WIDE_WALK");
   const bool wide = use_wide(sc) && !(ww && atoi(ww) == 0);
   // persistent: the resident blocks (<= kTraceGridCap: the walk shares k_trace's spill area)
-  const uint32_t cap = 256u * ((stats || (wide && use_wide8(sc))) ? (uint32_t)PB_WALK_WAVES : walk_blocks_per_cu(curves, wide));
+  const uint32_t cap = 256u * (stats ? (uint32_t)PB_WALK_WAVES : walk_blocks_per_cu(curves, wide));
   const uint32_t blocks = (n_upper + 15u) / 16u;
   dim3 g(blocks < 1u ? 1u : (blocks < cap ? blocks : cap));
-  if (wide && use_wide8(sc)) {
-    if (stats && curves) hipLaunchKernelGGL((k_sss_walk8<true, true>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
-    else if (stats) hipLaunchKernelGGL((k_sss_walk8<true, false>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
-    else if (curves) hipLaunchKernelGGL((k_sss_walk8<false, true>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
-    else hipLaunchKernelGGL((k_sss_walk8<false, false>), g, dim3(kBlock), 0, s, P, sc, rng_inc);
-    return;
-  }
   if (stats) PB_LAUNCH_TRAV(k_sss_walk, true, curves, wide, g, dim3(kBlock), 0, s, P, sc, rng_inc);
   else PB_LAUNCH_TRAV(k_sss_walk, false, curves, wide, g, dim3(kBlock), 0, s, P, sc, rng_inc);
 }
@@ -1880,11 +1768,6 @@ void launch_hook_closest(hipStream_t s, const DScene& sc, const float4* rays, ui
     return;
   }
   const dim3 g(grid_for(n, kTraceGridCap));
-  if (use_wide8(sc)) {
-    if (sc.num_curves) hipLaunchKernelGGL((k_hook_pv8<false, true>), g, dim3(kBlock), 0, s, sc, rays, n, out, (uint8_t*)nullptr, counts, spill);
-    else hipLaunchKernelGGL((k_hook_pv8<false, false>), g, dim3(kBlock), 0, s, sc, rays, n, out, (uint8_t*)nullptr, counts, spill);
-    return;
-  }
   if (wide && curves) hipLaunchKernelGGL((k_hook_pv<false, true, true>), g, dim3(kBlock), 0, s, sc, rays, n, out, (uint8_t*)nullptr, counts, spill);
   else if (wide) hipLaunchKernelGGL((k_hook_pv<false, false, true>), g, dim3(kBlock), 0, s, sc, rays, n, out, (uint8_t*)nullptr, counts, spill);
   else hipLaunchKernelGGL((k_hook_pv<false, true, false>), g, dim3(kBlock), 0, s, sc, rays, n, out, (uint8_t*)nullptr, counts, spill);
@@ -1903,11 +1786,6 @@ void launch_hook_any(hipStream_t s, const DScene& sc, const float4* rays, uint32
     return;
   }
   const dim3 g(grid_for(n, kTraceGridCap));
-  if (use_wide8(sc)) {
-    if (sc.num_curves) hipLaunchKernelGGL((k_hook_pv8<true, true>), g, dim3(kBlock), 0, s, sc, rays, n, (HookHit*)nullptr, out, counts, spill);
-    else hipLaunchKernelGGL((k_hook_pv8<true, false>), g, dim3(kBlock), 0, s, sc, rays, n, (HookHit*)nullptr, out, counts, spill);
-    return;
-  }
   if (wide && curves) hipLaunchKernelGGL((k_hook_pv<true, true, true>), g, dim3(kBlock), 0, s, sc, rays, n, (HookHit*)nullptr, out, counts, spill);
   else if (wide) hipLaunchKernelGGL((k_hook_pv<true, false, true>), g, dim3(kBlock), 0, s, sc, rays, n, (HookHit*)nullptr, out, counts, spill);
   else hipLaunchKernelGGL((k_hook_pv<true, true, false>), g, dim3(kBlock), 0, s, sc, rays, n, (HookHit*)nullptr, out, counts, spill);

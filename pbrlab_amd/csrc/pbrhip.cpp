@@ -658,7 +658,7 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
   // children per node with quantised boxes (64 B per node), followed by its own compact triangle slots and by the curve
   // pieces stored as chains of points (16 B per piece instead of a 64-byte slot): dscene.h::QNode.
   std::vector<QNode> wide;
-  std::vector<float4> qtri, qpts, wide8;
+  std::vector<float4> qtri, qpts;
   std::vector<uint32_t> qhit;
   const char* wide_env = getenv("PBRHIP_WIDE");
   static_assert(kMaxLeaf <= 2, "build_qtree expects at most two primitives per leaf of the binary tree");
@@ -750,51 +750,6 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
       return 1;
     };
     if (qpts.size() >= (1u << 27) || build_qtree(bvh.nodes, map_leaf, &wide) > (uint32_t)kStackDepth) wide.clear();
-    // The O tree (dscene.h::Node8; dtrace_pv8.h): eight children per node; nodes, TriPairs and curve leaves in one array of 16-byte
-    // words.  PBRHIP_WIDE8=0 at commit: none.  PBRHIP_Q8_COST="node,leaf": the collapse's prices (tuning).
-    const char* w8 = getenv("PBRHIP_WIDE8");
-    if (!wide.empty() && !(w8 && atoi(w8) == 0)) {
-      double cn = 1.0, cl = 1.0;
-      if (const char* e = getenv("PBRHIP_Q8_COST")) sscanf(e, "%lf,%lf", &cn, &cl);
-      // token of a leaf: first slot << 1 | (count - 1); two curve pieces are one leaf when the second starts where the first ends
-      // (or the other way round), bit for bit: the neighbouring pieces of a strand
-      auto joined = [&](uint32_t a, uint32_t b) { return memcmp(&slots[4 * (size_t)a + 1], &slots[4 * (size_t)b], 16) == 0; };
-      auto split_leaf = [&](uint32_t ref, const float* blo, const float* bhi, Q8Leaf* o) -> int {
-        const uint32_t first = (ref & 0x3FFFFFFFu) >> 3, count = (ref & 7u) + 1u;
-        if ((ref & kCurveBit) && count == 2 && !joined(first, first + 1) && !joined(first + 1, first)) {
-          for (uint32_t i = 0; i < 2; i++) {
-            const uint32_t g = bvh.slot_gid[first + i];
-            o[i].token = (first + i) << 1;
-            for (int a = 0; a < 3; a++) o[i].lo[a] = BvhNode::widen_lo(lo[3 * (size_t)g + a]), o[i].hi[a] = BvhNode::widen_hi(hi[3 * (size_t)g + a]);
-          }
-          return 2;
-        }
-        o[0].token = (first << 1) | (count - 1u);
-        for (int a = 0; a < 3; a++) o[0].lo[a] = blo[a], o[0].hi[a] = bhi[a];
-        return 1;
-      };
-      auto emit_leaf = [&](uint32_t token, float4* o) -> int {
-        const uint32_t first = token >> 1, count = (token & 1u) + 1u;
-        if (kinds[bvh.slot_gid[first]] == 0) {
-          pair_words(first, count, o);
-          return (int)kTriPairWords;
-        }
-        uint32_t a = first, b = first;  // the pieces in strand order
-        if (count == 2) {
-          if (joined(first, first + 1)) b = first + 1;
-          else a = first + 1;
-        }
-        o[0] = slots[4 * (size_t)a], o[1] = slots[4 * (size_t)a + 1];
-        o[2] = count == 2 ? slots[4 * (size_t)b + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
-        const uint32_t sub_a = __builtin_bit_cast(uint32_t, slots[4 * (size_t)a + 2].x), sub_b = __builtin_bit_cast(uint32_t, slots[4 * (size_t)b + 2].x);
-        o[3] = make_float4(__builtin_bit_cast(float, slot_code[a]), __builtin_bit_cast(float, count == 2 ? slot_code[b] : kNone),
-                           __builtin_bit_cast(float, (sub_a & 255u) | ((sub_b & 255u) << 8) | ((count - 1u) << 16)), 0.f);
-        return 4;
-      };
-      const uint32_t depth8 = build_q8tree(bvh.nodes, split_leaf, emit_leaf, &wide8, cn, cl);
-      if (depth8 == 0 || depth8 > 32u) wide8.clear();  // (kStackDepth8 of dtrace_pv8.h: one stack entry per level)
-      if (getenv("PBRHIP_DEBUG")) fprintf(stderr, "pbrhip: commit: O tree depth %u\n", depth8);
-    }
   }
   if (wide.empty()) s->d_wide.release(), s->d_qhit.release();
   if (getenv("PBRHIP_DEBUG")) fprintf(stderr, "pbrhip: commit: %u binary nodes, %zu wide nodes, %zu slots, %zu triangle leaves + %zu points in the Q tree\n", num_nodes, wide.size(), (size_t)ns, qtri.size() / kTriPairWords, qpts.size());
@@ -804,26 +759,6 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
     if (!qtri.empty()) HIPCHK(hipMemcpyAsync(s->d_wide.p + wide.size() * 4, qtri.data(), qtri.size() * 16, hipMemcpyHostToDevice, st));
     if (!qpts.empty()) HIPCHK(hipMemcpyAsync(s->d_wide.p + wide.size() * 4 + qtri.size(), qpts.data(), qpts.size() * 16, hipMemcpyHostToDevice, st));
     HIPCHK(s->d_qhit.upload(qhit, st));
-  }
-  if (wide8.empty()) s->d_wide8.release();
-  else HIPCHK(s->d_wide8.upload(wide8, st));
-  if (getenv("PBRHIP_DEBUG") && !wide8.empty()) {
-    size_t nodes8 = 0, kids8 = 0;
-    std::vector<uint32_t> todo{0u};
-    while (!todo.empty()) {
-      const uint32_t at = todo.back();
-      todo.pop_back();
-      Node8 nd;
-      memcpy(&nd, &wide8[at], sizeof(nd));
-      const uint32_t im = nd.masks & 255u, tm = (nd.masks >> 8) & 255u, cm = (nd.masks >> 16) & 255u;
-      nodes8++, kids8 += (size_t)__builtin_popcount(im | tm | cm);
-      for (int k = 0; k < 8; k++)
-        if ((im >> k) & 1u) {
-          const uint32_t below = (1u << k) - 1u;
-          todo.push_back(nd.base + 5u * (uint32_t)__builtin_popcount((im | tm) & below) + 4u * (uint32_t)__builtin_popcount(cm & below));
-        }
-    }
-    fprintf(stderr, "pbrhip: commit: O tree: %zu words (%zu nodes, %.2f children per node)\n", wide8.size(), nodes8, (double)kids8 / (double)std::max<size_t>(nodes8, 1));
   }
   HIPCHK(s->d_shade.upload(shade, st));
   HIPCHK(s->d_materials.upload(mats, st));
@@ -857,7 +792,6 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
   for (uint8_t kd : kinds) d.num_curves += kd ? 1u : 0u;
   d.wide = wide.empty() ? nullptr : s->d_wide.p, d.wide_nodes = (uint32_t)wide.size();
   d.q_tri0 = (uint32_t)wide.size() * 4u, d.q_pt0 = d.q_tri0 + (uint32_t)qtri.size(), d.q_hitcode = wide.empty() ? nullptr : s->d_qhit.p;
-  d.wide8 = wide8.empty() ? nullptr : s->d_wide8.p, d.wide8_words = (uint32_t)wide8.size();
   d.top_nodes = gpu_built ? 0u : std::min<uint32_t>(num_nodes, (uint32_t)kTopNodes);
   d.wide_top_nodes = std::min<uint32_t>((uint32_t)wide.size(), (uint32_t)kTopNodes);
   // light sampling works on the meshes' local positions (light-manager.h:128-136 "TODO transform"), the raytracer on the
@@ -1489,7 +1423,7 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
     publish(done);
   }
   S.passes_done = done;
-  S.node_bytes = trace_uses_wide8(s->dscene) ? sizeof(Node8) : (trace_uses_wide(s->dscene) ? sizeof(QNode) : sizeof(BvhNode));
+  S.node_bytes = trace_uses_wide(s->dscene) ? sizeof(QNode) : sizeof(BvhNode);
   S.curve_bytes = trace_uses_wide(s->dscene) ? 32 : 64;
   S.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   if (stats) *stats = S;

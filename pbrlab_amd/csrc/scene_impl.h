@@ -94,7 +94,6 @@ struct pbrhip_scene {
   // device scene
   pb::DevBuf<pb::BvhNode> d_nodes;
   pb::DevBuf<float4> d_wide;  // the Q tree: quantised 4-wide nodes + its triangle slots + curve points (DScene::wide), host-built trees only
-  pb::DevBuf<float4> d_wide8;  // the O tree (8-wide): 80-byte items, nodes and TriPairs (DScene::wide8); triangle-only host-built trees
   pb::DevBuf<uint32_t> d_qhit;  // hit code per curve point of the Q tree (DScene::q_hitcode)
   pb::DevBuf<pb::ShadeRec> d_shade;
   pb::DevBuf<pb::Material> d_materials;
@@ -125,7 +124,7 @@ struct pbrhip_scene {
   uint32_t xk_key[7] = {0, 0, 0, 0, 0, 0, 0};     // w, h, world, block, first rank, end rank, skipped rank
 
   size_t device_bytes() const {
-    return d_nodes.n * sizeof(pb::BvhNode) + d_wide.n * sizeof(float4) + d_wide8.n * sizeof(float4) + d_qhit.n * 4 + d_shade.n * sizeof(pb::ShadeRec) + d_materials.n * sizeof(pb::Material) +
+    return d_nodes.n * sizeof(pb::BvhNode) + d_wide.n * sizeof(float4) + d_qhit.n * 4 + d_shade.n * sizeof(pb::ShadeRec) + d_materials.n * sizeof(pb::Material) +
            d_lrecs.n * sizeof(pb::LightRec);
   }
 };

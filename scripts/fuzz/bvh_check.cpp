@@ -14,7 +14,7 @@ static bool inside(const float* lo, const float* hi, const float* l, const float
 int main() {
   std::mt19937 rng(7);
   std::uniform_real_distribution<float> U(-1.f, 1.f);
-  size_t cases = 0, cases8 = 0;
+  size_t cases = 0;
   for (int it = 0; it < 400; ++it) {
     uint32_t n = it < 8 ? (uint32_t)it : (uint32_t)(rng() % 3000);
     std::vector<float> lo(3 * (size_t)n), hi(3 * (size_t)n);
@@ -27,7 +27,7 @@ int main() {
       if (mode == 3 && i % 2) { c[0] = lo[3 * (i - 1)], c[1] = lo[3 * (i - 1) + 1], c[2] = lo[3 * (i - 1) + 2]; }   // duplicates
       float e = mode == 4 ? 0.f : 0.05f * (U(rng) + 1.f);
       for (int a = 0; a < 3; a++) lo[3 * i + a] = c[a] - (mode == 3 ? 0.f : e), hi[3 * i + a] = c[a] + e;
-      kinds[i] = (uint8_t)(it % 3 != 0 && rng() % 4 == 0);  // (every third case: triangles only -- the O tree's precondition)
+      kinds[i] = (uint8_t)(it % 3 != 0 && rng() % 4 == 0);  // (every third case: triangles only)
     }
     FlatBvh b;
     build_bvh(lo, hi, kinds, &b);
@@ -144,96 +144,8 @@ int main() {
     if (wide_prims != n) return printf("FAIL: %zu prims in wide leaves, %u expected\n", wide_prims, n), 1;
     for (int v : visited) if (v != 1) return printf("FAIL: unreachable wide node\n"), 1;
     if (bound != need) return printf("FAIL: stack need %u reported, %u found\n", bound, need), 1;
-    // the O tree (eight children per node; nodes, triangle leaves and curve leaves in one array of 16-byte words: dscene.h::Node8).
-    // Checked: word 0 is a node, every item reachable exactly once and the children of a node contiguous in slot order (so the
-    // words are covered without gap or overlap), every leaf of the binary tree in exactly one slot (a curve leaf whose two pieces
-    // are not neighbours -- here: pieces g, g + 1 -- as two), leaf kinds, every quantised child box -- rebuilt with fmaf(q, s, org)
-    // -- AND every ancestor's contains the widened boxes of the primitives below it, the reported depth is the true one.
-    {
-      // token = first slot << 1 | (count - 1); a leaf's item: word 0 = (first slot, count, marker, kind)
-      auto split_leaf = [&](uint32_t ref, const float* blo, const float* bhi, Q8Leaf* o) -> int {
-        const uint32_t first = (ref & 0x3FFFFFFFu) >> 3, cnt = (ref & 7u) + 1u;
-        if ((ref & kCurveBit) && cnt == 2) {
-          const uint32_t p0 = b.slot_gid[first], p1 = b.slot_gid[first + 1];
-          if ((p0 > p1 ? p0 - p1 : p1 - p0) != 1u) {
-            for (uint32_t i = 0; i < 2; i++) {
-              const uint32_t g = b.slot_gid[first + i];
-              o[i].token = (first + i) << 1;
-              for (int a = 0; a < 3; a++) o[i].lo[a] = BvhNode::widen_lo(lo[3 * g + a]), o[i].hi[a] = BvhNode::widen_hi(hi[3 * g + a]);
-            }
-            return 2;
-          }
-        }
-        o[0].token = (first << 1) | (cnt - 1u);
-        for (int a = 0; a < 3; a++) o[0].lo[a] = blo[a], o[0].hi[a] = bhi[a];
-        return 1;
-      };
-      auto emit_leaf = [&](uint32_t token, float4* o) -> int {
-        const uint32_t first = token >> 1, cnt = (token & 1u) + 1u;
-        const bool curve = kinds[b.slot_gid[first]] != 0;
-        for (int k = 0; k < 5; k++) o[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        o[0] = make_float4((float)first, (float)cnt, -12345.f, curve ? 1.f : 0.f);
-        return curve ? 4 : 5;
-      };
-      std::vector<float4> items;
-      const uint32_t depth8 = build_q8tree(b.nodes, split_leaf, emit_leaf, &items);
-      if (depth8 == 0 || items.size() < 5 + 4) return printf("FAIL: O tree not built\n"), 1;
-      const size_t nw = items.size() - 4;  // (four words of padding at the end)
-      std::vector<int> covered(nw, 0), prim8(n, 0);
-      struct It8 { uint32_t at, depth; float lo[3], hi[3]; };  // lo / hi: the intersection of the slot boxes of the node's ancestors
-      std::vector<It8> st8{{0u, 1u, {-INFINITY, -INFINITY, -INFINITY}, {INFINITY, INFINITY, INFINITY}}};
-      for (int k = 0; k < 5; k++) covered[k]++;
-      uint32_t true_depth = 0;
-      size_t prims8 = 0;
-      while (!st8.empty()) {
-        const It8 it8 = st8.back(); st8.pop_back();
-        true_depth = std::max(true_depth, it8.depth);
-        Node8 nd;
-        memcpy(&nd, &items[it8.at], sizeof(nd));
-        const uint32_t imask = nd.masks & 255u, tmask = (nd.masks >> 8) & 255u, cmask = (nd.masks >> 16) & 255u, present = imask | tmask | cmask;
-        if ((imask & tmask) || (imask & cmask) || (tmask & cmask) || !present || (nd.masks >> 24)) return printf("FAIL: O node masks\n"), 1;
-        const float sc[3] = {nd.sx, nd.sy, nd.sz};
-        const uint32_t* ql[3] = {nd.qlo_x, nd.qlo_y, nd.qlo_z};
-        const uint32_t* qh[3] = {nd.qhi_x, nd.qhi_y, nd.qhi_z};
-        for (int s8 = 0; s8 < 8; s8++) {
-          if (!((present >> s8) & 1u)) continue;
-          const uint32_t below = (1u << s8) - 1u;
-          const uint32_t at = nd.base + 5u * (uint32_t)__builtin_popcount((imask | tmask) & below) + 4u * (uint32_t)__builtin_popcount(cmask & below);
-          const uint32_t words = ((cmask >> s8) & 1u) ? 4u : 5u;
-          if (at + words > nw) return printf("FAIL: O item range\n"), 1;
-          for (uint32_t k = 0; k < words; k++) if (covered[at + k]++) return printf("FAIL: O items overlap\n"), 1;
-          float bl[3], bh[3];
-          for (int a = 0; a < 3; a++) {
-            if (!(sc[a] > 0.f) || !std::isfinite(sc[a])) return printf("FAIL: O step\n"), 1;
-            bl[a] = fmaf((float)((ql[a][s8 >> 2] >> (8 * (s8 & 3))) & 255u), sc[a], nd.org[a]);
-            bh[a] = fmaf((float)((qh[a][s8 >> 2] >> (8 * (s8 & 3))) & 255u), sc[a], nd.org[a]);
-            bl[a] = std::max(bl[a], it8.lo[a]), bh[a] = std::min(bh[a], it8.hi[a]);  // (every ancestor's box has to contain the primitive)
-          }
-          if (!((imask >> s8) & 1u)) {
-            const float4 w = items[at];
-            if (w.z != -12345.f || (w.w != 0.f) != (((cmask >> s8) & 1u) != 0u)) return printf("FAIL: O leaf item / kind\n"), 1;
-            const uint32_t first = (uint32_t)w.x, cnt = (uint32_t)w.y;
-            for (uint32_t k = 0; k < cnt; k++) {
-              const uint32_t g = b.slot_gid[first + k];
-              if (prim8[g]++) return printf("FAIL: primitive in two O leaves\n"), 1;
-              if ((kinds[g] != 0) != (w.w != 0.f)) return printf("FAIL: O leaf kind\n"), 1;
-              for (int a = 0; a < 3; a++)
-                if (!(bl[a] <= BvhNode::widen_lo(lo[3 * g + a]) && bh[a] >= BvhNode::widen_hi(hi[3 * g + a]))) return printf("FAIL: O box does not contain its primitive\n"), 1;
-            }
-            prims8 += cnt;
-          } else {
-            st8.push_back({at, it8.depth + 1u, {bl[0], bl[1], bl[2]}, {bh[0], bh[1], bh[2]}});
-          }
-        }
-      }
-      if (prims8 != n) return printf("FAIL: %zu prims in O leaves, %u expected\n", prims8, n), 1;
-      for (int v : covered) if (v != 1) return printf("FAIL: O words not covered exactly once\n"), 1;
-      if (depth8 != true_depth) return printf("FAIL: O depth %u reported, %u found\n", depth8, true_depth), 1;
-      cases8++;
-    }
     cases++;
   }
-  if (cases8 < 300) return printf("FAIL: only %zu O-tree cases\n", cases8), 1;
-  printf("bvh builder: %zu cases ok (%zu with the O tree)\n", cases, cases8);
+  printf("bvh builder: %zu cases ok\n", cases);
   return 0;
 }

@@ -654,16 +654,14 @@ def test_triangle_soup_and_ties(pa, seed, extra_slivers):
                 os.environ.pop("PBRHIP_SIMPLE_TRAVERSAL", None)
 
 
-@pytest.mark.parametrize("which", ["PBRHIP_QUAD", "PBRHIP_WIDE8"])
+@pytest.mark.parametrize("which", ["PBRHIP_QUAD"])
 def test_alternative_traversals_bit_exact(pa, pairs, which):
     """Alternative traversals behind environment switches (read per launch): hits do not depend on the visiting order, so soups (ties,
     slivers, tmax == hit distance) and whole renders are bit-identical.
     PBRHIP_QUAD: one ray per quad of lanes (dtrace_quad.h) -- k_tail runs it by default once a wave has at most eight paths left
     (the tail_paths=3000 renders below and every small render of this suite); here the hooks and every k_trace launch
-    (PBRHIP_QUAD_RAYS) run it as well.
-    PBRHIP_WIDE8 = 1 (round 5): k_trace, k_sss_walk and the hooks on the 8-wide O tree (dtrace_pv8.h: 80-byte nodes, octant-ordered
-    visits, one stack entry per node) instead of the 4-wide Q tree -- built, measured equal (triangles) or slower (hair) and left
-    off by default (profiles/README.md).  (Round 4's two-rays-per-lane and wave-pooled traversals were removed in round 5.)"""
+    (PBRHIP_QUAD_RAYS) run it as well.  (Round 4's two-rays-per-lane and wave-pooled traversals were removed in round 5, round 5's
+    8-wide O tree -- measured equal on triangles, 11 % slower on hair: profiles/README.md -- in round 6.)"""
     import _soups
     desc, so, rays = _soups.triangle_soup(2, 30)
     hb = so.trace_closest(rays, brute_force=True)
@@ -677,7 +675,7 @@ def test_alternative_traversals_bit_exact(pa, pairs, which):
     try:
         assert_hits_equal(sg.trace_closest(rays), hb)
         assert np.array_equal(sg.trace_any(short), ob)
-        for name in ("ggx", "sss") + (("hair",) if which == "PBRHIP_WIDE8" else ()):
+        for name in ("ggx", "sss"):
             _, g, o = pairs[name]
             rgba, cnt, _ = o.render(96, 64, 4, threads=4, math_mode=O.MATH_DEVICE)
             for tail in (0xFFFFFFFF, 3000):

@@ -40,10 +40,6 @@ BUDGETS = {
     "k_tail<1, false, true, true>": (168, 0),    # media + curves (C5)
     "k_tail<2, false, false, true>": (168, 0),   # textured materials
     "k_trace_quad<false>": (128, 0),             # one ray per quad of lanes (small launches; off by default)
-    # the O tree's kernels (round 5, off by default): five blocks per CU (96 VGPRs), nothing spilled
-    "k_trace8<false, false, false>": (96, 0),
-    "k_trace8<false, true, false>": (96, 0),
-    "k_sss_walk8<false, false>": (128, 0),
     "k_shade_hair": (128, 0),
     "k_sss_step": (128, 0),
     "k_classify": (64, 0),
