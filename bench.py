@@ -273,6 +273,23 @@ def spawn_ranks(n):
     return subprocess.run(cmd, env=env).returncode
 
 
+def rank_diagnostics(dist, device, render_ms, exchange_ms):
+    """N > 1: what each rank spent per step -- gathered AFTER the timed region -- so that a disappointing scaling figure can be read:
+    per_rank_render_ms[r] = rank r's own Render() (its shard of the frame, blocking), exchange_ms = the slowest rank's time from the end
+    of its render to the frame being complete on rank 0 (the wait for the slowest rank's render is part of it: see exchange_ms_rank0 for
+    the root's own, i.e. the transfer), imbalance = max / mean of the render times.  Every rank calls it (one all_gather)."""
+    import torch
+    mine = torch.tensor([float(render_ms), float(exchange_ms)], dtype=torch.float64, device=device)
+    allr = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(allr, mine)
+    render = [float(t[0]) for t in allr]
+    exch = [float(t[1]) for t in allr]
+    mean = sum(render) / len(render)
+    return {"per_rank_render_ms": render, "exchange_ms": max(exch), "exchange_ms_per_rank": exch, "exchange_ms_rank0": exch[0],
+            "imbalance": max(render) / mean if mean > 0 else None,
+            "slowest_rank": max(range(len(render)), key=render.__getitem__)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -305,8 +322,9 @@ def main():
         dist.init_process_group("gloo")
         t = torch.tensor([dist.get_rank() + 1])
         dist.all_reduce(t)
+        diag = rank_diagnostics(dist, torch.device("cpu"), 10.0 * (dist.get_rank() + 1), 1.0 + dist.get_rank())   # (the N > 1 line's per-rank fields)
         if dist.get_rank() == 0:
-            print(json.dumps({"selftest": dist.get_world_size(), "sum": int(t.item())}))
+            print(json.dumps({"selftest": dist.get_world_size(), "sum": int(t.item()), "diagnostics": diag}))
         dist.destroy_process_group()
         return
     if args.cpu_baseline_child:
@@ -388,9 +406,14 @@ def main():
         else:
             exchange = "torch"                       # reported in config.exchange
 
+    clock = {"render": 0.0, "exchange": 0.0}   # this rank's host clock per phase, summed over the steps of a timed() call
+
     def step(spp, flags=0, to_host=False):
+        t_a = time.perf_counter()
         _, st = api.Render(scene, W, H, spp, tile_rank=rank, tile_world=world, device_out=ptrs, flags=flags,
-                           max_paths_in_flight=args.max_paths, num_streams=args.streams, shard_block=shard_block)
+                           max_paths_in_flight=args.max_paths, num_streams=args.streams, shard_block=shard_block)   # (blocking: the shard is complete in this rank's HBM)
+        t_b = time.perf_counter()
+        clock["render"] += t_b - t_a
         if dist is not None:                   # the only exchange step: the framebuffer, over xGMI
             if exchange == "gather":
                 comm.gather_layer(scene, W, H, ptrs[0], ptrs[1], shard_block=shard_block, root=0)
@@ -402,6 +425,7 @@ def main():
             h_rgba.copy_(rgba, non_blocking=True)
             h_count.copy_(count, non_blocking=True)
         torch.cuda.synchronize()
+        clock["exchange"] += time.perf_counter() - t_b
         return st
 
     def barrier():
@@ -413,6 +437,7 @@ def main():
         for _ in range(warmup):
             step(spp, to_host=to_host)
         barrier()
+        clock["render"] = clock["exchange"] = 0.0
         t0 = time.perf_counter()
         agg = {}
         for _ in range(steps):
@@ -438,6 +463,7 @@ def main():
     # `value`: the frame is complete in rank 0's HBM when a step ends (the scene was resident when it started); the copy of the
     # RenderLayer to the host -- pbrlab's layer is host memory -- is measured separately below ("host_layer", PCIe-inclusive)
     elapsed, agg = timed(spp, args.steps, args.warmup, 0 if args.no_roofline else api.RENDER_TIMING)
+    diag = rank_diagnostics(dist, dev, clock["render"] / args.steps * 1e3, clock["exchange"] / args.steps * 1e3) if dist is not None else None
     check_layer(spp)
     h_elapsed, _ = timed(spp, args.steps, 0, 0, to_host=True)
     host_layer = {"value": W * H * spp * args.steps / h_elapsed / 1e6, "unit": "Msamples/s", "ms_per_step": h_elapsed / args.steps * 1e3,
@@ -568,6 +594,8 @@ def main():
                        "rng": "PCG32((pass<<32)+pixel, 1234567890)"},
             "roofline": roofline, "cpu_baseline": cpu, "host_layer": host_layer,
         }
+        if diag is not None:   # N > 1: where each rank's time went (gathered after the timed region)
+            out.update(diag)
         if other is not None:
             out["weak" if not weak else "strong"] = other
         print(json.dumps(out))

@@ -112,13 +112,17 @@ typedef struct {
   uint64_t passes_done; /* passes every pixel of this rank holds when the call returns (= num_sample unless cancelled) */
   uint64_t node_bytes;  /* footprint of one node of the tree k_trace walked: 64 (the Q tree: 4 children, quantised boxes; or the binary tree) */
   uint64_t curve_bytes; /* bytes fetched per curve-piece test: 32 (Q tree: two 16-byte points of a chain) or 64 (binary tree: one slot) */
+  uint64_t suspended_rays; /* PBRHIP_RENDER_STATS: closest-hit rays a k_trace launch suspended at its drain and the next launch resumed
+                              (counted ONCE in closest_rays; their node / primitive counts are complete: nothing is traversed twice) */
+  double ms_host_idle;  /* PBRHIP_RENDER_TIMING: sum over the path groups of the time their stream sat empty between two bursts of
+                           launches (the host's round trips; 0 when the next iteration was always enqueued in time) */
 } pbrhip_render_stats;
 
 /* Layout version of the structs of this header (pbrhip_render_desc, pbrhip_render_stats, pbrhip_*_param, pbrhip_hit): it
- * changes whenever one of them changes (3 -> 4: pbrhip_render_stats grew by curve_bytes).  The library writes whole structs
+ * changes whenever one of them changes (3 -> 4: pbrhip_render_stats grew by curve_bytes; 5 -> 6: by suspended_rays, ms_host_idle).  The library writes whole structs
  * (n of them for pbrhip_render_multi), so a caller compiled against another version must not call it: check
  * pbrhip_abi_version() == PBRHIP_ABI_VERSION once after loading (include/pbrlab_hip.hpp and pbrlab_amd/api.py do). */
-#define PBRHIP_ABI_VERSION 5u
+#define PBRHIP_ABI_VERSION 6u
 uint32_t pbrhip_abi_version(void);
 /* Which implementation of cos / sin / exp / log -- the reference's std::cos ... on float, sampler/sampling-utils.h:10-14,
  * closure/microfacet-ggx.h:55-118, shader/random-walk-sss.h:116,183,192-194 -- this build of the library computes with:

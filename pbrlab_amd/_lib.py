@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PBRHIP_LIB") or os.path.join(HERE, "libpbrhip.so")  # PBRHIP_LIB: A/B builds
 CSRC = os.path.join(HERE, "csrc")
 
-ABI_VERSION = 5  # PBRHIP_ABI_VERSION of include/pbrhip.h (struct layouts of this binding)
+ABI_VERSION = 6  # PBRHIP_ABI_VERSION of include/pbrhip.h (struct layouts of this binding)
 
 # every symbol include/pbrhip.h declares
 EXPORTS = [

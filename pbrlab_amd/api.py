@@ -57,7 +57,8 @@ class RenderStats(C.Structure):
                                            "ms_shade_hair", "ms_sss_step", "ms_tail", "ms_accumulate", "ms_compact")] +
                 [(n, C.c_uint64) for n in ("n_trace_closest", "n_tail", "n_surface", "n_shade_principled",
                                            "n_shade_hair", "n_sss_step")] + [("ms_total", C.c_double)] +
-                [(n, C.c_uint64) for n in ("tail_closest_rays", "tail_shadow_rays", "pruned_rays", "passes_done", "node_bytes", "curve_bytes")])
+                [(n, C.c_uint64) for n in ("tail_closest_rays", "tail_shadow_rays", "pruned_rays", "passes_done", "node_bytes", "curve_bytes", "suspended_rays")] +
+                [("ms_host_idle", C.c_double)])
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

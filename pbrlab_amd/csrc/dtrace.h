@@ -31,6 +31,8 @@ struct TravStats {
   uint32_t ahist[8], amax_steps;  // the same for any-hit (shadow) rays
   uint32_t refill_ticks;          // 100 MHz ticks the wave spent in refills (lane 0)
   unsigned long long cyc[4];      // shader-clock cycles (s_memtime) of the wave's loop turns by what the turn did: node, triangle, curve phase, refill (lane 0)
+  uint32_t suspended;             // rays this lane suspended (dtrace_pv.h)
+  unsigned long long t_exhausted; // 100 MHz clock when this wave found the ray queue empty (0: never; always recorded, once per wave: PBRHIP_WAVE_LOG)
 };
 
 __device__ __forceinline__ V3 ld3(const float4& a) { return V3(a.x, a.y, a.z); }
@@ -198,6 +200,33 @@ __device__ __forceinline__ bool segment_test(const float4& a, const float4& b, u
 __device__ __forceinline__ bool segment_test(const float4& a, const float4& b, uint32_t i, V3 o, V3 d, V3 inv3, float tmin, float tmax,
                                              float& t, float& u, float& v) {
   return segment_test(a, b, i, o, ray_frame(d), inv3, tmin, tmax, t, u, v);
+}
+// ... in two steps, so that a leaf of two NEIGHBOURING pieces (points a b c: pieces a-b and b-c) projects its middle point once:
+// segment_project = a point in the ray's frame (x, y across the ray, z along it); segment_core = the test on two projected points.
+// The expressions are segment_test's own, so each piece gets segment_test's bits.
+__device__ __forceinline__ V3 segment_project(const float4& a, V3 o, const RayFrame& f) {
+  const V3 ra = V3(a.x, a.y, a.z) - o;
+  return V3(dot(ra, f.bx), dot(ra, f.by), dot(ra, f.dn));
+}
+__device__ __forceinline__ bool segment_core(const float4& a, const float4& b, V3 pa, V3 pb, uint32_t i, V3 o, float inv_len, V3 inv3, float tmin, float tmax,
+                                             float& t, float& u, float& v) {
+  const float pxa = pa.x, pya = pa.y, pza = pa.z, pxb = pb.x, pyb = pb.y, pzb = pb.z;
+  float ex = pxb - pxa, ey = pyb - pya;
+  float len2 = ex * ex + ey * ey;
+  if (!(len2 > 0.0f)) return false;
+  float s = -(pxa * ex + pya * ey) / len2;
+  if (!(s >= 0.0f && s <= 1.0f)) return false;
+  float dist = (ey * pxa - ex * pya) / sqrtf(len2);
+  float r = a.w + s * (b.w - a.w);
+  if (!(r > 0.0f && fabsf(dist) <= r)) return false;
+  float tt = (pza + s * (pzb - pza)) * inv_len;
+  if (!(tt > tmin && tt <= tmax)) return false;
+  const float rm = __builtin_fmaxf(fabsf(a.w), fabsf(b.w));
+  const V3 lo(__builtin_fminf(a.x, b.x) - rm, __builtin_fminf(a.y, b.y) - rm, __builtin_fminf(a.z, b.z) - rm);
+  const V3 hi(__builtin_fmaxf(a.x, b.x) + rm, __builtin_fmaxf(a.y, b.y) + rm, __builtin_fmaxf(a.z, b.z) + rm);
+  if (!hit_inside(lo, hi, o, inv3, tt)) return false;
+  t = tt, u = ((float)i + s) * 0.25f, v = dist / r;
+  return true;
 }
 __device__ __forceinline__ bool segment_test(const float4& a, const float4& b, uint32_t i, V3 o, const RayFrame& f, V3 inv3, float tmin,
                                              float tmax, float& t, float& u, float& v) {

@@ -18,7 +18,10 @@
 
 namespace pb {
 
-constexpr uint32_t kPvBatch = 512;        // rays grabbed per atomicAdd, at most
+#ifndef PB_BATCH
+#define PB_BATCH 512
+#endif
+constexpr uint32_t kPvBatch = PB_BATCH;   // rays grabbed per atomicAdd, at most
 #ifndef PB_GUIDE
 #define PB_GUIDE 2
 #endif
@@ -55,6 +58,9 @@ constexpr int kPvRefillIdleCurves = PB_REFILL_CURVES;  // the same for scenes wi
 #ifndef PB_W_TRI
 #define PB_W_TRI 2
 #endif
+#ifndef PB_CURVE_PAIRS
+#define PB_CURVE_PAIRS 0  // Q tree: 1 = both pieces of a two-piece curve leaf in one turn (measured: see profiles/README.md); 0: one piece per turn (rounds 3-5)
+#endif
 #ifndef PB_W_CURVE
 #define PB_W_CURVE 2  // (round 3, Q tree: 1 -> 216.6 ms per C4 frame, 2 -> 213.5; together with the refill at 24 idle lanes 210.2)
 #endif
@@ -83,6 +89,20 @@ template <typename Sink>
 struct SinkSplits<Sink, decltype((void)Sink::kSplit)> { static constexpr bool value = Sink::kSplit && !Sink::kWalk; };
 template <typename Sink>
 __device__ constexpr bool sink_splits() { return SinkSplits<Sink>::value; }
+// a sink with `static constexpr bool kSuspend = true` takes part in the suspension of long rays (kernels.h::PathState::susp_turns):
+//   uint32_t susp_turns();  uint32_t* susp_out();  const uint32_t* susp_in();  static constexpr bool kResumes (its queue can hold suspended rays)
+//   bool suspendable(uint32_t tag)                                   a closest-hit ray whose path can skip a shading round
+//   void suspended(uint32_t tag, uint32_t rec, V3 o, V3 d)           marks the path: its ray's state is record `rec` of susp_out
+//   uint32_t resume_index(uint32_t tag)                              the record of a ray whose load() returned a tag with kTagResume
+// Tag bits of such a sink: kTagShadow (its own), kTagNoSuspend, kTagResume; the low 28 bits are the path slot.
+template <typename Sink, typename = void>
+struct SinkSuspends { static constexpr bool value = false; };
+template <typename Sink>
+struct SinkSuspends<Sink, decltype((void)Sink::kSuspend)> { static constexpr bool value = Sink::kSuspend && !Sink::kWalk; };
+template <typename Sink>
+__device__ constexpr bool sink_suspends() { return SinkSuspends<Sink>::value; }
+constexpr uint32_t kTagShadow = 0x80000000u, kTagNoSuspend = 0x40000000u, kTagResume = 0x20000000u;
+constexpr uint32_t kSuspRecWords = 72;  // == kernels.h::kSuspWords: hit (4 words) | cur, state | rem << 8 | sp << 16, 0, 0 | the stack
 
 // WIDE: the Q tree (sc.wide: QNode, dscene.h: four children per 64-byte node with quantised boxes, compact triangle slots,
 // curve pieces as chains of 16-byte points) instead of the binary one -- half the dependent fetches per ray and half the bytes
@@ -160,6 +180,10 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
 
   unsigned long long t_turn = STATS ? __builtin_readcyclecounter() : 0ull;  // STATS: the turn's cycles go to what it did
   int did = -1;
+  uint32_t drain_turns = 0u;  // loop turns since this wave found the queue empty (wave-uniform)
+  // index of this wave in the grid (wave-uniform: a scalar register; the suspend record of lane l is 64 x wave_id + l)
+  uint32_t wave_id = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+  asm volatile("" : "+s"(wave_id));  // (computed HERE: left to itself the compiler sinks it behind the loop and keeps threadIdx.x alive -- in scratch -- for it)
   for (;;) {
     if (STATS) {
       const unsigned long long t_now = __builtin_readcyclecounter();
@@ -185,7 +209,7 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)base, 0));
         batch_cur = base < n ? base : n;
         batch_end = (base + batch) < n ? (base + batch) : n;
-        if (batch_cur >= n) exhausted = true;
+        if (batch_cur >= n) exhausted = true, st.t_exhausted = wall_clock64();
         // guided self-scheduling: the batches shrink as the queue empties (down to one wave-full), so that the waves run
         // dry at about the same time.  With fixed 512-ray batches the last batch of the unlucky waves was ~0.35 ms of a
         // 16 M-ray launch during which the rest of the chip idled (one wave traces a ray in ~0.8 us).
@@ -264,9 +288,29 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
 #pragma unroll
           for (int k = 0; k < 10; k++) frame[(uint32_t)k * stride] = w[k];
         }
-        hit.u = 0.f, hit.v = 0.f, hit.slot = kNone;
-        sp = 0, steps = 0;
-        advance = true, have_next = true, next = 0u;  // root is always an internal node
+        bool resumed = false;
+        if constexpr (sink_suspends<Sink>()) resumed = Sink::kResumes && (tag & kTagResume) != 0u;
+        if (resumed) {
+          // a ray suspended by the previous launch: it goes on where it stopped (its item is fetched again at the load site below)
+          if constexpr (sink_suspends<Sink>()) {
+            tag &= ~kTagResume;
+            const uint32_t* rec = sink.susp_in() + (size_t)sink.resume_index(tag) * kSuspRecWords;
+            hit.t = __uint_as_float(rec[0]), hit.u = __uint_as_float(rec[1]), hit.v = __uint_as_float(rec[2]), hit.slot = rec[3];
+            cur = rec[4];
+            const uint32_t meta = rec[5];
+            state = meta & 255u, rem = (meta >> 8) & 255u, sp = (int)(meta >> 16);
+            for (int i = 0; i < sp; i++) {
+              const uint32_t v = rec[8 + i];
+              if (i < kLds) stk_base[(uint32_t)i * stride] = v;
+              else spill[(uint32_t)(i - kLds) * spill_stride] = v;
+            }
+            steps = 0, need_load = true;
+          }
+        } else {
+          hit.u = 0.f, hit.v = 0.f, hit.slot = kNone;
+          sp = 0, steps = 0;
+          advance = true, have_next = true, next = 0u;  // root is always an internal node
+        }
       }
       batch_cur += taken;
       if (STATS) {
@@ -276,6 +320,15 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
       }
     } else {
       if (n_idle == 64) break;  // queue exhausted and every lane done
+      if constexpr (sink_suspends<Sink>()) {
+        // The drain: the queue is empty, this wave's last rays are finishing one by one and the chip runs nearly empty while they
+        // do.  After susp_turns more turns the wave stops as soon as every ray it still traces can be suspended (closest-hit rays:
+        // below); the launch that follows takes them up again in its bulk phase.
+        if (exhausted && sink.susp_turns() != 0u) {
+          if (drain_turns < sink.susp_turns()) drain_turns++;
+          else if (__ballot(state >= kStNode && state <= kStCurve && !sink.suspendable(tag)) == 0ull) break;
+        }
+      }
       unsigned long long node_mask = __ballot(state == kStNode);
       unsigned long long tri_mask = __ballot(state == kStTri);
       int n_node = __popcll(node_mask), n_tri = __popcll(tri_mask);
@@ -404,6 +457,51 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
           } else {
             advance = true;  // leaf done: pop
           }
+        } else if (PB_CURVE_PAIRS && WIDE && CURVES && mine && is_curve) {
+          // A curve leaf of the Q tree: one or two NEIGHBOURING pieces of a chain -- points cur, cur + 1 (, cur + 2) in D0, D1 (, D2) --
+          // in ONE turn (round 6): the ray frame is read once, the middle point projected once, and the second piece needs no turn
+          // of its own (a curve turn ran at 18 of 64 lanes).  Piece by piece the operations, their order and the accept rule are
+          // those of two one-piece turns: the same bits.
+          if (STATS) steps += 1u + rem, (any_ray ? st.acurves : st.curves) += 1u + rem;
+          // (the frame is read again for the third point instead of being held across the first piece's test: twenty LDS reads
+          // instead of ten, but no register more than a one-piece turn needs -- held, it spilt 28 bytes into the loop)
+          auto read_frame = [&]() {
+            RayFrame f;
+            f.dn = V3(frame[0], frame[stride], frame[2 * stride]), f.bx = V3(frame[3 * stride], frame[4 * stride], frame[5 * stride]);
+            f.by = V3(frame[6 * stride], frame[7 * stride], frame[8 * stride]), f.inv_len = frame[9 * stride];
+            return f;
+          };
+          const V3 i3(inv4.x, inv4.y, inv4.z);
+          const uint32_t pt = cur - sc.q_pt0;
+          bool occ = false;
+          V3 pb;
+          {
+            const RayFrame f = read_frame();
+            const V3 pa = segment_project(D0, o, f);
+            pb = segment_project(D1, o, f);
+            float t, u, v;
+            bool ok = segment_core(D0, D1, pa, pb, pt & 3u, o, f.inv_len, i3, tmin, hit.t, t, u, v);
+            const uint32_t code = kQPointHit | pt;
+            if (ok && !any_ray && t == hit.t && hit.slot != kNone) ok = q_gid(sc, code) < q_gid(sc, hit.slot);
+            if (ok) hit.t = t, hit.u = u, hit.v = v, hit.slot = code;
+            occ = any_ray && ok;
+          }
+          if (rem != 0u && !occ) {
+            const RayFrame f = read_frame();
+            const V3 pc = segment_project(D2, o, f);
+            float t, u, v;
+            bool ok = segment_core(D1, D2, pb, pc, (pt + 1u) & 3u, o, f.inv_len, i3, tmin, hit.t, t, u, v);
+            const uint32_t code = kQPointHit | (pt + 1u);
+            if (ok && !any_ray && t == hit.t && hit.slot != kNone) ok = q_gid(sc, code) < q_gid(sc, hit.slot);
+            if (ok) hit.t = t, hit.u = u, hit.v = v, hit.slot = code;
+            occ = any_ray && ok;
+          }
+          if (occ) {
+            state = kStDoneOccluded;
+            if (STATS) st.ahist[steps <= 16u ? 0 : (28 - __clz(steps - 1u) > 7 ? 7 : 28 - __clz(steps - 1u))]++, st.amax_steps = steps > st.amax_steps ? steps : st.amax_steps;
+          } else {
+            advance = true;  // leaf done: pop
+          }
         } else if (mine) {
           if (STATS) steps++;
           float t, u, v;
@@ -480,7 +578,7 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
       } else {
         const float4* g = items + cur;
         D0 = g[0], D1 = g[1];
-        if (!CURVES || state != kStCurve) D2 = g[2];
+        if (!CURVES || state != kStCurve || PB_CURVE_PAIRS) D2 = g[2];  // (a curve leaf: its third point -- the chains are padded, so the read is in bounds)
         if (!CURVES || state == kStNode) D3w = g[3];
         if (!CURVES && state == kStTri) D4 = g[4];
       }
@@ -500,6 +598,21 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
     if (state >= kStDone) {  // rays that finished after the queue ran dry
       if (WIDE && CURVES) hit.slot = q_final_code(sc, hit.slot);
       sink.done(tag, hit, state == kStDoneOccluded);
+    }
+  }
+  if constexpr (sink_suspends<Sink>()) {
+    // SUSPEND what is still being traced (the wave left its loop at the end of the drain): the stack, the current item and the hit
+    // held so far go to the lane's record (one per resident thread: no counter), the path is marked (sink.suspended: its hit code
+    // becomes kHitSuspended) and the ray goes on -- from this very point, so its hit is what it would have been -- in the next
+    // iteration's launch.  The prefetched item is not kept (the resuming lane fetches it again), so this costs the loop no register.
+    if (state >= kStNode && state <= kStCurve) {
+      const uint32_t j = wave_id * 64u + __lane_id();
+      uint32_t* rec = sink.susp_out() + (size_t)j * kSuspRecWords;
+      rec[0] = __float_as_uint(hit.t), rec[1] = __float_as_uint(hit.u), rec[2] = __float_as_uint(hit.v), rec[3] = hit.slot;
+      rec[4] = cur, rec[5] = state | (rem << 8) | ((uint32_t)sp << 16);
+      for (int i = 0; i < sp; i++) rec[8 + i] = i < kLds ? stk_base[(uint32_t)i * stride] : spill[(uint32_t)(i - kLds) * spill_stride];
+      sink.suspended(tag, j, o, d);
+      if (STATS) st.suspended++;
     }
   }
 }

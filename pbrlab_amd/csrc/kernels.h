@@ -64,14 +64,37 @@ struct PathState {
   uint32_t pass_run;
   uint64_t seed_seq;
   uint32_t no_medium;  // no material of the scene can enter a medium: every shadow ray is an ordinary one (kShNormal), so an occluded one has nothing to deliver
+  // Resumable rays (round 6; dtrace_pv.h).  Every k_trace launch used to end with a drain of ~0.35 ms in which the chip ran nearly
+  // empty while a few long rays finished.  Now a wave that has found the queue empty keeps going for susp_turns more loop turns and
+  // then SUSPENDS the closest-hit rays it still holds: the traversal state (stack, current item, the hit held so far: one
+  // kSuspWords-word record, susp_out) is stored, the path's hit record becomes (record index, -, -, kHitSuspended), the path goes
+  // to no shading queue in this iteration (k_classify / the direct first shading re-queue it with kQResume) and the ray RESUMES at
+  // the head of the next iteration's k_trace (susp_in = this launch's susp_out), inside that launch's bulk phase.  A suspended ray
+  // loses nothing and its hit does not change (the traversal continues where it stopped), so images are bit-identical; the path
+  // just skips one shading round.  Shadow rays and the bounded rays of paths inside a medium are never suspended (a shadow ray's
+  // payload sits at the path's slot, which the path's next shading overwrites).  susp_turns = 0: never (the launch before k_tail,
+  // the hooks).
+  uint32_t susp_turns;             // drain turns before suspension (0: never)
+  uint32_t* susp_out;              // this launch's records: one per resident thread of the launch (kSuspRecords)
+  const uint32_t* susp_in;         // the previous launch's
+  uint32_t shadow_first;           // k_trace takes the shadow rays of the previous bounce before this bounce's closest-hit rays
 };
+constexpr uint32_t kSuspWords = 72;  // hit (4) | cur, state | rem << 8 | sp << 16, -, - (4) | stack (kStackDepth = 64)
+static_assert(kStackDepth <= 64, "a suspend record holds the whole traversal stack");
 
 enum : uint32_t { kFlagNotFirst = 1u };
 constexpr uint32_t kFirstDirect = 3u;
 // queue entry = path slot | in-medium bit | "the Russian roulette at the head of this path's next shading fails" bit
 constexpr uint32_t kQSssBit = 0x80000000u, kQDoomed = 0x40000000u, kQPathMask = 0x0FFFFFFFu;
+// ... | "the path's pending shading is its FIRST bounce" (a camera ray that was suspended: its shading runs in a later iteration, next
+// to other paths' later bounces) | "the path's ray is a suspended one: resume it" (trace queue only)
+constexpr uint32_t kQFirst = 1u << 29, kQResume = 1u << 28;
+constexpr uint32_t kHitSuspended = 0xFFFFFFFEu;  // hit code of a path whose closest-hit ray was suspended (kNone = 0xFFFFFFFF: a miss)
 // shade-kernel result word (written over the kernel's own queue entry): path slot (28 bits) | flags
 constexpr uint32_t kRPathMask = 0x0FFFFFFFu, kRShadow = 1u << 28, kRAlive = 1u << 29;
+// ... or, for a path whose closest-hit ray was suspended: kRResume WITHOUT kRAlive (no shading produces that: a path inside a medium
+// is alive) | kQDoomed of its queue entry | kRResumeFirst = its kQFirst; k_compact re-queues it with kQResume
+constexpr uint32_t kRResume = kQSssBit, kRResumeFirst = kRShadow;
 constexpr uint64_t kMaxPathsInFlight = (1ull << 28) - 1;
 enum : uint32_t { kShNormal = 0u, kShSssEntry = 1u, kShSssExit = 2u };
 enum : uint32_t {
@@ -86,15 +109,17 @@ enum : uint32_t {
   kStatStepHist0, kStatStepHistLast = kStatStepHist0 + 7, kStatMaxSteps, kStatMaxWaveIters,
   kStatWalkNodes, kStatWalkTris, kStatWalkTurns, kStatWalkSteps,
   kStatAnyHist0, kStatAnyHistLast = kStatAnyHist0 + 7, kStatAnyMaxSteps,
+  kStatSuspended,  // rays suspended (each is counted once more as a closest-hit ray of the launch that resumes it: subtracted there)
   kStatCycNode, kStatCycTri, kStatCycCurve, kStatCycRefill, kStatWalkCycTrav, kStatWalkCycStep,  // shader-clock cycles of the phase-voting waves' loop turns by what the turn did (lane 0 of every wave)
   kStatNum
 };
 
 // Resident 256-thread blocks per CU of the persistent traversal kernel = waves per SIMD (VGPR budget 512 / waves).
-// Triangle-only scenes: 7 (<= 72 VGPRs; A/B on C2: 6 -> 48.4 ms, 7 -> 45.2, 8 spills -> 62.3).  Scenes with curves need
-// more registers: 6 (7 spills: C4 254 -> 434 ms).
+// Binary tree (trees built on the GPU, PBRHIP_WIDE=0), triangle-only scenes: 7 in rounds 1-5 (<= 72 VGPRs; A/B on C2 in round 1: 6 -> 48.4 ms,
+// 7 -> 45.2, 8 spills -> 62.3); 6 since round 6 -- with the resume path of the suspended rays in the refill the kernel no longer fits
+// 72 registers without scratch in its triangle phase.  Scenes with curves need more registers: 6 (7 spills: C4 254 -> 434 ms).
 #ifndef PB_TRACE_BLOCKS
-#define PB_TRACE_BLOCKS 7
+#define PB_TRACE_BLOCKS 6
 #endif
 #ifndef PB_TRACE_BLOCKS_CURVES
 #define PB_TRACE_BLOCKS_CURVES 6
@@ -115,9 +140,11 @@ constexpr uint32_t kTraceGridCap = 256 * (kTraceBlocksPerCU > kTraceBlocksPerCUC
 // grid x the entries of its stack that do not live in LDS (the one-ray-per-lane kernels -- k_tail, the simple hooks -- run
 // smaller grids: (kStackDepth - kSimpleLdsStack) x 4096 x 256 and x PB_TAIL_BLOCKS x 256)
 constexpr size_t kSpillWords = (size_t)kStackDepth * kTraceGridCap * 256;
+constexpr size_t kSuspRecords = (size_t)kTraceGridCap * 256;  // suspend records of one k_trace launch: one per resident thread
 static_assert((size_t)(kStackDepth - kSimpleLdsStack) * 4096 * 256 <= kSpillWords, "spill area of the one-ray-per-lane hook grids (grid_for(n, 4096))");
 constexpr uint32_t kShadeGridCap = 256 * 8;
 constexpr int kMaxGroups = 8;
+constexpr uint32_t kRingSlots = 16;  // iterations of one group the host may have enqueued and not yet heard of
 constexpr uint32_t kWaveLogWaves = 8192, kWaveLogLaunches = 64;  // PBRHIP_WAVE_LOG buffer: launches x waves x 4 words  // concurrent path groups (one HIP stream each)
 
 struct HookHit {  // == pbrhip_hit == TraceResult (raytracer.h:9-17)
@@ -138,7 +165,7 @@ void launch_sss_step(hipStream_t s, const PathState& P, const DScene& sc, uint32
 void launch_sss_walk(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc, bool stats);
 void launch_accumulate(hipStream_t s, const PathState& P, const uint32_t* pix_index, uint32_t npix, uint32_t npass,
                        float* rgba, uint32_t* count);
-void launch_advance(hipStream_t s, const PathState& P);
+void launch_advance(hipStream_t s, const PathState& P, uint32_t* ring_slot, uint32_t stamp);  // ring_slot: 4 words of device-visible host memory (or null)
 void launch_texture_fetch(hipStream_t s, const DScene& sc, uint32_t tex_id, const float* uv, uint32_t n, float* rgb);  // test hook: Texture::FetchFloat3
 void launch_leaf_eval(hipStream_t s, uint32_t op, const float* in, uint32_t n, uint32_t in_words, float* out, uint32_t out_words);  // test hook: the device's leaf functions
 // RenderLayer shard of a pixel list: shard = npix x rgba (16 B) followed by npix x count (4 B); 16-byte aligned

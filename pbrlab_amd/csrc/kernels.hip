@@ -72,22 +72,51 @@ template <bool SPLIT, bool FIRST = false>
 struct TraceSinkT {
   static constexpr bool kWalk = false;
   static constexpr bool kSplit = SPLIT;
+  static constexpr bool kSuspend = true;
   const PathState& P;
-  uint32_t n_closest;
+  uint32_t n_closest, n_shadow;
+  // resumable rays (dtrace_pv.h, kernels.h::PathState::susp_turns)
+  __device__ __forceinline__ uint32_t susp_turns() const { return P.susp_turns; }
+  static constexpr bool kResumes = !FIRST;  // (a group's first launch traces camera rays only)
+  __device__ __forceinline__ uint32_t* susp_out() const { return P.susp_out; }
+  __device__ __forceinline__ const uint32_t* susp_in() const { return P.susp_in; }
+  __device__ __forceinline__ bool suspendable(uint32_t tag) const { return (tag & (kTagShadow | kTagNoSuspend)) == 0u; }
+  __device__ __forceinline__ void suspended(uint32_t tag, uint32_t rec, V3 o, V3 d) const {
+    const uint32_t p = tag & kQPathMask;
+    P.hit[p] = make_float4(__uint_as_float(rec), 0.f, 0.f, __uint_as_float(kHitSuspended));
+    if (FIRST) {  // a camera ray was computed, not loaded: the launch that resumes it loads it like any other ray
+      P.ray_o[p] = mk4(o, 0.0f);
+      P.ray_d[p] = mk4(d, kInf);
+    }
+  }
+  __device__ __forceinline__ uint32_t resume_index(uint32_t tag) const { return __float_as_uint(P.hit[tag & kQPathMask].x); }
+  // a trace-queue entry's flags as tag bits: a path inside a medium is never suspended, a suspended ray resumes
+  static __device__ __forceinline__ uint32_t entry_tag(uint32_t entry) {
+    return (entry & kQPathMask) | ((entry & kQSssBit) ? kTagNoSuspend : 0u) | ((entry & kQResume) ? kTagResume : 0u);
+  }
+  // queue position -> (shadow ray?, index in its queue): the shadow rays of the previous bounce first (shadow_first) or last
+  __device__ __forceinline__ bool is_shadow(uint32_t idx, uint32_t& k) const {
+    if (P.shadow_first) {
+      k = idx < n_shadow ? idx : idx - n_shadow;
+      return idx < n_shadow;
+    }
+    k = idx < n_closest ? idx : idx - n_closest;
+    return idx >= n_closest;
+  }
   struct Pending {
     float4 c, L;  // a shadow ray's pending contribution (+ mode) and its path's radiance
   };
   __device__ __forceinline__ Pending done_issue(uint32_t tag, bool occluded) const {
     Pending q = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
-    if ((tag & 0x80000000u) && !(occluded && P.no_medium)) {
-      const uint32_t p = tag & 0x7FFFFFFFu;
+    if ((tag & kTagShadow) && !(occluded && P.no_medium)) {
+      const uint32_t p = tag & kQPathMask;
       q.c = P.sh_c[p], q.L = P.L[p];
     }
     return q;
   }
   __device__ __forceinline__ void done_finish(uint32_t tag, const Pending& q, const Hit& h, bool occluded) const {
-    const uint32_t p = tag & 0x7FFFFFFFu;
-    if (!(tag & 0x80000000u)) {
+    const uint32_t p = tag & kQPathMask;
+    if (!(tag & kTagShadow)) {
       P.hit[p] = make_float4(h.t, h.u, h.v, __uint_as_float(h.slot));
       return;
     }
@@ -109,23 +138,26 @@ struct TraceSinkT {
   }
   __device__ __forceinline__ uint32_t load_entry(uint32_t idx) const {
     if (FIRST) return 0u;
-    return idx < n_closest ? P.q_in[idx] : P.q_shadow_in[idx - n_closest];
+    uint32_t k;
+    return is_shadow(idx, k) ? P.q_shadow_in[k] : P.q_in[k];
   }
   __device__ __forceinline__ bool load_ray(uint32_t idx, uint32_t entry, uint32_t& tag, V3& o, V3& d, float& tmin, float& tmax) const {
     if (FIRST) {
       camera_ray(idx, tag, o, d, tmin, tmax);
       return false;
     }
-    if (idx < n_closest) {
-      tag = entry & kQPathMask;
-      const float4 o4 = P.ray_o[tag], d4 = P.ray_d[tag];
+    uint32_t k;
+    if (!is_shadow(idx, k)) {
+      tag = entry_tag(entry);
+      const uint32_t p = entry & kQPathMask;
+      const float4 o4 = P.ray_o[p], d4 = P.ray_d[p];
       o = ld3(o4), d = ld3(d4), tmin = o4.w, tmax = d4.w;
       return false;
     }
     tag = entry;
     float4 o4 = P.ray_o[tag], d4 = P.sh_d[tag];
     o = ld3(o4), d = ld3(d4), tmin = o4.w, tmax = d4.w;
-    tag |= 0x80000000u;
+    tag |= kTagShadow;
     return true;
   }
   __device__ __forceinline__ bool load(uint32_t idx, uint32_t& tag, V3& o, V3& d, float& tmin, float& tmax) const {
@@ -133,21 +165,24 @@ struct TraceSinkT {
       camera_ray(idx, tag, o, d, tmin, tmax);
       return false;
     }
-    if (idx < n_closest) {
-      tag = P.q_in[idx] & kQPathMask;
-      const float4 o4 = P.ray_o[tag], d4 = P.ray_d[tag];
+    uint32_t k;
+    if (!is_shadow(idx, k)) {
+      const uint32_t entry = P.q_in[k];
+      tag = entry_tag(entry);
+      const uint32_t p = entry & kQPathMask;
+      const float4 o4 = P.ray_o[p], d4 = P.ray_d[p];
       o = ld3(o4), d = ld3(d4), tmin = o4.w, tmax = d4.w;
       return false;
     }
-    tag = P.q_shadow_in[idx - n_closest];
+    tag = P.q_shadow_in[k];
     float4 o4 = P.ray_o[tag], d4 = P.sh_d[tag];
     o = ld3(o4), d = ld3(d4), tmin = o4.w, tmax = d4.w;
-    tag |= 0x80000000u;
+    tag |= kTagShadow;
     return true;
   }
   __device__ __forceinline__ void done(uint32_t tag, const Hit& h, bool occluded) const {
-    const uint32_t p = tag & 0x7FFFFFFFu;
-    if (!(tag & 0x80000000u)) {
+    const uint32_t p = tag & kQPathMask;
+    if (!(tag & kTagShadow)) {
       P.hit[p] = make_float4(h.t, h.u, h.v, __uint_as_float(h.slot));
       return;
     }
@@ -190,6 +225,10 @@ __device__ __forceinline__ void trace_stats_out(const PathState& P, const TravSt
     if (__lane_id() == 0)
       for (int i = 0; i < 4; i++)
         if (st.cyc[i]) atomicAdd(&P.stats[kStatCycNode + i], st.cyc[i]);
+    {
+      const uint32_t su = wave_sum(st.suspended);
+      if (__lane_id() == 0 && su) atomicAdd(&P.stats[kStatSuspended], (unsigned long long)su);
+    }
     if (__lane_id() == 0) atomicMax(&P.stats[kStatMaxWaveIters], (unsigned long long)(st.it_node + st.it_tri + st.it_curve + st.it_refill));
     if (threadIdx.x == 0 && blockIdx.x == 0) {
       atomicAdd(&P.stats[kStatClosestRays], (unsigned long long)n_closest);
@@ -218,17 +257,19 @@ __global__ __launch_bounds__(kBlock, trace_blocks_per_cu(CURVES, WIDE) - (FIRST 
   const uint32_t n_closest = P.counts[kCntIn], n_shadow = P.counts[kCntShadowIn];
   TravStats st = {};
   uint32_t overflow = 0u;
-  TraceSinkT<CURVES, FIRST> sink = {P, n_closest};
+  TraceSinkT<CURVES, FIRST> sink = {P, n_closest, n_shadow};
   const unsigned long long t_start = P.wave_log ? wall_clock64() : 0ull;
+  uint32_t wave_idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * kBlock + threadIdx.x) >> 6));
+  asm volatile("" : "+s"(wave_idx));  // (a scalar, computed before the loop: threadIdx.x does not stay alive across it)
   trace_pv<FIRST ? 0 : 2, STATS, CURVES, WIDE>(sc, n_closest + (FIRST ? 0u : n_shadow), &P.counts[kCntHead], sink, stk + threadIdx.x, kBlock,
                              P.spill + blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, st, &overflow,
                              CURVES ? frm + threadIdx.x : nullptr, top, ntop);
   if (overflow) P.counts[kCntOverflow] = 1u;
   if (P.wave_log && __lane_id() == 0 && P.wave_log_launch < kWaveLogLaunches) {
-    const uint32_t w = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const uint32_t w = wave_idx;
     if (w < kWaveLogWaves) {
       unsigned long long* o = P.wave_log + ((size_t)P.wave_log_launch * kWaveLogWaves + w) * 4;
-      o[0] = t_start, o[1] = wall_clock64(), o[2] = st.it_refill | ((unsigned long long)st.refill_ticks << 32), o[3] = st.it_node + st.it_tri + st.it_curve;
+      o[0] = t_start, o[1] = wall_clock64(), o[2] = STATS ? (st.it_refill | ((unsigned long long)st.refill_ticks << 32)) : st.t_exhausted, o[3] = st.it_node + st.it_tri + st.it_curve;
     }
   }
   if (STATS) trace_stats_out(P, st, n_closest, n_shadow);
@@ -245,12 +286,13 @@ __global__ __launch_bounds__(kBlock) void k_trace_quad(PathState P, DScene sc) {
   constexpr uint32_t quads = kBlock / 4;
   const uint32_t quad = threadIdx.x >> 2;
   uint32_t overflow = 0u;
-  TraceSinkT<false> sink = {P, n_closest};
+  TraceSinkT<false> sink = {P, n_closest, n_shadow};
   for (uint32_t i = blockIdx.x * quads + quad; i < n; i += gridDim.x * quads) {
     uint32_t tag;
     V3 o, d;
     float tmin, tmax;
     const bool any = sink.load(i, tag, o, d, tmin, tmax);
+    tag &= ~kTagResume;  // (a ray another launch suspended is traced from its start here: the same hit)
     Hit h;
     const bool occluded = traverse_quad<2>(sc, o, d, tmin, tmax, h, stk + quad, quads, &overflow, any, P.spill + blockIdx.x * quads + quad, gridDim.x * quads);
     if ((threadIdx.x & 3u) == 0u) sink.done(tag, h, occluded);
@@ -368,15 +410,15 @@ __global__ __launch_bounds__(kBlock) void k_classify(PathState P, DScene sc) {
   uint32_t* const counters[4] = {&P.counts[kCntSss], &tile_principled[0], &P.counts[kCntHair], &tile_principled[1]};
   uint32_t* const queues[4] = {P.q_sss, P.q_principled, P.q_hair, P.q_principled};
   for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    uint32_t p[kItemsPerThread], dest[kItemsPerThread];
+    uint32_t p[kItemsPerThread], dest[kItemsPerThread];  // p: path slot | kQFirst (handed on to the shading queues)
     bool doomed[kItemsPerThread];
 #pragma unroll
     for (int j = 0; j < kItemsPerThread; j++) {
       uint32_t i = tile * kTileItems + j * kBlock + threadIdx.x;
       dest[j] = 0, p[j] = 0, doomed[j] = false;
       if (i < n) {
-        const uint32_t e = P.first ? P.slot0 + i : P.q_in[i];  // (a group's first bounce: entry i is path slot0 + i)
-        p[j] = e & kQPathMask;
+        const uint32_t e = P.first ? ((P.slot0 + i) | kQFirst) : P.q_in[i];  // (a group's first bounce: entry i is path slot0 + i)
+        p[j] = e & (kQPathMask | kQFirst);
         dest[j] = (e & kQSssBit) ? 1u : 0xFFu;
         doomed[j] = (e & kQDoomed) != 0u;
       }
@@ -384,9 +426,12 @@ __global__ __launch_bounds__(kBlock) void k_classify(PathState P, DScene sc) {
 #pragma unroll
     for (int j = 0; j < kItemsPerThread; j++)
       if (dest[j] == 0xFFu) {
-        const uint32_t code = __float_as_uint(P.hit[p[j]].w);
+        const uint32_t code = __float_as_uint(P.hit[p[j] & kQPathMask].w);
         dest[j] = (code & kHitHair) ? 3u : ((code & kHitMore) ? 2u : 4u);
         if (code == kNone || (!(code & kHitLight) && (doomed[j] || (code & kHitNoMaterial)))) dest[j] = 0u;
+        // a path whose ray was suspended (its ray goes on in the next launch) rides through the principled queue untouched: the shading
+        // kernel turns its entry into a "resume" result word and k_compact re-queues it -- no atomic, no queue of its own
+        if (code == kHitSuspended) dest[j] = 4u, p[j] |= kQResume | (doomed[j] ? kQDoomed : 0u);
       }
     if (threadIdx.x < 2) tile_principled[threadIdx.x] = 0u;
     __syncthreads();
@@ -417,31 +462,34 @@ __global__ __launch_bounds__(kBlock) void k_compact(PathState P) {
   const uint32_t ntiles = (n + kTileItems - 1) / kTileItems;
   uint32_t* const counters[2] = {&P.counts[kCntOut], &P.counts[kCntShadow]};
   for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    uint32_t e[kItemsPerThread], d_out[kItemsPerThread], d_sh[kItemsPerThread];
+    uint32_t e[kItemsPerThread];
 #pragma unroll
     for (int j = 0; j < kItemsPerThread; j++) {
       uint32_t i = tile * kTileItems + j * kBlock + threadIdx.x;
       e[j] = 0;
       if (i < n) e[j] = (i < n0) ? P.q_principled[i] : ((i < n0 + n1) ? P.q_hair[i - n0] : P.q_sss[i - n0 - n1]);
-      d_out[j] = (e[j] & kRAlive) ? 1u : 0u;
-      d_sh[j] = (e[j] & kRShadow) ? 2u : 0u;
     }
+    // a "resume" word (kRResume without kRAlive: the path's ray was suspended, kernels.h) goes back to the trace queue with kQResume
+    // (everything below is a function of e[j]: nothing else is kept per item)
+    auto resumes = [](uint32_t w) { return (w & (kRAlive | kRResume)) == kRResume; };
     // two independent streams share one pass: run the compactor once per stream
     TileCompactor<2, kItemsPerThread> ta = {wcount, base, {}};
     {
       uint32_t dest[kItemsPerThread];
 #pragma unroll
-      for (int j = 0; j < kItemsPerThread; j++) dest[j] = d_out[j];
+      for (int j = 0; j < kItemsPerThread; j++) dest[j] = ((e[j] & kRAlive) || resumes(e[j])) ? 1u : 0u;
       ta.run(dest, counters);
 #pragma unroll
       for (int j = 0; j < kItemsPerThread; j++)
-        if (dest[j]) P.q_out[ta.slot(j, 1u)] = e[j] & (kRPathMask | kQSssBit | kQDoomed);
+        if (dest[j])
+          P.q_out[ta.slot(j, 1u)] = resumes(e[j]) ? ((e[j] & (kRPathMask | kQDoomed)) | kQResume | ((e[j] & kRResumeFirst) ? kQFirst : 0u))
+                                                  : (e[j] & (kRPathMask | kQSssBit | kQDoomed));
       __syncthreads();
     }
     {
       uint32_t dest[kItemsPerThread];
 #pragma unroll
-      for (int j = 0; j < kItemsPerThread; j++) dest[j] = d_sh[j];
+      for (int j = 0; j < kItemsPerThread; j++) dest[j] = ((e[j] & kRShadow) && !resumes(e[j])) ? 2u : 0u;
       ta.run(dest, counters);
 #pragma unroll
       for (int j = 0; j < kItemsPerThread; j++)
@@ -770,14 +818,20 @@ __global__ __launch_bounds__(kBlock, MODE == kShadePlain ? PB_SHADE_WAVES : (MOD
   const bool direct = P.first == kFirstDirect;
   const uint32_t n = P.counts[direct ? kCntIn : kCntPrincipled];
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-    const uint32_t p = direct ? P.slot0 + i : P.q_principled[i];
+    const uint32_t e = direct ? P.slot0 + i : P.q_principled[i];
+    const uint32_t p = e & kQPathMask;
     uint32_t r = 0u;
     bool go = true;
+    // a path whose closest-hit ray k_trace suspended is not shaded now: its result word says "resume" (kernels.h: kRResume; the
+    // path's kQDoomed / kQFirst ride along) and k_compact puts it back into the trace queue
     if (direct) {
       const uint32_t code = __float_as_uint(P.hit[p].w);
       go = !(code == kNone || (!(code & kHitLight) && (code & kHitNoMaterial)));
+      if (code == kHitSuspended) go = false, r = kRResume | kRResumeFirst;
+    } else if (e & kQResume) {
+      go = false, r = kRResume | (e & kQDoomed) | ((e & kQFirst) ? kRResumeFirst : 0u);
     }
-    if (go) r = shade_principled_path<MODE>(P, sc, p, rng_inc, P.first != 0u, staged ? lds_bsdf : nullptr, lights_staged ? lds_lights : nullptr);
+    if (go) r = shade_principled_path<MODE>(P, sc, p, rng_inc, P.first != 0u || (e & kQFirst) != 0u, staged ? lds_bsdf : nullptr, lights_staged ? lds_lights : nullptr);
     P.q_principled[i] = p | r;
   }
 }
@@ -856,8 +910,8 @@ __global__ __launch_bounds__(kBlock) void k_shade_hair(PathState P, DScene sc, u
   if (lights_staged) __syncthreads();
   const uint32_t n = P.counts[kCntHair];
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-    const uint32_t p = P.q_hair[i];
-    P.q_hair[i] = p | shade_hair_path(P, sc, p, rng_inc, P.first != 0u, lights_staged ? lds_lights : nullptr);
+    const uint32_t e = P.q_hair[i], p = e & kQPathMask;
+    P.q_hair[i] = p | shade_hair_path(P, sc, p, rng_inc, P.first != 0u || (e & kQFirst) != 0u, lights_staged ? lds_lights : nullptr);
   }
 }
 
@@ -1195,7 +1249,7 @@ __global__ __launch_bounds__(kBlock, PB_TAIL_WAVES) void k_tail(PathState P, DSc
   per_wave = per_wave < 1u ? 1u : (per_wave > 64u ? 64u : per_wave);
   TravStats st = {};
   uint32_t overflow = 0u, n_closest = 0u, n_shadow = 0u;  // rays traced here (STATS)
-  const TraceSink sink = {P, 0u};
+  const TraceSink sink = {P, 0u, 0u};
   uint32_t* const stack = stk + threadIdx.x;
   constexpr uint32_t kHave = 0x80000000u, kMedium = 0x40000000u, kFirst = 0x20000000u;  // lane state = path slot | flags
   constexpr bool kOctets = PB_TAIL_OCTETS != 0 && WIDE && !CURVES;
@@ -1203,7 +1257,7 @@ __global__ __launch_bounds__(kBlock, PB_TAIL_WAVES) void k_tail(PathState P, DSc
     uint32_t state = 0u;
     if (lane < per_wave && base + lane < n) {
       const uint32_t e = P.first ? P.slot0 + base + lane : P.q_in[base + lane];
-      state = (e & kQPathMask) | kHave | ((e & kQSssBit) ? kMedium : 0u) | (P.first ? kFirst : 0u);  // the tail starts at the very first bounce of tiny renders
+      state = (e & kQPathMask) | kHave | ((e & kQSssBit) ? kMedium : 0u) | ((P.first || (e & kQFirst)) ? kFirst : 0u);  // the tail starts at the very first bounce of tiny renders (kQFirst: a camera ray that was suspended on its way)
     }
     uint32_t team = 1u;  // lanes per path: 1, 2 (pairs) or 8 (octets)
     for (;;) {
@@ -1577,10 +1631,16 @@ __global__ __launch_bounds__(kBlock) void k_hook_quad(DScene sc, const float4* _
 }
 
 // queue flip between iterations: counts[In] = counts[Out]; the per-iteration counters restart at 0
-__global__ void k_advance(uint32_t* counts) {
+// ... and the host is told (ring: four words of pinned host memory, the stamp last): it sizes the launches after the next from these
+__global__ void k_advance(uint32_t* counts, uint32_t* ring, uint32_t stamp) {
   if (threadIdx.x == 0) {
     counts[kCntIn] = counts[kCntOut];
     counts[kCntShadowIn] = counts[kCntShadow];
+    if (ring) {
+      ring[0] = counts[kCntOut], ring[1] = counts[kCntShadow], ring[2] = counts[kCntOverflow];
+      __threadfence_system();
+      __hip_atomic_store(&ring[3], stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     counts[kCntOut] = 0, counts[kCntPrincipled] = 0, counts[kCntHair] = 0, counts[kCntSss] = 0, counts[kCntShadow] = 0;
     counts[kCntHead] = 0, counts[kCntWalkHead] = 0;
   }
@@ -1751,7 +1811,7 @@ void launch_layer_unpack_add(hipStream_t s, const uint32_t* pix, uint32_t npix, 
                      reinterpret_cast<const float4*>(shard), reinterpret_cast<const uint32_t*>(shard + 4 * (size_t)npix),
                      reinterpret_cast<float4*>(rgba), count);
 }
-void launch_advance(hipStream_t s, const PathState& P) { hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, s, P.counts); }
+void launch_advance(hipStream_t s, const PathState& P, uint32_t* ring_slot, uint32_t stamp) { hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, s, P.counts, ring_slot, stamp); }
 // counts: kCntNum zeroed words (queue head + overflow flag); spill: traversal-stack spill area
 void launch_hook_closest(hipStream_t s, const DScene& sc, const float4* rays, uint32_t n, HookHit* out, uint32_t* counts,
                          uint32_t* spill, bool simple) {

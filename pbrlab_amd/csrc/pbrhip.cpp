@@ -78,6 +78,9 @@ extern "C" int pbrhip_scene_create(pbrhip_scene** out) {
   s->device = g_device;
   HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   HIPCHK(hipHostMalloc((void**)&s->h_counts, sizeof(uint32_t) * kCntNum * kMaxGroups, hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&s->h_ring, sizeof(uint32_t) * 4 * kRingSlots * kMaxGroups, hipHostMallocDefault));
+  memset(s->h_ring, 0, sizeof(uint32_t) * 4 * kRingSlots * kMaxGroups);
+  HIPCHK(hipHostGetDevicePointer((void**)&s->d_ring, s->h_ring, 0));
   memset(&s->dscene, 0, sizeof(s->dscene));
   *out = s.release();
   return PBRHIP_OK;
@@ -92,6 +95,7 @@ extern "C" int pbrhip_scene_destroy(pbrhip_scene* s) {
   for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
   for (hipStream_t g : s->group_streams) (void)hipStreamDestroy(g);
   if (s->h_counts) (void)hipHostFree(s->h_counts);
+  if (s->h_ring) (void)hipHostFree(s->h_ring);
   hipStream_t st = s->stream;
   delete s;
   if (st) (void)hipStreamDestroy(st);
@@ -725,6 +729,7 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
       pair_words(first, count, &qtri[(size_t)rec * kTriPairWords]);
       return rec;
     };
+    size_t leaves_one = 0, leaves_pair = 0, leaves_split = 0;  // curve leaves of one piece / of two neighbouring pieces / binary leaves cut in two (PBRHIP_DEBUG)
     auto map_leaf = [&](uint32_t ref, const float* blo, const float* bhi, QChild* o) -> int {
       const uint32_t first = (ref & 0x3FFFFFFFu) >> 3, count = (ref & 7u) + 1u;
       if (!(ref & kCurveBit)) {
@@ -741,15 +746,18 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
             o[i].ref = kLeafBit | kCurveBit | (piece_point[g] << 3);
             for (int a = 0; a < 3; a++) o[i].lo[a] = BvhNode::widen_lo(lo[3 * (size_t)g + a]), o[i].hi[a] = BvhNode::widen_hi(hi[3 * (size_t)g + a]);
           }
+          leaves_split++;
           return 2;
         }
         p0 = std::min(p0, p1);
       }
       o[0].ref = kLeafBit | kCurveBit | (p0 << 3) | (count - 1u);
       for (int a = 0; a < 3; a++) o[0].lo[a] = blo[a], o[0].hi[a] = bhi[a];
+      (count == 2 ? leaves_pair : leaves_one)++;
       return 1;
     };
     if (qpts.size() >= (1u << 27) || build_qtree(bvh.nodes, map_leaf, &wide) > (uint32_t)kStackDepth) wide.clear();
+    if (getenv("PBRHIP_DEBUG")) fprintf(stderr, "pbrhip: commit: curve leaves of the Q tree (counted over the collapse's visits): %zu of one piece, %zu of two neighbouring pieces, %zu binary leaves cut in two\n", leaves_one, leaves_pair, leaves_split);
   }
   if (wide.empty()) s->d_wide.release(), s->d_qhit.release();
   if (getenv("PBRHIP_DEBUG")) fprintf(stderr, "pbrhip: commit: %u binary nodes, %zu wide nodes, %zu slots, %zu triangle leaves + %zu points in the Q tree\n", num_nodes, wide.size(), (size_t)ns, qtri.size() / kTriPairWords, qpts.size());
@@ -930,6 +938,15 @@ struct Timer {
     double* acc;
   };
   std::vector<Rec> recs;
+  // first / last event of every enqueued iteration of the group: the gaps between them are the time the stream sat empty
+  std::vector<std::pair<size_t, size_t>> iters;
+  double* idle_acc = nullptr;
+  void iteration_begins() {
+    if (on) iters.push_back({used, used});
+  }
+  void iteration_ends() {
+    if (on && !iters.empty() && used >= 1) iters.back().second = used - 1;
+  }
   hipError_t begin(double* acc) {
     if (!on) return hipSuccess;
     while (events.size() < used + 2) {
@@ -962,6 +979,14 @@ struct Timer {
       *r.acc += (double)ms;
     }
     recs.clear();
+    for (size_t i = 1; i < iters.size() && idle_acc; i++) {
+      float ms = 0.f;
+      if (iters[i - 1].second >= iters[i].first || iters[i].first >= used) continue;
+      hipError_t rc = hipEventElapsedTime(&ms, events[iters[i - 1].second], events[iters[i].first]);
+      if (rc != hipSuccess) return rc;
+      *idle_acc += (double)ms;
+    }
+    iters.clear();
     used = 0;
     for (hipEvent_t e : events) s->events.push_back(e);  // back to the scene's pool
     events.clear();
@@ -969,6 +994,11 @@ struct Timer {
   }
 };
 }  // namespace
+
+static uint32_t env_u32(const char* name, uint32_t dflt) {
+  const char* e = getenv(name);
+  return e ? (uint32_t)strtoul(e, nullptr, 10) : dflt;
+}
 
 void pb::shard_pixels(uint32_t w, uint32_t h, uint32_t rank, uint32_t world, uint32_t block, std::vector<uint32_t>* out) {
   if (block == 0) block = 64;  // CreateTiles' tile (pbrhip_create_tiles enumerates the same blocks in the same order)
@@ -986,6 +1016,8 @@ int pb::ensure_pixels(pbrhip_scene* s, uint32_t w, uint32_t h, uint32_t rank, ui
   if (block == 0) block = 64;
   uint32_t pt = 8u;
   if (const char* e = getenv("PBRHIP_PIXEL_TILE")) pt = (uint32_t)strtoul(e, nullptr, 10);
+  const bool shuffle = env_u32("PBRHIP_PATCH_SHUFFLE", 1u) != 0u;
+  pt |= shuffle ? 0x80000000u : 0u;  // (part of the cache key below)
   if (s->pk_w == w && s->pk_h == h && s->pk_rank == rank && s->pk_world == world && s->pk_block == block && s->pk_tile == pt && s->pix_index.p) return PBRHIP_OK;
   std::vector<uint32_t> pix;
   shard_pixels(w, h, rank, world, block, &pix);
@@ -994,24 +1026,49 @@ int pb::ensure_pixels(pbrhip_scene* s, uint32_t w, uint32_t h, uint32_t rank, ui
   // rays are an 8 x 8 patch, not a 64 x 1 strip: they share more of the tree, and so do their later bounces.  A permutation of
   // the list: every value is a function of (pixel, pass) alone, images do not change.
   HIPCHK(s->pix_index.upload(pix, s->stream));  // (the shard's own order: what the exchange packs and unpacks by, multi.cpp)
+  const uint32_t pt_key = pt;
+  pt &= 0x7FFFFFFFu;
   if (pt > 1u && pt < block) {
     std::vector<uint32_t> ordered;
     ordered.reserve(pix.size());
+    std::vector<std::pair<uint32_t, uint32_t>> patches;  // (first entry, entries) of every patch in `ordered`
     uint32_t t = 0;
     for (uint32_t by = 0; by < h; by += block)
       for (uint32_t bx = 0; bx < w; bx += block, t++) {
         if (t % world != rank) continue;
         const uint32_t ey = std::min(by + block, h), ex = std::min(bx + block, w);
         for (uint32_t sy = by; sy < ey; sy += pt)
-          for (uint32_t sx = bx; sx < ex; sx += pt)
+          for (uint32_t sx = bx; sx < ex; sx += pt) {
+            const uint32_t at = (uint32_t)ordered.size();
             for (uint32_t y = sy; y < std::min(sy + pt, ey); y++)
               for (uint32_t x = sx; x < std::min(sx + pt, ex); x++) ordered.push_back(y * w + x);
+            patches.push_back({at, (uint32_t)ordered.size() - at});
+          }
       }
+    // Round 6: the patches in a SCATTERED order (patch i of the list = patch i x K mod M of the image order, K ~ 0.38 M, coprime to
+    // M).  k_trace's waves take rays from the queue in batches of up to 512 = eight patches, a wave takes only five or six batches
+    // per launch, and in image order a batch is ONE image region: the batches over dense geometry cost several times the batches over
+    // the walls, the waves that drew them found the queue empty up to 0.46 ms after the first wave had (per-wave timeline:
+    // profiles/README.md), and every launch ended with the chip half empty for that long.  Scattered, a batch is eight regions and
+    // consecutive batches are unrelated: the batches cost about the same.  A permutation: the image does not depend on it.
+    if (shuffle && patches.size() > 2) {
+      const uint64_t M = patches.size();
+      uint64_t K = (uint64_t)((double)M * 0.381966) | 1ull;
+      auto gcd = [](uint64_t a, uint64_t b) { while (b) { const uint64_t r = a % b; a = b, b = r; } return a; };
+      while (gcd(K, M) != 1) K += 2;
+      std::vector<uint32_t> scattered;
+      scattered.reserve(ordered.size());
+      for (uint64_t i = 0; i < M; i++) {
+        const auto& pch = patches[(size_t)((i * K) % M)];
+        scattered.insert(scattered.end(), ordered.begin() + pch.first, ordered.begin() + pch.first + pch.second);
+      }
+      ordered.swap(scattered);
+    }
     pix.swap(ordered);
   }
   HIPCHK(s->path_pix.upload(pix, s->stream));
   HIPCHK(hipStreamSynchronize(s->stream));
-  s->pk_w = w, s->pk_h = h, s->pk_rank = rank, s->pk_world = world, s->pk_block = block, s->pk_tile = pt, s->pk_npix = (uint32_t)pix.size();
+  s->pk_w = w, s->pk_h = h, s->pk_rank = rank, s->pk_world = world, s->pk_block = block, s->pk_tile = pt_key, s->pk_npix = (uint32_t)pix.size();
   return PBRHIP_OK;
 }
 
@@ -1048,10 +1105,6 @@ static uint32_t pass_run_for(uint32_t npass, bool curves) {
   uint32_t r = 1u;
   while (r * 2u <= want && npass % (r * 2u) == 0u) r *= 2u;
   return r;
-}
-static uint32_t env_u32(const char* name, uint32_t dflt) {
-  const char* e = getenv(name);
-  return e ? (uint32_t)strtoul(e, nullptr, 10) : dflt;
 }
 
 // How the passes of a chunk are split into path groups (each group = its own queues, counters and HIP stream; path
@@ -1160,6 +1213,7 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
     P.sh_d.base = s->srec.p, P.sh_c.base = s->srec.p + 1, P.sh_e = s->sh_e.p;
     P.counts = s->counts.p, P.stats = want_stats ? s->stats.p : nullptr, P.spill = s->spill.p;
     P.first = 0u, P.cam_org[0] = P.cam_org[1] = P.cam_org[2] = 0.f;
+    P.susp_turns = 0u, P.susp_out = nullptr, P.susp_in = nullptr, P.shadow_first = 0u;
     P.no_medium = s->has_sss ? 0u : 1u;
     P.wave_log = nullptr, P.wave_log_launch = 0;
     // debugging aid: PBRHIP_WAVE_LOG=<file> with PBRHIP_RENDER_STATS dumps start / end / turns of every wave of every
@@ -1191,12 +1245,27 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
     // chunk is the largest, so its plan has the most groups
     const uint32_t max_lanes = std::min<uint32_t>((uint32_t)kMaxGroups, (uint32_t)plan_groups(std::min(chunk_passes, d->num_sample), npix, want_groups).size());
     if (int rc = ensure_groups(s, std::max(1u, max_lanes))) return rc;
+    // Resumable rays and the pipelined host loop (round 6; kernels.h::PathState::susp_turns, scene_impl.h::h_ring).
+    // susp_turns: loop turns a k_trace wave keeps draining after the queue ran dry before it suspends its closest-hit rays (0: never);
+    // pipe_depth: iterations of a group enqueued ahead of what the host has heard of (1: the old round trip per iteration).  An
+    // iteration enqueued ahead sizes its launches by the last count the host saw (live paths only ever decrease: an upper bound).
+    const uint32_t susp_turns = env_u32("PBRHIP_SUSP_TURNS", 24u);
+    const uint32_t pipe_depth = std::min(std::max(1u, env_u32("PBRHIP_PIPE_DEPTH", 2u)), kRingSlots - 1u);
+    const uint32_t pipe_depth_small = std::min(std::max(1u, env_u32("PBRHIP_PIPE_DEPTH_SMALL", 8u)), kRingSlots - 1u);  // below 256 Ki live paths (renders without k_tail)
+    // close to the hand-over to k_tail (live paths <= pipe_stop x tail_paths) nothing is enqueued ahead: the hand-over is decided on
+    // exact counts (an iteration enqueued ahead would run as a full wavefront iteration on what k_tail finishes faster)
+    const double pipe_stop = getenv("PBRHIP_PIPE_STOP") ? atof(getenv("PBRHIP_PIPE_STOP")) : 2.0;
+    const uint32_t shadow_first = env_u32("PBRHIP_SHADOW_FIRST", 1u);
+    HIPCHK(s->susp.reserve((size_t)std::max(1u, max_lanes) * 2u * kSuspRecords * kSuspWords));  // (264 MB per group in flight)
     struct Group {
       PathState P;
       uint32_t n0, first_pass, npass, slot0;  // paths at the start, pass range, first path slot
       uint32_t n = 0, iters = 0;
       int lane = -1;  // stream / counter / spill slot while active
       bool started = false, finished = false;
+      uint32_t enq = 0, seen = 0;     // iterations enqueued / heard of (ring stamps)
+      uint32_t stamps[kRingSlots];    // stamp of enqueued iteration i at [i % kRingSlots]
+      bool tail_enqueued = false;
       Timer tm;
     };
 
@@ -1217,75 +1286,98 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
         gr.P.cam = cam, gr.P.pix_index = s->path_pix.p, gr.P.npix = npix, gr.P.width = d->width, gr.P.first_pass = gr.first_pass;
         gr.P.slot0 = gr.slot0, gr.P.seed_seq = d->seed_seq;
         gr.P.pass_run = pass_run_for(gr.npass, sc.num_curves != 0);
+        gr.P.shadow_first = shadow_first, gr.P.susp_turns = 0u;
         gr.tm = Timer{s, want_timing, nullptr};
+        gr.tm.idle_acc = &S.ms_host_idle;
       }
       bool lane_busy[kMaxGroups] = {};
       auto lane_stream = [&](int lane) { return lane == 0 ? st : s->group_streams[lane - 1]; };
-      auto lane_hcounts = [&](int lane) { return s->h_counts + lane * kCntNum; };
-      auto enqueue = [&](Group& gr) -> int {
+      auto ring_slot = [&](int lane, uint32_t i) { return (size_t)(lane * kRingSlots + i % kRingSlots) * 4u; };
+      // every enqueued iteration ends with k_advance, which tells the host (ring) what is left
+      auto advance = [&](Group& gr, hipStream_t gst) {
+        const uint32_t stamp = ++s->ring_stamp ? s->ring_stamp : ++s->ring_stamp;  // (never 0: the rings start zeroed)
+        gr.stamps[gr.enq % kRingSlots] = stamp;
+        launch_advance(gst, gr.P, s->d_ring + ring_slot(gr.lane, gr.enq), stamp);
+        gr.enq++;
+      };
+      // one iteration of group gr, its launches sized for at most n_upper live paths (and as many pending shadow rays)
+      auto enqueue_iteration = [&](Group& gr, uint32_t n_upper, bool to_tail) -> int {
         hipStream_t gst = lane_stream(gr.lane);
-        // Long tails (few paths, many bounces) are latency-bound: below 256 Ki active paths several iterations
-        // are queued per host round trip (kernels read their counts on the device and fall through when empty).
-        const int burst = gr.n < (1u << 18) ? 8 : 1;
-        const uint32_t n = std::max(gr.n, 1u);
-        if (gr.n <= tail_paths) {
-          // few live paths: trace this bounce (and the pending shadow rays), then finish every path in one launch
-          gr.P.first = gr.iters++ == 0 ? 1u : 0u;
-          HIPCHK(gr.tm.begin(&S.ms_trace_closest));
-          gr.P.wave_log_launch = wave_log_launches++;
-          launch_trace(gst, gr.P, sc, 2 * n, want_stats);
-          HIPCHK(gr.tm.end());
+        const uint32_t n = std::max(n_upper, 1u);
+        gr.P.first = gr.iters++ == 0 ? 1u : 0u;
+        // the launch's suspend records: written by this k_trace, read by the next (alternating halves of the lane's area)
+        uint32_t* const susp_lane = s->susp.p + (size_t)gr.lane * 2u * kSuspRecords * kSuspWords;
+        gr.P.susp_out = susp_lane + (size_t)(gr.iters & 1u) * kSuspRecords * kSuspWords;
+        gr.P.susp_in = susp_lane + (size_t)((gr.iters & 1u) ^ 1u) * kSuspRecords * kSuspWords;
+        gr.P.susp_turns = to_tail ? 0u : susp_turns;  // (k_tail takes every path to its end: the rays in front of it all finish)
+        gr.tm.iteration_begins();
+        HIPCHK(gr.tm.begin(&S.ms_trace_closest));
+        gr.P.wave_log_launch = wave_log_launches++;
+        launch_trace(gst, gr.P, sc, 2 * n, want_stats);  // this bounce's closest rays + last bounce's shadow rays
+        HIPCHK(gr.tm.end());
+        S.n_trace_closest++, S.iterations++;
+        if (to_tail) {
+          // few live paths: after this bounce's trace (and the pending shadow rays) every path is finished in one launch
           HIPCHK(gr.tm.begin(&S.ms_tail));
           launch_tail(gst, gr.P, sc, n, rng_inc, want_stats, s->has_sss, s->has_textured);
           HIPCHK(gr.tm.end());
-          launch_advance(gst, gr.P);  // nothing was queued: both "in" counts become 0
-          S.n_trace_closest++, S.n_tail++, S.iterations++;
-          HIPCHK(hipMemcpyAsync(lane_hcounts(gr.lane), gr.P.counts, sizeof(uint32_t) * kCntNum, hipMemcpyDeviceToHost, gst));
+          S.n_tail++;
+          gr.tm.iteration_ends();
+          advance(gr, gst);  // nothing was queued: both "in" counts become 0
+          gr.tail_enqueued = true;
           return PBRHIP_OK;
         }
-        for (int it = 0; it < burst; it++) {
-          gr.P.first = gr.iters++ == 0 ? 1u : 0u;
-          HIPCHK(gr.tm.begin(&S.ms_trace_closest));
-          gr.P.wave_log_launch = wave_log_launches++;
-          launch_trace(gst, gr.P, sc, 2 * n, want_stats);  // this bounce's closest rays + last bounce's shadow rays
+        // a first bounce in a scene without hair needs no routing -- every hit takes the principled shader --: the shading kernel
+        // walks the group's paths itself (kFirstDirect)
+        // (media do not matter here: no path is inside one before its first shading)
+        const bool direct = gr.P.first && !s->has_hair && env_u32("PBRHIP_FIRST_DIRECT", 1u) != 0u;
+        if (direct) gr.P.first = kFirstDirect;
+        if (!direct) {
+          HIPCHK(gr.tm.begin(&S.ms_surface));
+          launch_classify(gst, gr.P, sc, n);
           HIPCHK(gr.tm.end());
-          // a first bounce in a scene without hair needs no routing -- every hit takes the principled shader --: the shading kernel
-          // walks the group's paths itself (kFirstDirect)
-          // (media do not matter here: no path is inside one before its first shading)
-          const bool direct = gr.P.first && !s->has_hair && env_u32("PBRHIP_FIRST_DIRECT", 1u) != 0u;
-          if (direct) gr.P.first = kFirstDirect;
-          if (!direct) {
-            HIPCHK(gr.tm.begin(&S.ms_surface));
-            launch_classify(gst, gr.P, sc, n);
-            HIPCHK(gr.tm.end());
-            S.n_surface++;
-          }
-          HIPCHK(gr.tm.begin(&S.ms_shade_principled));
-          launch_shade_principled(gst, gr.P, sc, n, rng_inc, s->has_sss, s->has_textured);
-          HIPCHK(gr.tm.end());
-          if (s->has_hair) {
-            HIPCHK(gr.tm.begin(&S.ms_shade_hair));
-            launch_shade_hair(gst, gr.P, sc, n, rng_inc);
-            HIPCHK(gr.tm.end());
-            S.n_shade_hair++;
-          }
-          if (s->has_sss) {
-            HIPCHK(gr.tm.begin(&S.ms_sss_step));
-            if (sss_walk) launch_sss_walk(gst, gr.P, sc, n, rng_inc, want_stats);  // every walk forward to its last event ...
-            launch_sss_step(gst, gr.P, sc, n, rng_inc);                            // ... which the step kernel handles
-            HIPCHK(gr.tm.end());
-            S.n_sss_step++;
-          }
-          HIPCHK(gr.tm.begin(&S.ms_compact));
-          launch_compact(gst, gr.P, n);
-          HIPCHK(gr.tm.end());
-          S.n_trace_closest++, S.n_shade_principled++;
-          launch_advance(gst, gr.P);
-          std::swap(gr.P.q_in, gr.P.q_out);
-          std::swap(gr.P.q_shadow, gr.P.q_shadow_in);
-          S.iterations++;
+          S.n_surface++;
         }
-        HIPCHK(hipMemcpyAsync(lane_hcounts(gr.lane), gr.P.counts, sizeof(uint32_t) * kCntNum, hipMemcpyDeviceToHost, gst));
+        HIPCHK(gr.tm.begin(&S.ms_shade_principled));
+        launch_shade_principled(gst, gr.P, sc, n, rng_inc, s->has_sss, s->has_textured);
+        HIPCHK(gr.tm.end());
+        if (s->has_hair) {
+          HIPCHK(gr.tm.begin(&S.ms_shade_hair));
+          launch_shade_hair(gst, gr.P, sc, n, rng_inc);
+          HIPCHK(gr.tm.end());
+          S.n_shade_hair++;
+        }
+        if (s->has_sss) {
+          HIPCHK(gr.tm.begin(&S.ms_sss_step));
+          if (sss_walk) launch_sss_walk(gst, gr.P, sc, n, rng_inc, want_stats);  // every walk forward to its last event ...
+          launch_sss_step(gst, gr.P, sc, n, rng_inc);                            // ... which the step kernel handles
+          HIPCHK(gr.tm.end());
+          S.n_sss_step++;
+        }
+        HIPCHK(gr.tm.begin(&S.ms_compact));
+        launch_compact(gst, gr.P, n);
+        HIPCHK(gr.tm.end());
+        S.n_shade_principled++;
+        gr.tm.iteration_ends();
+        advance(gr, gst);
+        std::swap(gr.P.q_in, gr.P.q_out);
+        std::swap(gr.P.q_shadow, gr.P.q_shadow_in);
+        return PBRHIP_OK;
+      };
+      // keeps group gr's stream fed: iterations are enqueued ahead of the counts the host has seen (gr.n = the last count heard:
+      // an upper bound for every later iteration)
+      auto feed = [&](Group& gr) -> int {
+        if (gr.tail_enqueued) return PBRHIP_OK;
+        const uint32_t depth = gr.n < (1u << 18) ? pipe_depth_small : pipe_depth;
+        while (gr.enq - gr.seen < depth) {
+          const bool exact = gr.enq == gr.seen;  // the host knows this iteration's input counts
+          if (gr.n <= tail_paths) {
+            if (int rc = enqueue_iteration(gr, gr.n, true)) return rc;
+            break;
+          }
+          if (!exact && tail_paths && (double)gr.n <= pipe_stop * (double)tail_paths) break;
+          if (int rc = enqueue_iteration(gr, gr.n, false)) return rc;
+        }
         return PBRHIP_OK;
       };
       auto start = [&](Group& gr, int lane) -> int {
@@ -1294,19 +1386,19 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
         gr.tm.stream = gst;
         gr.P.counts = s->counts.p + lane * kCntNum;
         gr.P.spill = s->spill.p + (size_t)lane * kSpillWords;
-        uint32_t* hc = lane_hcounts(lane);
+        uint32_t* hc = s->h_counts + lane * kCntNum;
         memset(hc, 0, sizeof(uint32_t) * kCntNum);
         hc[kCntIn] = gr.n0;
         HIPCHK(hipMemcpyAsync(gr.P.counts, hc, sizeof(uint32_t) * kCntNum, hipMemcpyHostToDevice, gst));
         HIPCHK(gr.tm.begin(&S.ms_generate));
         launch_generate(gst, gr.P, gr.n0);
         HIPCHK(gr.tm.end());
-        return enqueue(gr);
+        return feed(gr);
       };
-      // Scheduler: poll the active groups' streams; a group whose burst has drained gets its next one; a finished
-      // group frees its lane; passes are accumulated (ascending, on the main stream) as soon as every earlier group
-      // of the chunk is complete, and *finish_pass follows.  *cancel is read on every turn.
-      uint32_t next_start = 0, acc_prefix = 0, active = 0, acc_passes = 0;
+      // Scheduler: poll the active groups' rings; a group whose oldest enqueued iteration has reported gets more work enqueued
+      // behind what is still running; a finished group frees its lane; passes are accumulated (ascending, on the main stream) as
+      // soon as every earlier group of the chunk is complete, and *finish_pass follows.  *cancel is read on every turn.
+      uint32_t next_start = 0, acc_prefix = 0, active = 0, acc_passes = 0, idle_polls = 0;
       for (;;) {
         if (!stop && cancelled()) stop = true;
         // start groups while the window allows
@@ -1328,25 +1420,30 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
         bool progressed = false;
         for (Group& gr : G) {
           if (!gr.started || gr.finished) continue;
-          hipError_t q = hipStreamQuery(lane_stream(gr.lane));
-          if (q == hipErrorNotReady) continue;
-          HIPCHK(q);
-          progressed = true;
-          HIPCHK(gr.tm.collect());
-          const uint32_t* hc = lane_hcounts(gr.lane);
-          if (hc[kCntOverflow]) return fail(PBRHIP_EOVERFLOW, "BVH traversal stack overflow");
-          gr.n = std::max(hc[kCntIn], hc[kCntShadowIn]);  // pending shadow rays need one more trace
-          if (trace_sched)
-            fprintf(stderr, "sched %8.3f ms  group %d (passes %u)  iter %u  live %u\n",
-                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(),
-                    (int)(&gr - G.data()), gr.npass, gr.iters, gr.n);
-          if (gr.n == 0 || stop) {  // complete -- or abandoned: a cancelled render drops what is in flight
+          // the oldest iteration the host has not heard of: has its k_advance written the stamp?
+          while (gr.seen < gr.enq) {
+            const volatile uint32_t* slot = s->h_ring + ring_slot(gr.lane, gr.seen);
+            if (__atomic_load_n(&slot[3], __ATOMIC_ACQUIRE) != gr.stamps[gr.seen % kRingSlots]) break;
+            progressed = true;
+            if (slot[2]) return fail(PBRHIP_EOVERFLOW, "BVH traversal stack overflow");
+            gr.n = std::max(slot[0], slot[1]);  // pending shadow rays need one more trace
+            gr.seen++;
+            if (trace_sched)
+              fprintf(stderr, "sched %8.3f ms  group %d (passes %u)  iter %u of %u enqueued  live %u\n",
+                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(),
+                      (int)(&gr - G.data()), gr.npass, gr.seen, gr.enq, gr.n);
+          }
+          if (gr.seen == gr.enq && (gr.n == 0 || stop)) {  // complete -- or abandoned: a cancelled render drops what is in flight
+            HIPCHK(hipStreamSynchronize(lane_stream(gr.lane)));  // (its last k_advance has written the stamp: the stream is about to be idle)
+            HIPCHK(gr.tm.collect());
             gr.finished = gr.n == 0;
             if (!gr.finished) gr.started = false;
             lane_busy[gr.lane] = false, active--;
+            progressed = true;
             continue;
           }
-          if (int rc = enqueue(gr)) return rc;
+          if (gr.n != 0 && !stop)
+            if (int rc = feed(gr)) return rc;
         }
         // accumulate the complete prefix of the chunk's groups
         while (acc_prefix < ng && G[acc_prefix].finished) {
@@ -1366,7 +1463,22 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
           S.samples += (uint64_t)gr.npass * npix;
           publish((size_t)done + acc_passes);  // render.cc:224-231
         }
-        if (!progressed) std::this_thread::yield();
+        if (!progressed) {
+          std::this_thread::yield();
+          // (now and then: a stream that failed, or went idle without its last stamp, must not leave this loop spinning)
+          if ((++idle_polls & 1023u) == 0u)
+            for (Group& gr : G) {
+              if (!gr.started || gr.finished || gr.seen == gr.enq) continue;
+              const hipError_t q = hipStreamQuery(lane_stream(gr.lane));
+              if (q == hipErrorNotReady) continue;
+              HIPCHK(q);
+              const volatile uint32_t* slot = s->h_ring + ring_slot(gr.lane, gr.enq - 1u);
+              if (__atomic_load_n(&slot[3], __ATOMIC_ACQUIRE) != gr.stamps[(gr.enq - 1u) % kRingSlots])
+                return fail(PBRHIP_EHIP, "render: a path group's stream went idle without reporting its last iteration");
+            }
+        } else {
+          idle_polls = 0;
+        }
       }
       HIPCHK(hipStreamSynchronize(st));
       done += acc_passes;
@@ -1384,7 +1496,8 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
     if (want_stats) {
       unsigned long long hs[kStatNum];
       HIPCHK(hipMemcpy(hs, s->stats.p, sizeof(hs), hipMemcpyDeviceToHost));
-      S.closest_rays = hs[kStatClosestRays], S.closest_nodes = hs[kStatClosestNodes];
+      S.closest_rays = hs[kStatClosestRays] - hs[kStatSuspended], S.closest_nodes = hs[kStatClosestNodes];  // (a suspended ray is counted by the launch that suspends it and by the one that resumes it)
+      S.suspended_rays = hs[kStatSuspended];
       S.closest_tris = hs[kStatClosestTris], S.closest_curves = hs[kStatClosestCurves];
       S.shadow_rays = hs[kStatShadowRays], S.shadow_nodes = hs[kStatShadowNodes];
       S.tail_closest_rays = hs[kStatTailClosestRays], S.tail_shadow_rays = hs[kStatTailShadowRays];

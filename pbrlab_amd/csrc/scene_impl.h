@@ -113,6 +113,14 @@ struct pbrhip_scene {
   pb::DevBuf<pb::HookHit> hook_hits;
   pb::DevBuf<uint8_t> hook_occ;
   uint32_t* h_counts = nullptr;            // pinned, kMaxGroups x kCntNum
+  // Round 6: what the host learns about an iteration it enqueued -- written by the iteration's last kernel (k_advance) straight into
+  // pinned host memory: kRingSlots slots of 4 words per group lane: live paths, pending shadow rays, overflow flag, stamp (a number
+  // that is unique per scene and launch, written last).  The host polls the stamp: no copy, no stream query, and the NEXT iteration
+  // is already enqueued behind this one (pbrhip.cpp::render_impl).
+  uint32_t* h_ring = nullptr;              // pinned, kMaxGroups x kRingSlots x 4
+  uint32_t* d_ring = nullptr;              // the same memory as the device addresses it
+  uint32_t ring_stamp = 0;                 // last stamp handed out
+  pb::DevBuf<uint32_t> susp;               // suspend records of the resumable rays: lanes x 2 (written / read by alternate launches) x cap x kSuspWords
   std::vector<hipStream_t> group_streams;  // streams of path groups 1.. (group 0 uses `stream`)
   // pixel list cache key (ensure_pixels)
   uint32_t pk_w = 0, pk_h = 0, pk_rank = 0, pk_world = 0, pk_block = 0, pk_tile = 0, pk_npix = 0;

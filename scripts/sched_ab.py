@@ -15,7 +15,8 @@ W, H = 1920, 1080
 rgba = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda"); cnt = torch.zeros((H, W), dtype=torch.int32, device="cuda")
 torch.cuda.synchronize()
 REPS = int(os.environ.get("REPS", "3"))
-KEYS = ("PBRHIP_WIDE", "PBRHIP_WIDE_WALK", "PBRHIP_RAYS_PER_WAVE", "PBRHIP_GROUPS", "PBRHIP_WINDOW", "PBRHIP_BULK_DIV", "PBRHIP_GROUP_MIN_PATHS", "PBRHIP_STREAMS", "PBRHIP_TAIL_PATHS", "PBRHIP_QUAD_RAYS", "PBRHIP_PIXEL_TILE", "PBRHIP_TRACE_BLOCKS_SMALL", "PBRHIP_TRACE_BLOCKS", "PBRHIP_RETIRE")
+KEYS = ("PBRHIP_WIDE", "PBRHIP_WIDE_WALK", "PBRHIP_RAYS_PER_WAVE", "PBRHIP_GROUPS", "PBRHIP_WINDOW", "PBRHIP_BULK_DIV", "PBRHIP_GROUP_MIN_PATHS", "PBRHIP_STREAMS", "PBRHIP_TAIL_PATHS", "PBRHIP_QUAD_RAYS", "PBRHIP_PIXEL_TILE", "PBRHIP_TRACE_BLOCKS_SMALL", "PBRHIP_TRACE_BLOCKS", "PBRHIP_RETIRE",
+        "PBRHIP_SUSP_TURNS", "PBRHIP_PIPE_DEPTH", "PBRHIP_PIPE_DEPTH_SMALL", "PBRHIP_PIPE_STOP", "PBRHIP_SHADOW_FIRST", "PBRHIP_PATCH_SHUFFLE")
 CONFIGS = [
     {"PBRHIP_STREAMS": "1"},
     {"PBRHIP_STREAMS": "2"},                                 # round 1's default for big chunks
@@ -39,6 +40,9 @@ if os.environ.get("SCHED_CONFIGS"):
     CONFIGS = json.loads(os.environ["SCHED_CONFIGS"])
 
 
+SUMS = {}
+
+
 def best(world, rank=0, **kw):
     t_best, st_best = 1e9, None
     for _ in range(REPS):
@@ -48,6 +52,10 @@ def best(world, rank=0, **kw):
         dt = (time.perf_counter() - t) * 1e3
         if dt < t_best:
             t_best, st_best = dt, st
+    # the frame must not depend on the schedule: a checksum of its bits, compared with the first configuration's
+    chk = (int(rgba.view(torch.int32).to(torch.int64).sum().item()), int(cnt.to(torch.int64).sum().item()))
+    if SUMS.setdefault(world, chk) != chk:
+        print(f"!! world {world}: the frame differs from the first configuration's ({chk} vs {SUMS[world]})", flush=True)
     return t_best, st_best
 
 
@@ -60,8 +68,9 @@ for cfg in CONFIGS:
     t8, st8 = best(8)
     t4, _ = best(4)
     t2, _ = best(2)
+    _, sts = api.Render(s, W, H, spp, tile_rank=0, tile_world=8, device_out=(rgba.data_ptr(), cnt.data_ptr()), shard_block=16, flags=api.RENDER_STATS)
     print(f"{str(cfg):90s} world1 {t1:6.2f} ms ({st1['iterations']:3d} it)  1/2 {t2:6.2f} ({t1 / t2:.2f}x)  1/4 {t4:6.2f} ({t1 / t4:.2f}x)  "
-          f"1/8 {t8:6.2f} ms ({st8['iterations']:3d} it, {t1 / t8:.2f}x)", flush=True)
+          f"1/8 {t8:6.2f} ms ({st8['iterations']:3d} it, {t1 / t8:.2f}x; {sts['suspended_rays']} of {sts['closest_rays']} closest-hit rays suspended once)", flush=True)
 
 # where the time of rank 0's eighth goes (one group), and its timeline
 for k in KEYS:

@@ -31,7 +31,7 @@ def test_struct_layouts_match_header():
     from pbrlab_amd import _lib, api
     assert C.sizeof(api.PrincipledParam) == 25 * 4 and C.sizeof(api.HairParam) == 20 * 4
     assert C.sizeof(api.RenderDesc) == 56 and api.RAY_DT.itemsize == 32 and api.HIT_DT.itemsize == 36
-    assert C.sizeof(api.RenderStats) == 11 * 8 + 9 * 8 + 6 * 8 + 8 + 6 * 8
+    assert C.sizeof(api.RenderStats) == 11 * 8 + 9 * 8 + 6 * 8 + 8 + 7 * 8 + 8
     # the library's own idea of the layouts (a caller built against another header must be able to tell)
     L = _lib.lib()
     assert L.pbrhip_abi_version() == _lib.ABI_VERSION

@@ -156,4 +156,10 @@ def test_bench_spawns_its_own_ranks():
     r = subprocess.run([sys.executable, bench, "--gpus", "2", "--spawn-selftest"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-    assert json.loads(line) == {"selftest": 2, "sum": 3}
+    out = json.loads(line)
+    assert out["selftest"] == 2 and out["sum"] == 3
+    # the per-rank fields an N > 1 bench line carries (bench.rank_diagnostics, gathered over the same process group): rank r reports a
+    # render of 10 (r + 1) ms and an exchange of 1 + r ms
+    d = out["diagnostics"]
+    assert d["per_rank_render_ms"] == [10.0, 20.0] and d["exchange_ms"] == 2.0 and d["exchange_ms_rank0"] == 1.0
+    assert abs(d["imbalance"] - 20.0 / 15.0) < 1e-12 and d["slowest_rank"] == 1
