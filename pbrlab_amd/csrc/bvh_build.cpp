@@ -361,7 +361,7 @@ uint32_t build_qtree(const std::vector<BvhNode>& N2, const std::function<int(uin
         QChild c[2];
         const int m = map_leaf(ref, lo, hi, c);
         if (m == 1) {
-          T[v].ref = c[0].ref, T[v].prims = (c[0].ref & 7u) + 1u;
+          T[v].ref = c[0].ref, T[v].prims = ((c[0].ref & kCurveBit) && (c[0].ref & kCurvePairBit)) ? 2u : (c[0].ref & 3u) + 1u;  // (a curve record of two pieces: kCurvePairBit)
           for (int a = 0; a < 3; a++) T[v].lo[a] = c[0].lo[a], T[v].hi[a] = c[0].hi[a];
         } else {
           for (int j = 0; j < 2; j++) {

@@ -76,6 +76,17 @@ static_assert(sizeof(BvhNode) == 64, "node must be 64 B");
 // (count - 1) with `first` a POINT index (DScene::q_pt0): the linear pieces of a strand are stored as a chain of points
 // (xyz + radius, 16 B), piece p = points p, p + 1, piece-in-cubic index = p & 3 (every cubic starts at a multiple of 4).
 // An unused child has reference kEmptyChild.
+// Round 6 (PB_CURVE_RECORDS): a curve leaf is a RECORD instead of a stretch of a chain: four consecutive 16-byte words a0 a1 b0 b1 -- the
+// end points of its one or two pieces, copied; 64-byte aligned: one item, like a node -- and both pieces are tested in ONE turn of the
+// traversal.  Why: nine in ten of the two-piece leaves the SAH builder makes over hair are two pieces of NEIGHBOURING STRANDS, side by
+// side, not neighbours in a chain; rounds 3-5 cut such a leaf into two leaves of one piece (two children of its node, two turns).
+// Its reference is  kLeafBit | kCurveBit | (P | i_a) << 3 | (two pieces ? kCurvePairBit | i_b : 0),  P = the record's first point index
+// (a multiple of 4), i_a / i_b = the pieces' indices in their cubics (what `p & 3` was for a chain piece); piece a is point P, piece b
+// point P + 2 (q_hitcode has their codes).  PBRHIP_CURVE_RECORDS=0 at commit: the chains of rounds 3-5.
+constexpr uint32_t kCurvePairBit = 4u;
+#ifndef PB_CURVE_RECORDS
+#define PB_CURVE_RECORDS 1
+#endif
 struct alignas(16) QNode {
   float org[3], sx;
   float sy, sz;

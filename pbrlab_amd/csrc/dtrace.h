@@ -367,11 +367,17 @@ __device__ __forceinline__ bool leaf_test(const DScene& sc, uint32_t leaf, V3 o,
     best_t = hit.t;
     return occluded;
   }
-  for (uint32_t s = first; s < first + count; s++) {
+  // a curve record of the Q tree (dscene.h; PB_CURVE_RECORDS): one or two pieces at points P, P + 2; the low bits of `first` and of the
+  // reference are their indices in their cubics
+  const bool rec = PB_CURVE_RECORDS && WIDE && CURVES && is_curve;
+  const uint32_t sub_a = first & 3u, sub_b = leaf & 3u;
+  if (rec) first &= ~3u, count = (leaf & kCurvePairBit) ? 2u : 1u;
+  for (uint32_t k = 0; k < count; k++) {
+    const uint32_t s = first + (rec ? 2u * k : k);
     float t, u, v;
     bool ok;
     uint32_t code;
-    if (WIDE) {  // Q tree of a scene with curves: 48-byte triangle slots / chains of curve points (dscene.h)
+    if (WIDE) {  // Q tree of a scene with curves: 48-byte triangle slots / curve records or chains of curve points (dscene.h)
       if (!is_curve) {
         const float4* g = sc.wide + sc.q_tri0 + (size_t)s * 3;
         float4 a = g[0], b = g[1], c = g[2];
@@ -382,7 +388,7 @@ __device__ __forceinline__ bool leaf_test(const DScene& sc, uint32_t leaf, V3 o,
         const float4* g = sc.wide + sc.q_pt0 + s;
         float4 a = g[0], b = g[1];
         if (STATS) st.curves++;
-        ok = segment_test(a, b, s & 3u, o, d, inv, tmin, best_t, t, u, v);
+        ok = segment_test(a, b, rec ? (k ? sub_b : sub_a) : (s & 3u), o, d, inv, tmin, best_t, t, u, v);
         code = kQPointHit | s;
       }
     } else {

@@ -31,7 +31,7 @@ constexpr uint32_t kPvGuide = PB_GUIDE;   // a grab takes 1 / (kPvGuide x waves)
 #endif
 constexpr int kPvLdsStack = PB_LDS_STACK;  // stack entries per lane kept in LDS
 #ifndef PB_LDS_STACK_DEEP
-#define PB_LDS_STACK_DEEP 16
+#define PB_LDS_STACK_DEEP (PB_CURVE_RECORDS ? 20 : 16)  // (five blocks per CU with curve records: 30.7 KB of LDS each)
 #endif
 // ... and for the Q tree of scenes with curves (hair: trees 14-16 levels deep, up to three entries per level): a wave whose
 // lanes are on both sides of the LDS / spill boundary runs both push paths every node turn
@@ -57,9 +57,6 @@ constexpr int kPvRefillIdleCurves = PB_REFILL_CURVES;  // the same for scenes wi
 #endif
 #ifndef PB_W_TRI
 #define PB_W_TRI 2
-#endif
-#ifndef PB_CURVE_PAIRS
-#define PB_CURVE_PAIRS 0  // Q tree: 1 = both pieces of a two-piece curve leaf in one turn (measured: see profiles/README.md); 0: one piece per turn (rounds 3-5)
 #endif
 #ifndef PB_W_CURVE
 #define PB_W_CURVE 2  // (round 3, Q tree: 1 -> 216.6 ms per C4 frame, 2 -> 213.5; together with the refill at 24 idle lanes 210.2)
@@ -457,14 +454,15 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
           } else {
             advance = true;  // leaf done: pop
           }
-        } else if (PB_CURVE_PAIRS && WIDE && CURVES && mine && is_curve) {
-          // A curve leaf of the Q tree: one or two NEIGHBOURING pieces of a chain -- points cur, cur + 1 (, cur + 2) in D0, D1 (, D2) --
-          // in ONE turn (round 6): the ray frame is read once, the middle point projected once, and the second piece needs no turn
-          // of its own (a curve turn ran at 18 of 64 lanes).  Piece by piece the operations, their order and the accept rule are
-          // those of two one-piece turns: the same bits.
-          if (STATS) steps += 1u + rem, (any_ray ? st.acurves : st.curves) += 1u + rem;
-          // (the frame is read again for the third point instead of being held across the first piece's test: twenty LDS reads
-          // instead of ten, but no register more than a one-piece turn needs -- held, it spilt 28 bytes into the loop)
+        } else if (PB_CURVE_RECORDS && WIDE && CURVES && mine && is_curve) {
+          // A curve leaf of the Q tree is a RECORD (round 6, dscene.h): the end points a0 a1 (b0 b1) of its one or two pieces in D0, D1
+          // (D2, D3w), both tested in this ONE turn (rem & kCurvePairBit: a second piece; the pieces' indices in their cubics are the low
+          // bits of cur and of rem).  Piece by piece the operations, their order and the accept rule are those of two one-piece turns:
+          // the same bits.
+          const bool two = (rem & kCurvePairBit) != 0u;
+          if (STATS) steps += two ? 2u : 1u, (any_ray ? st.acurves : st.curves) += two ? 2u : 1u;
+          // (the frame is read again for the second piece instead of being held across the first piece's test: twenty LDS reads
+          // instead of ten, but no register more than a one-piece turn needs)
           auto read_frame = [&]() {
             RayFrame f;
             f.dn = V3(frame[0], frame[stride], frame[2 * stride]), f.bx = V3(frame[3 * stride], frame[4 * stride], frame[5 * stride]);
@@ -472,26 +470,24 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
             return f;
           };
           const V3 i3(inv4.x, inv4.y, inv4.z);
-          const uint32_t pt = cur - sc.q_pt0;
+          const uint32_t pt = (cur & ~3u) - sc.q_pt0;  // point index of the first piece
           bool occ = false;
-          V3 pb;
           {
             const RayFrame f = read_frame();
-            const V3 pa = segment_project(D0, o, f);
-            pb = segment_project(D1, o, f);
+            const V3 pa = segment_project(D0, o, f), pb = segment_project(D1, o, f);
             float t, u, v;
-            bool ok = segment_core(D0, D1, pa, pb, pt & 3u, o, f.inv_len, i3, tmin, hit.t, t, u, v);
+            bool ok = segment_core(D0, D1, pa, pb, cur & 3u, o, f.inv_len, i3, tmin, hit.t, t, u, v);
             const uint32_t code = kQPointHit | pt;
             if (ok && !any_ray && t == hit.t && hit.slot != kNone) ok = q_gid(sc, code) < q_gid(sc, hit.slot);
             if (ok) hit.t = t, hit.u = u, hit.v = v, hit.slot = code;
             occ = any_ray && ok;
           }
-          if (rem != 0u && !occ) {
+          if (two && !occ) {
             const RayFrame f = read_frame();
-            const V3 pc = segment_project(D2, o, f);
+            const V3 pa = segment_project(D2, o, f), pb = segment_project(D3w, o, f);
             float t, u, v;
-            bool ok = segment_core(D1, D2, pb, pc, (pt + 1u) & 3u, o, f.inv_len, i3, tmin, hit.t, t, u, v);
-            const uint32_t code = kQPointHit | (pt + 1u);
+            bool ok = segment_core(D2, D3w, pa, pb, rem & 3u, o, f.inv_len, i3, tmin, hit.t, t, u, v);
+            const uint32_t code = kQPointHit | (pt + 2u);
             if (ok && !any_ray && t == hit.t && hit.slot != kNone) ok = q_gid(sc, code) < q_gid(sc, hit.slot);
             if (ok) hit.t = t, hit.u = u, hit.v = v, hit.slot = code;
             occ = any_ray && ok;
@@ -576,10 +572,12 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
         const float4* g = top + cur;
         D0 = g[0], D1 = g[1], D2 = g[2], D3w = g[3];
       } else {
-        const float4* g = items + cur;
+        // (a curve record: four words; the low bits of its address carry a piece index)
+        const bool at_rec = PB_CURVE_RECORDS && CURVES && state == kStCurve;
+        const float4* g = items + (at_rec ? (cur & ~3u) : cur);
         D0 = g[0], D1 = g[1];
-        if (!CURVES || state != kStCurve || PB_CURVE_PAIRS) D2 = g[2];  // (a curve leaf: its third point -- the chains are padded, so the read is in bounds)
-        if (!CURVES || state == kStNode) D3w = g[3];
+        if (!CURVES || state != kStCurve || at_rec) D2 = g[2];
+        if (!CURVES || state == kStNode || at_rec) D3w = g[3];
         if (!CURVES && state == kStTri) D4 = g[4];
       }
     } else if (need_load) {

@@ -65,6 +65,11 @@ extern "C" int pbrhip_set_device(int device) {
   return PBRHIP_OK;
 }
 
+static uint32_t env_u32(const char* name, uint32_t dflt) {
+  const char* e = getenv(name);
+  return e ? (uint32_t)strtoul(e, nullptr, 10) : dflt;
+}
+
 // ------------------------------------------------------------------ scene construction
 extern "C" int pbrhip_scene_create(pbrhip_scene** out) {
   return guarded([&]() -> int {
@@ -672,7 +677,7 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
     std::vector<uint32_t> piece_point(np, kNone);
     {
       uint32_t prev_inst = kNone, prev_geom = kNone;
-      for (uint32_t g = 0; g < np; g++) {
+      for (uint32_t g = 0; g < np && !(env_u32("PBRHIP_CURVE_RECORDS", PB_CURVE_RECORDS) != 0u); g++) {  // (curve records: no chains)
         const PrimRef& pr = prims[g];
         if (pr.kind != 1 || pr.sub != 0) continue;
         float wcps[16], pt[5][4];
@@ -697,7 +702,7 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
     for (uint32_t k = 0; k < ns; k++) {
       const uint32_t g = bvh.slot_gid[k];
       slot_code[k] = k | __builtin_bit_cast(uint32_t, slots[4 * (size_t)k + 2].w);
-      if (prims[g].kind != 0) qhit[piece_point[g]] = slot_code[k];
+      if (prims[g].kind != 0 && piece_point[g] != kNone) qhit[piece_point[g]] = slot_code[k];
     }
     // Triangle leaves.  Triangle-only scenes: one TriPair per leaf (dscene.h): its one or two triangles interleaved coordinate by
     // coordinate, 80 bytes, both tested at once on packed fp32.  Scenes with curves (their kernels have no registers to spare
@@ -729,12 +734,31 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
       pair_words(first, count, &qtri[(size_t)rec * kTriPairWords]);
       return rec;
     };
-    size_t leaves_one = 0, leaves_pair = 0, leaves_split = 0;  // curve leaves of one piece / of two neighbouring pieces / binary leaves cut in two (PBRHIP_DEBUG)
+    size_t leaves_one = 0, leaves_pair = 0, leaves_split = 0;  // curve leaves of one piece / of two pieces / binary leaves cut in two (PBRHIP_DEBUG)
+    const bool curve_records = env_u32("PBRHIP_CURVE_RECORDS", PB_CURVE_RECORDS) != 0u;
     auto map_leaf = [&](uint32_t ref, const float* blo, const float* bhi, QChild* o) -> int {
       const uint32_t first = (ref & 0x3FFFFFFFu) >> 3, count = (ref & 7u) + 1u;
       if (!(ref & kCurveBit)) {
         o[0].ref = kLeafBit | (tri_pair(first, count) << 3) | (count - 1u);
         for (int a = 0; a < 3; a++) o[0].lo[a] = blo[a], o[0].hi[a] = bhi[a];
+        return 1;
+      }
+      if (curve_records) {
+        // a record (dscene.h): the end points of the leaf's one or two pieces, 64-byte aligned, tested in one turn
+        while (qpts.size() % 4) qpts.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
+        const uint32_t P = (uint32_t)qpts.size();
+        uint32_t sub[2] = {0u, 0u};
+        for (uint32_t i = 0; i < count; i++) {
+          const float4* sl = &slots[4 * (size_t)(first + i)];  // (a piece's slot of the binary tree: its two end points, then its index in the cubic)
+          qpts.push_back(sl[0]), qpts.push_back(sl[1]);
+          sub[i] = __builtin_bit_cast(uint32_t, sl[2].x) & 3u;
+        }
+        qhit.resize(qpts.size(), kNone);
+        qhit[P] = slot_code[first];
+        if (count == 2) qhit[P + 2] = slot_code[first + 1];
+        o[0].ref = kLeafBit | kCurveBit | ((P | sub[0]) << 3) | (count == 2 ? (kCurvePairBit | sub[1]) : 0u);
+        for (int a = 0; a < 3; a++) o[0].lo[a] = blo[a], o[0].hi[a] = bhi[a];
+        (count == 2 ? leaves_pair : leaves_one)++;
         return 1;
       }
       uint32_t p0 = piece_point[bvh.slot_gid[first]];
@@ -756,8 +780,11 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
       (count == 2 ? leaves_pair : leaves_one)++;
       return 1;
     };
-    if (qpts.size() >= (1u << 27) || build_qtree(bvh.nodes, map_leaf, &wide) > (uint32_t)kStackDepth) wide.clear();
-    if (getenv("PBRHIP_DEBUG")) fprintf(stderr, "pbrhip: commit: curve leaves of the Q tree (counted over the collapse's visits): %zu of one piece, %zu of two neighbouring pieces, %zu binary leaves cut in two\n", leaves_one, leaves_pair, leaves_split);
+    if (build_qtree(bvh.nodes, map_leaf, &wide) > (uint32_t)kStackDepth || qpts.size() >= (1u << 27)) wide.clear();
+    while (qtri.size() % 4) qtri.push_back(make_float4(0.f, 0.f, 0.f, 0.f));  // (q_pt0 a multiple of 4: the low bits of a curve record's address are free)
+    for (int k = 0; k < 4; k++) qpts.push_back(make_float4(0.f, 0.f, 0.f, 0.f));  // (the load site reads four words of a leaf)
+    qhit.resize(qpts.size(), kNone);
+    if (getenv("PBRHIP_DEBUG")) fprintf(stderr, "pbrhip: commit: curve leaves of the Q tree (counted over the collapse's visits): %zu of one piece, %zu of two pieces, %zu binary leaves cut in two\n", leaves_one, leaves_pair, leaves_split);
   }
   if (wide.empty()) s->d_wide.release(), s->d_qhit.release();
   if (getenv("PBRHIP_DEBUG")) fprintf(stderr, "pbrhip: commit: %u binary nodes, %zu wide nodes, %zu slots, %zu triangle leaves + %zu points in the Q tree\n", num_nodes, wide.size(), (size_t)ns, qtri.size() / kTriPairWords, qpts.size());
@@ -995,10 +1022,6 @@ struct Timer {
 };
 }  // namespace
 
-static uint32_t env_u32(const char* name, uint32_t dflt) {
-  const char* e = getenv(name);
-  return e ? (uint32_t)strtoul(e, nullptr, 10) : dflt;
-}
 
 void pb::shard_pixels(uint32_t w, uint32_t h, uint32_t rank, uint32_t world, uint32_t block, std::vector<uint32_t>* out) {
   if (block == 0) block = 64;  // CreateTiles' tile (pbrhip_create_tiles enumerates the same blocks in the same order)
