@@ -55,6 +55,93 @@ SIMDS, XCDS, CUS, CLOCK_HZ = 1024, 8, 256, 2.4e9   # 256 CUs x 4 SIMDs in 8 XCDs
 # (scripts/ubench/vmem_gather2.hip, profiles/r5_gather2.txt; L2-resident: 21.9; a fully coalesced control: 31.7).  An ESTIMATE of
 # what the load path can deliver to k_trace's access pattern -- it never sets `bound`.
 GATHER_L1_BYTES_PER_CLK_CU = 23.9
+# ... by item footprint (the same file: own 64 B = 4 loads 23.9, own 80 B = 5 loads 28.0, own 128 B = 8 loads 16.0 bytes per clock and CU from L1)
+GATHER_PEAK_BY_ITEM = {64: 23.9, 80: 28.0, 128: 16.0}
+
+
+# Cycles one wave64 VALU instruction occupies its SIMD, by class -- MEASURED (scripts/ubench/valu_rate.hip, valu_rate2.hip: profiles/r5_valu_rate*.txt,
+# r5_ubench_pmc.txt), in the chip's own cycles (GRBM_GUI_ACTIVE / 8 XCDs over SQ_INSTS_VALU / 1024 SIMDs of the VALU-bound calibration kernels:
+# v_fma_f32 2.33, v_pk_fma 4.18, v_pk_mul 4.19, v_pk_add 4.26, v_min 4.20, v_cvt_f32_ubyte 4.32, v_mul_lo 4.23, v_rcp 8.18; the second table's
+# instructions at the same 0.91 x nominal clock).  Round 6: the VALU ceiling is  SQ_INSTS_VALU x (the kernel's own mean cost per instruction,
+# from the histogram of its main loop in the code object) / (1024 SIMDs x the kernel's cycles)  -- not SQ_ACTIVE_INST_VALU x 4, which prices every
+# instruction at four cycles and read 1.16-1.25 on kernels made of plain fp32 multiply-adds.
+VALU_FULL, VALU_HALF, VALU_TRANS, VALU_F64 = 2.33, 4.2, 8.2, 8.2
+VALU_FULL_RATE = ("v_fma_f32", "v_fmac_f32", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_add_u32",
+                  "v_sub_u32", "v_subrev_u32", "v_mov_b32", "v_cndmask_b32", "v_add_co_u32", "v_addc_co_u32", "v_not_b32", "v_accvgpr")
+VALU_TRANSCENDENTAL = ("v_rcp_", "v_rsq_", "v_sqrt_", "v_exp_", "v_log_", "v_sin_", "v_cos_")
+
+
+def valu_cost(mnemonic):
+    m = mnemonic.lower()
+    if m.endswith("_f64") or "_f64_" in m or m.startswith(("v_mul_hi_", "v_mad_u64", "v_mad_i64", "v_lshlrev_b64", "v_lshrrev_b64", "v_lshl_add_u64")):
+        return VALU_F64 if "f64" in m else VALU_HALF
+    if m.startswith(VALU_TRANSCENDENTAL):
+        return VALU_TRANS
+    base = m[:-4] if m.endswith(("_e32", "_e64")) else m
+    base = base.replace("_dpp", "").replace("_sdwa", "")
+    if base.startswith(VALU_FULL_RATE):
+        return VALU_FULL
+    return VALU_HALF     # packed fp32, min / max / min3 / max3, compares, conversions, shifts, bit-field, integer multiply / mad, readlane ...: 3.9-4.5 measured
+
+
+def isa_histogram(kernel_substring):
+    """Static instruction histogram of one kernel of the built libpbrhip.so (llvm-objdump on its gfx950 code object): the VALU instructions of
+    its MAIN LOOP -- the widest backward branch: the persistent traversal's loop -- by mnemonic, and their mean measured cost (valu_cost).
+    A static mix stands in for the dynamic one (the loop's phases run at different frequencies): an estimate, said so in the output."""
+    import collections
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin"
+    lib = os.environ.get("PBRHIP_LIB") or os.path.join(ROOT, "pbrlab_amd", "libpbrhip.so")
+    if not (os.path.exists(lib) and os.path.exists(os.path.join(llvm, "llvm-objdump")) and shutil.which("c++filt")):
+        return None
+    tmp = tempfile.mkdtemp(prefix="pbr_isa_", dir="/tmp")
+    try:
+        fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "dev.co")
+        subprocess.run([os.path.join(llvm, "llvm-objcopy"), f"--dump-section=.hip_fatbin={fat}", lib], check=True, capture_output=True)
+        subprocess.run([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={fat}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                        f"--output={co}"], check=True, capture_output=True)
+        asm = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", co], check=True, capture_output=True, text=True).stdout
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    names = re.findall(r"^[0-9a-f]+ <(\S+)>:$", asm, re.M)
+    dem = subprocess.run(["c++filt"] + names, capture_output=True, text=True).stdout.split("\n")
+    want = next((n for n, d in zip(names, dem) if kernel_substring in d), None)
+    if want is None:
+        return None
+    body = asm.split(f"<{want}>:\n", 1)[1]
+    body = re.split(r"\n[0-9a-f]+ <\S+>:\n", body, 1)[0]
+    rows = []   # (address, mnemonic, branch target or None)
+    for line in body.splitlines():
+        m = re.match(r"\s+(\S+)\s.*//\s*([0-9A-Fa-f]+):", line)
+        if not m:
+            continue
+        t = re.search(r"<[^>]*\+0x([0-9a-fA-F]+)>", line)
+        rows.append((int(m.group(2), 16), m.group(1), t.group(1) if t else None))
+    if not rows:
+        return None
+    base = rows[0][0]
+    lo, hi = rows[0][0], rows[-1][0]
+    span = 0
+    for addr, mn, tgt in rows:
+        if tgt is not None and mn.startswith(("s_cbranch", "s_branch")):
+            ta = base + int(tgt, 16)
+            if ta < addr and addr - ta > span:
+                span, lo, hi = addr - ta, ta, addr
+    hist = collections.Counter(mn for addr, mn, _ in rows if lo <= addr <= hi and mn.startswith("v_"))
+    n = sum(hist.values())
+    if not n:
+        return None
+    cost = sum(valu_cost(mn) * c for mn, c in hist.items()) / n
+    full = sum(c for mn, c in hist.items() if valu_cost(mn) == VALU_FULL)
+    return {"kernel": next(d for nme, d in zip(names, dem) if nme == want).split("(")[0].replace("void pb::", ""), "valu_in_loop": n,
+            "mean_cycles_per_valu": cost, "full_rate_share": full / n, "salu_in_loop": sum(1 for addr, mn, _ in rows if lo <= addr <= hi and mn.startswith("s_")),
+            "vmem_in_loop": sum(1 for addr, mn, _ in rows if lo <= addr <= hi and mn.startswith(("global_", "flat_", "buffer_", "scratch_"))),
+            "top": dict(hist.most_common(8))}
 
 
 def csrc_hash():
@@ -465,7 +552,7 @@ def main():
     elapsed, agg = timed(spp, args.steps, args.warmup, 0 if args.no_roofline else api.RENDER_TIMING)
     diag = rank_diagnostics(dist, dev, clock["render"] / args.steps * 1e3, clock["exchange"] / args.steps * 1e3) if dist is not None else None
     check_layer(spp)
-    h_elapsed, _ = timed(spp, args.steps, 0, 0, to_host=True)
+    h_elapsed, _ = timed(spp, args.steps, 1, 0, to_host=True)   # (one untimed step first: the pinned destination is touched, the copy engine is warm)
     host_layer = {"value": W * H * spp * args.steps / h_elapsed / 1e6, "unit": "Msamples/s", "ms_per_step": h_elapsed / args.steps * 1e3,
                   "note": "the same steps, each ending with the RenderLayer (rgba f32 + count u32: 20 bytes per pixel) copied to pinned host memory of rank 0 -- "
                           "pbrlab's RenderLayer is host memory; PCIe-inclusive, reported beside `value`, never as it"}
@@ -473,6 +560,7 @@ def main():
     if world > 1:   # the other scaling mode, same run, as a secondary figure
         o_spp = w["spp"] * (1 if weak else world)
         o_elapsed, _ = timed(o_spp, args.steps, 1, 0)
+        check_layer(o_spp)
         other = {"scaling": "strong" if weak else "weak", "spp": o_spp, "ms_per_step": o_elapsed / args.steps * 1e3,
                  "value": W * H * o_spp * args.steps / o_elapsed / 1e6, "unit": "Msamples/s"}
 
@@ -518,34 +606,47 @@ def main():
                 # the kernel's own cycles: GRBM_GUI_ACTIVE is summed over the 8 XCDs (and over the launches of the pass)
                 cycles = pmc.get("GRBM_GUI_ACTIVE", 0.0) / XCDS
                 clock_hz = cycles / n_disp / solo_launch_s if cycles else None   # (counter pass / solo timing of the same launches: an estimate)
-                if pmc.get("SQ_ACTIVE_INST_VALU") and cycles:
-                    # VALU ceiling as a COUNTER RATIO (round 5; VERDICT round 4: a constant of 4 cycles per instruction was wrong for v_fma_f32
-                    # and a constant of 2 is wrong for everything else): SQ_ACTIVE_INST_VALU counts, in units of 4 cycles, the time the
-                    # waves spend executing VALU instructions; over 1024 SIMDs x the kernel's active cycles it is the fraction of the
-                    # launch the VALU pipes are busy.  Calibrated on kernels that are VALU-bound by construction
-                    # (scripts/ubench/valu_rate.hip, profiles/r5_ubench_pmc.txt): v_pk_fma / v_pk_mul / v_pk_add / v_min / v_cvt_f32_ubyte /
-                    # v_mul_lo_u32 (4.2-4.7 cycles per wave64 instruction and SIMD each, measured) read 0.96-0.99, v_rcp_f32 (8.2 cycles)
-                    # 0.98, the instruction mix of a Q-node slab test 1.02 -- and a stream of NOTHING BUT v_fma_f32 reads 1.70: that one
-                    # instruction class issues in 2.3-2.6 cycles and the counter prices it at 4.  k_trace has ~8 % plain v_fma_f32.
-                    frac_valu = pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / (SIMDS * cycles)
-                    valu = {"frac": frac_valu, "insts_valu_per_launch": pmc.get("SQ_INSTS_VALU", 0.0) / n_disp, "insts_salu_per_launch": pmc.get("SQ_INSTS_SALU", 0) / n_disp,
+                isa = isa_histogram({"c4": "k_trace<false, true, true, false>", "c5": "k_trace<false, true, true, false>"}.get(args.workload, "k_trace<false, false, true, false>"))
+                if pmc.get("SQ_INSTS_VALU") and cycles and isa:
+                    # VALU ceiling from the kernel's own instruction mix (round 6): wave-instructions issued x the mean measured cost of an instruction of
+                    # the kernel's main loop, over 1024 SIMDs x the kernel's cycles.  Scalar instructions share the issue slot (~1.7 cycles each between
+                    # vector ones, measured): reported as `with_salu`, a second estimate.  An estimator that reads above 1 is a broken model: null + why.
+                    busy = pmc["SQ_INSTS_VALU"] * isa["mean_cycles_per_valu"] / (SIMDS * cycles)
+                    busy_salu = (pmc["SQ_INSTS_VALU"] * isa["mean_cycles_per_valu"] + pmc.get("SQ_INSTS_SALU", 0.0) * 1.7) / (SIMDS * cycles)
+                    valu = {"frac": busy if busy <= 1.0 else None,
+                            "reason": None if busy <= 1.0 else f"the ISA-histogram model reads {busy:.2f} > 1: the static mix of the loop does not describe this launch's dynamic mix",
+                            "with_salu": busy_salu if busy_salu <= 1.0 else None,
+                            "mean_cycles_per_valu_inst": isa["mean_cycles_per_valu"], "full_rate_share": isa["full_rate_share"], "loop": {k: isa[k] for k in ("kernel", "valu_in_loop", "salu_in_loop", "vmem_in_loop", "top")},
+                            "insts_valu_per_launch": pmc.get("SQ_INSTS_VALU", 0.0) / n_disp, "insts_salu_per_launch": pmc.get("SQ_INSTS_SALU", 0) / n_disp,
                             "active_cycles_per_launch": cycles / n_disp, "clock_ghz": clock_hz / 1e9 if clock_hz else None,
-                            "cycles_per_valu_inst": pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / pmc["SQ_INSTS_VALU"] if pmc.get("SQ_INSTS_VALU") else None,
                             "lanes_per_valu": pmc["SQ_THREAD_CYCLES_VALU"] / pmc["SQ_INSTS_VALU"] if pmc.get("SQ_THREAD_CYCLES_VALU") and pmc.get("SQ_INSTS_VALU") else None,
                             "wait_any_frac": pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"] if pmc.get("SQ_WAVE_CYCLES") else None,
-                            "note": "frac = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs): a counter ratio over the kernel's own active cycles "
-                                    "(no clock assumed), ~1.0 on VALU-bound calibration kernels of this instruction mix; clock_ghz = active cycles / solo launch duration"}
-                    fracs["valu"] = frac_valu
+                            "counter_ratio_r5": pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / (SIMDS * cycles) if pmc.get("SQ_ACTIVE_INST_VALU") else None,
+                            "note": "frac = SQ_INSTS_VALU x mean measured cycles per VALU instruction of the kernel's main loop (static histogram of the code object: "
+                                    "full-rate fp32 add / mul / fma and simple integer / move / select 2.33 cycles, packed fp32, min / max, compares, conversions, shifts, "
+                                    "integer multiplies 4.2, transcendentals 8.2 -- scripts/ubench/valu_rate*.hip) / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); reads 1.0 on the "
+                                    "VALU-bound calibration kernels by construction (u_fma 2.33, u_pk_fma 4.18, u_rcp 8.18 cycles per instruction: profiles/r5_ubench_pmc.txt); "
+                                    "a static mix stands in for the dynamic one: an estimate; counter_ratio_r5 = round 5's SQ_ACTIVE_INST_VALU x 4 ratio, kept for comparison only"}
+                    if busy <= 1.0:
+                        fracs["valu"] = busy
                 if pmc.get("TCP_TOTAL_ACCESSES_sum") and cycles:
                     # the vector-memory load path: 16-byte lane accesses x 16 B over the kernel's cycles, against what the same access
                     # pattern gets from an L1-resident table (GATHER_L1_BYTES_PER_CLK_CU, measured).  An estimate: reported, never `bound`.
                     b_clk_cu = pmc["TCP_TOTAL_ACCESSES_sum"] * 16.0 / (cycles * CUS)
                     tag, miss = pmc.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0), pmc.get("TCP_TCC_READ_REQ_sum", 0.0)
-                    gather = {"frac": b_clk_cu / GATHER_L1_BYTES_PER_CLK_CU, "bytes_per_clk_cu": b_clk_cu, "peak_bytes_per_clk_cu": GATHER_L1_BYTES_PER_CLK_CU,
+                    # the peak for THIS kernel's items (round 6): nodes and curve records are 64-byte items (4 loads), the triangle leaves of a
+                    # triangle-only scene 80-byte items (5 loads: TriPair), 48-byte triangle slots are priced as 64; the byte-weighted harmonic mean
+                    nb = node_b * (sst["closest_nodes"] + sst["shadow_nodes"]) + 64.0 * (sst["closest_curves"] + sst["shadow_curves"]) / 2.0
+                    tb = (80.0 / 2.0 if not desc.num_segments() else 64.0) * (sst["closest_tris"] + sst["shadow_tris"])
+                    peak_items = (nb + tb) / (nb / GATHER_PEAK_BY_ITEM[64] + tb / GATHER_PEAK_BY_ITEM[80 if not desc.num_segments() else 64]) if (nb + tb) else GATHER_L1_BYTES_PER_CLK_CU
+                    g_frac = b_clk_cu / peak_items
+                    gather = {"frac": g_frac if g_frac <= 1.0 else None,
+                              "reason": None if g_frac <= 1.0 else f"reads {g_frac:.2f} > 1 of the micro-benchmark's rate for this item mix: the kernel's accesses share lines (lanes_per_line) the benchmark's do not",
+                              "bytes_per_clk_cu": b_clk_cu, "peak_bytes_per_clk_cu": peak_items,
                               "l1_hit_rate": 1.0 - miss / tag if tag else None, "lanes_per_line": pmc["TCP_TOTAL_ACCESSES_sum"] / tag if tag else None,
                               "l2_read_latency_cycles": pmc["TCP_TCC_READ_REQ_LATENCY_sum"] / miss if miss and pmc.get("TCP_TCC_READ_REQ_LATENCY_sum") else None,
                               "note": "ESTIMATE (does not set `bound`): TCP_TOTAL_ACCESSES x 16 B per clock and CU over the measured rate of per-lane 64-byte gathers "
-                                      "from an L1-resident table (scripts/ubench/vmem_gather2.hip: 23.9 B/clk/CU at 1-6 blocks per CU; L2-resident 21.9; "
+                                      "from an L1-resident table, by item footprint (scripts/ubench/vmem_gather2.hip: 64-byte items 23.9, 80-byte items 28.0 B/clk/CU at 1-6 blocks per CU; L2-resident 21.9; "
                                       "coalesced control 31.7; beyond L2 the unit of cost is the 128-byte line: ~60 G lines/s chip-wide)"}
                 ok = {k: v for k, v in fracs.items() if v is not None and v <= 1.0}   # a ceiling fraction above 1 is a broken model, never a bound
                 if ok:
@@ -593,6 +694,15 @@ def main():
                        "parallelism": f"{shard_block}x{shard_block} pixel blocks, block index % {world}" if world > 1 else "1gpu",
                        "rng": "PCG32((pass<<32)+pixel, 1234567890)"},
             "roofline": roofline, "cpu_baseline": cpu, "host_layer": host_layer,
+            "metric_definition": {"version": 2,
+                                  "value": "a step = Render() of the frame with the scene resident in HBM; it ends with the complete RenderLayer (rgba f32 + count u32) "
+                                           "in the HBM of rank 0 (N > 1: after the exchange over xGMI)",
+                                  "why": "the run's measurement contract: \"`value` is whole-job throughput with inputs already resident in HBM when the timed region starts "
+                                         "(if the boundary hands over host buffers, note the PCIe-inclusive rate in DESIGN.md -- it is never `value`)\"; pbrlab's "
+                                         "RenderLayer is host memory, so the PCIe-inclusive figure is reported beside it as host_layer.  Rounds 1-4 (version 1) reported the "
+                                         "host-inclusive figure as `value`: compare like with like -- r4 value with r5 / r6 host_layer.value",
+                                  "host_copy": "41.5 MB (1920 x 1080 x 20 B) over PCIe in 0.7-0.8 ms = its ~55 GB/s: the copy cannot start before the last pass is "
+                                               "accumulated (the layer is a sum over all passes) -- it is the floor of host_layer.ms_per_step - ms_per_step"},
         }
         if diag is not None:   # N > 1: where each rank's time went (gathered after the timed region)
             out.update(diag)

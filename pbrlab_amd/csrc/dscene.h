@@ -82,7 +82,7 @@ static_assert(sizeof(BvhNode) == 64, "node must be 64 B");
 // side, not neighbours in a chain; rounds 3-5 cut such a leaf into two leaves of one piece (two children of its node, two turns).
 // Its reference is  kLeafBit | kCurveBit | (P | i_a) << 3 | (two pieces ? kCurvePairBit | i_b : 0),  P = the record's first point index
 // (a multiple of 4), i_a / i_b = the pieces' indices in their cubics (what `p & 3` was for a chain piece); piece a is point P, piece b
-// point P + 2 (q_hitcode has their codes).  PBRHIP_CURVE_RECORDS=0 at commit: the chains of rounds 3-5.
+// point P + 2 (q_hitcode has their codes).  A build option (-DPB_CURVE_RECORDS=0: the chains of rounds 3-5, one piece per turn).
 constexpr uint32_t kCurvePairBit = 4u;
 #ifndef PB_CURVE_RECORDS
 #define PB_CURVE_RECORDS 1

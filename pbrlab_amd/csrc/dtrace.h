@@ -31,7 +31,7 @@ struct TravStats {
   uint32_t ahist[8], amax_steps;  // the same for any-hit (shadow) rays
   uint32_t refill_ticks;          // 100 MHz ticks the wave spent in refills (lane 0)
   unsigned long long cyc[4];      // shader-clock cycles (s_memtime) of the wave's loop turns by what the turn did: node, triangle, curve phase, refill (lane 0)
-  uint32_t suspended;             // rays this lane suspended (dtrace_pv.h)
+  uint32_t suspended, suspended_any;  // closest-hit / any-hit rays this lane suspended (dtrace_pv.h)
   unsigned long long t_exhausted; // 100 MHz clock when this wave found the ray queue empty (0: never; always recorded, once per wave: PBRHIP_WAVE_LOG)
 };
 

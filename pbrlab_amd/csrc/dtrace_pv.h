@@ -98,7 +98,7 @@ template <typename Sink>
 struct SinkSuspends<Sink, decltype((void)Sink::kSuspend)> { static constexpr bool value = Sink::kSuspend && !Sink::kWalk; };
 template <typename Sink>
 __device__ constexpr bool sink_suspends() { return SinkSuspends<Sink>::value; }
-constexpr uint32_t kTagShadow = 0x80000000u, kTagNoSuspend = 0x40000000u, kTagResume = 0x20000000u;
+constexpr uint32_t kTagShadow = 0x80000000u, kTagNoSuspend = 0x40000000u, kTagResume = 0x20000000u, kTagHeld = 0x10000000u;
 constexpr uint32_t kSuspRecWords = 72;  // == kernels.h::kSuspWords: hit (4 words) | cur, state | rem << 8 | sp << 16, 0, 0 | the stack
 
 // WIDE: the Q tree (sc.wide: QNode, dscene.h: four children per 64-byte node with quantised boxes, compact triangle slots,
@@ -610,7 +610,7 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
       rec[4] = cur, rec[5] = state | (rem << 8) | ((uint32_t)sp << 16);
       for (int i = 0; i < sp; i++) rec[8 + i] = i < kLds ? stk_base[(uint32_t)i * stride] : spill[(uint32_t)(i - kLds) * spill_stride];
       sink.suspended(tag, j, o, d);
-      if (STATS) st.suspended++;
+      if (STATS) (any_ray ? st.suspended_any : st.suspended)++;
     }
   }
 }

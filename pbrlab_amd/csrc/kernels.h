@@ -71,13 +71,18 @@ struct PathState {
   // to no shading queue in this iteration (k_classify / the direct first shading re-queue it with kQResume) and the ray RESUMES at
   // the head of the next iteration's k_trace (susp_in = this launch's susp_out), inside that launch's bulk phase.  A suspended ray
   // loses nothing and its hit does not change (the traversal continues where it stopped), so images are bit-identical; the path
-  // just skips one shading round.  Shadow rays and the bounded rays of paths inside a medium are never suspended (a shadow ray's
-  // payload sits at the path's slot, which the path's next shading overwrites).  susp_turns = 0: never (the launch before k_tail,
-  // the hooks).
+  // just skips one shading round.  The bounded rays of paths inside a medium are never suspended.  A SHADOW ray (scenes without media
+  // only: no_medium) is suspended too: its payload sits at the path's own slot, which the path's next shading would overwrite, and its
+  // contribution has to reach L before that shading's (float sums do not commute) -- so the suspending lane sets hold[p], re-queues the
+  // ray itself (one atomic per wave: q_shadow) and the path's next shading, finding hold[p] set, does nothing but hand the path back
+  // (result word kRHold -> trace-queue entry with kQHold: its closest-hit ray is NOT traced again, its hit record stands); the launch that
+  // finishes the shadow ray clears hold[p].  susp_turns = 0: never (the launch before k_tail, the hooks).
   uint32_t susp_turns;             // drain turns before suspension (0: never)
   uint32_t* susp_out;              // this launch's records: one per resident thread of the launch (kSuspRecords)
   const uint32_t* susp_in;         // the previous launch's
   uint32_t shadow_first;           // k_trace takes the shadow rays of the previous bounce before this bounce's closest-hit rays
+  PathView<uint4, 4> rng4;         // rec + 3 as one 16-byte word: generator state (x, y) | hold (z) | -
+  PathView<uint32_t, 16> hold;     // rec + 3, third word: 1 while the path's shadow ray is suspended -- the path's next shading waits for it (above)
 };
 constexpr uint32_t kSuspWords = 72;  // hit (4) | cur, state | rem << 8 | sp << 16, -, - (4) | stack (kStackDepth = 64)
 static_assert(kStackDepth <= 64, "a suspend record holds the whole traversal stack");
@@ -89,12 +94,18 @@ constexpr uint32_t kQSssBit = 0x80000000u, kQDoomed = 0x40000000u, kQPathMask = 
 // ... | "the path's pending shading is its FIRST bounce" (a camera ray that was suspended: its shading runs in a later iteration, next
 // to other paths' later bounces) | "the path's ray is a suspended one: resume it" (trace queue only)
 constexpr uint32_t kQFirst = 1u << 29, kQResume = 1u << 28;
+// in a scene WITHOUT media bit 31 of a trace-queue entry means: the path is HELD -- its closest-hit ray is traced already (the hit record
+// stands), it waits for its suspended shadow ray (PathState::hold)
+constexpr uint32_t kQHold = kQSssBit;
 constexpr uint32_t kHitSuspended = 0xFFFFFFFEu;  // hit code of a path whose closest-hit ray was suspended (kNone = 0xFFFFFFFF: a miss)
 // shade-kernel result word (written over the kernel's own queue entry): path slot (28 bits) | flags
 constexpr uint32_t kRPathMask = 0x0FFFFFFFu, kRShadow = 1u << 28, kRAlive = 1u << 29;
 // ... or, for a path whose closest-hit ray was suspended: kRResume WITHOUT kRAlive (no shading produces that: a path inside a medium
 // is alive) | kQDoomed of its queue entry | kRResumeFirst = its kQFirst; k_compact re-queues it with kQResume
 constexpr uint32_t kRResume = kQSssBit, kRResumeFirst = kRShadow;
+// ... or, for a HELD path (its shadow ray is suspended: PathState::hold): kRHold without kRAlive and without kRResume (no shading
+// produces that: kQDoomed comes with kRAlive) | kRHoldDoomed = the kQDoomed of its queue entry; k_compact re-queues it with kQHold
+constexpr uint32_t kRHold = kQDoomed, kRHoldDoomed = kRShadow;
 constexpr uint64_t kMaxPathsInFlight = (1ull << 28) - 1;
 enum : uint32_t { kShNormal = 0u, kShSssEntry = 1u, kShSssExit = 2u };
 enum : uint32_t {
@@ -109,6 +120,8 @@ enum : uint32_t {
   kStatStepHist0, kStatStepHistLast = kStatStepHist0 + 7, kStatMaxSteps, kStatMaxWaveIters,
   kStatWalkNodes, kStatWalkTris, kStatWalkTurns, kStatWalkSteps,
   kStatAnyHist0, kStatAnyHistLast = kStatAnyHist0 + 7, kStatAnyMaxSteps,
+  kStatHeld,  // trace-queue entries of HELD paths (no ray behind them: subtracted from the closest-hit rays)
+  kStatSuspendedShadow,  // shadow rays suspended (counted once more as a shadow ray of the launch that resumes each)
   kStatSuspended,  // rays suspended (each is counted once more as a closest-hit ray of the launch that resumes it: subtracted there)
   kStatCycNode, kStatCycTri, kStatCycCurve, kStatCycRefill, kStatWalkCycTrav, kStatWalkCycStep,  // shader-clock cycles of the phase-voting waves' loop turns by what the turn did (lane 0 of every wave)
   kStatNum

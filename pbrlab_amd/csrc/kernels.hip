@@ -80,19 +80,43 @@ struct TraceSinkT {
   static constexpr bool kResumes = !FIRST;  // (a group's first launch traces camera rays only)
   __device__ __forceinline__ uint32_t* susp_out() const { return P.susp_out; }
   __device__ __forceinline__ const uint32_t* susp_in() const { return P.susp_in; }
-  __device__ __forceinline__ bool suspendable(uint32_t tag) const { return (tag & (kTagShadow | kTagNoSuspend)) == 0u; }
+  // closest-hit rays of paths outside media; in scenes without media shadow rays as well (kernels.h::PathState::hold)
+  __device__ __forceinline__ bool suspendable(uint32_t tag) const {
+    return (tag & kTagNoSuspend) == 0u && (!(tag & kTagShadow) || (!FIRST && P.no_medium != 0u));
+  }
   __device__ __forceinline__ void suspended(uint32_t tag, uint32_t rec, V3 o, V3 d) const {
     const uint32_t p = tag & kQPathMask;
+    if (!FIRST && (tag & kTagShadow)) {
+      // a shadow ray: its record index goes where a medium exit would keep its second contribution (unused without media), the path is
+      // held, and the ray re-queues itself for the next launch (one atomic per wave; k_compact appends behind it)
+      P.sh_e[p] = make_float4(__uint_as_float(rec), 0.f, 0.f, 0.f);
+      P.hold[p] = 1u;
+      const unsigned long long m = __ballot(true);
+      const int leader = __ffsll((long long)m) - 1;
+      uint32_t base = 0u;
+      if ((int)__lane_id() == leader) base = atomicAdd(&P.counts[kCntShadow], (uint32_t)__popcll(m));
+      base = (uint32_t)__shfl((int)base, leader);
+      P.q_shadow[base + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = p | kQResume;
+      return;
+    }
     P.hit[p] = make_float4(__uint_as_float(rec), 0.f, 0.f, __uint_as_float(kHitSuspended));
     if (FIRST) {  // a camera ray was computed, not loaded: the launch that resumes it loads it like any other ray
       P.ray_o[p] = mk4(o, 0.0f);
       P.ray_d[p] = mk4(d, kInf);
     }
   }
-  __device__ __forceinline__ uint32_t resume_index(uint32_t tag) const { return __float_as_uint(P.hit[tag & kQPathMask].x); }
-  // a trace-queue entry's flags as tag bits: a path inside a medium is never suspended, a suspended ray resumes
-  static __device__ __forceinline__ uint32_t entry_tag(uint32_t entry) {
-    return (entry & kQPathMask) | ((entry & kQSssBit) ? kTagNoSuspend : 0u) | ((entry & kQResume) ? kTagResume : 0u);
+  __device__ __forceinline__ uint32_t resume_index(uint32_t tag) const {
+    const uint32_t p = tag & kQPathMask;
+    return __float_as_uint((tag & kTagShadow) ? P.sh_e[p].x : P.hit[p].x);
+  }
+  // a trace-queue entry's flags as tag bits: a path inside a medium is never suspended (with media) / a held path's ray is not
+  // traced again (without: kQHold = the same bit), a suspended ray resumes
+  __device__ __forceinline__ uint32_t entry_tag(uint32_t entry) const {
+    return (entry & kQPathMask) | ((entry & kQSssBit) ? (kTagNoSuspend | (P.no_medium ? kTagHeld : 0u)) : 0u) | ((entry & kQResume) ? kTagResume : 0u);
+  }
+  // a shadow-queue entry: kQResume = the ray was suspended (its path is held: cleared when the ray is delivered)
+  static __device__ __forceinline__ uint32_t shadow_tag(uint32_t entry) {
+    return (entry & kQPathMask) | kTagShadow | ((entry & kQResume) ? (kTagResume | kTagHeld) : 0u);
   }
   // queue position -> (shadow ray?, index in its queue): the shadow rays of the previous bounce first (shadow_first) or last
   __device__ __forceinline__ bool is_shadow(uint32_t idx, uint32_t& k) const {
@@ -117,9 +141,11 @@ struct TraceSinkT {
   __device__ __forceinline__ void done_finish(uint32_t tag, const Pending& q, const Hit& h, bool occluded) const {
     const uint32_t p = tag & kQPathMask;
     if (!(tag & kTagShadow)) {
-      P.hit[p] = make_float4(h.t, h.u, h.v, __uint_as_float(h.slot));
+      if (!(tag & kTagHeld)) P.hit[p] = make_float4(h.t, h.u, h.v, __uint_as_float(h.slot));  // (a held path's hit record stands)
+      else if (P.stats) atomicAdd(&P.stats[kStatHeld], 1ull);  // (statistics renders: the entry was no ray)
       return;
     }
+    if (tag & kTagHeld) P.hold[p] = 0u;  // (a shadow ray that was suspended: its path may be shaded again)
     if (occluded && P.no_medium) return;  // (an ordinary shadow ray that is occluded adds nothing)
     const uint32_t mode = __float_as_uint(q.c.w);
     if (mode == kShSssEntry) {
@@ -151,13 +177,13 @@ struct TraceSinkT {
       tag = entry_tag(entry);
       const uint32_t p = entry & kQPathMask;
       const float4 o4 = P.ray_o[p], d4 = P.ray_d[p];
-      o = ld3(o4), d = ld3(d4), tmin = o4.w, tmax = d4.w;
+      o = ld3(o4), d = ld3(d4), tmin = o4.w, tmax = (tag & kTagHeld) ? -1.0f : d4.w;  // (a held path: an empty interval -- nothing is traced)
       return false;
     }
-    tag = entry;
-    float4 o4 = P.ray_o[tag], d4 = P.sh_d[tag];
+    tag = shadow_tag(entry);
+    const uint32_t p = entry & kQPathMask;
+    float4 o4 = P.ray_o[p], d4 = P.sh_d[p];
     o = ld3(o4), d = ld3(d4), tmin = o4.w, tmax = d4.w;
-    tag |= kTagShadow;
     return true;
   }
   __device__ __forceinline__ bool load(uint32_t idx, uint32_t& tag, V3& o, V3& d, float& tmin, float& tmax) const {
@@ -171,21 +197,24 @@ struct TraceSinkT {
       tag = entry_tag(entry);
       const uint32_t p = entry & kQPathMask;
       const float4 o4 = P.ray_o[p], d4 = P.ray_d[p];
-      o = ld3(o4), d = ld3(d4), tmin = o4.w, tmax = d4.w;
+      o = ld3(o4), d = ld3(d4), tmin = o4.w, tmax = (tag & kTagHeld) ? -1.0f : d4.w;  // (a held path: an empty interval -- nothing is traced)
       return false;
     }
-    tag = P.q_shadow_in[k];
-    float4 o4 = P.ray_o[tag], d4 = P.sh_d[tag];
+    const uint32_t entry = P.q_shadow_in[k];
+    tag = shadow_tag(entry);
+    const uint32_t p = entry & kQPathMask;
+    float4 o4 = P.ray_o[p], d4 = P.sh_d[p];
     o = ld3(o4), d = ld3(d4), tmin = o4.w, tmax = d4.w;
-    tag |= kTagShadow;
     return true;
   }
   __device__ __forceinline__ void done(uint32_t tag, const Hit& h, bool occluded) const {
     const uint32_t p = tag & kQPathMask;
     if (!(tag & kTagShadow)) {
-      P.hit[p] = make_float4(h.t, h.u, h.v, __uint_as_float(h.slot));
+      if (!(tag & kTagHeld)) P.hit[p] = make_float4(h.t, h.u, h.v, __uint_as_float(h.slot));  // (a held path's hit record stands)
+      else if (P.stats) atomicAdd(&P.stats[kStatHeld], 1ull);  // (statistics renders: the entry was no ray)
       return;
     }
+    if (tag & kTagHeld) P.hold[p] = 0u;  // (a shadow ray that was suspended: its path may be shaded again)
     if (occluded && P.no_medium) return;  // (an ordinary shadow ray that is occluded adds nothing: its payload is not even read)
     const float4 c = P.sh_c[p];
     const uint32_t mode = __float_as_uint(c.w);
@@ -226,8 +255,9 @@ __device__ __forceinline__ void trace_stats_out(const PathState& P, const TravSt
       for (int i = 0; i < 4; i++)
         if (st.cyc[i]) atomicAdd(&P.stats[kStatCycNode + i], st.cyc[i]);
     {
-      const uint32_t su = wave_sum(st.suspended);
+      const uint32_t su = wave_sum(st.suspended), sa = wave_sum(st.suspended_any);
       if (__lane_id() == 0 && su) atomicAdd(&P.stats[kStatSuspended], (unsigned long long)su);
+      if (__lane_id() == 0 && sa) atomicAdd(&P.stats[kStatSuspendedShadow], (unsigned long long)sa);
     }
     if (__lane_id() == 0) atomicMax(&P.stats[kStatMaxWaveIters], (unsigned long long)(st.it_node + st.it_tri + st.it_curve + st.it_refill));
     if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -418,8 +448,8 @@ __global__ __launch_bounds__(kBlock) void k_classify(PathState P, DScene sc) {
       dest[j] = 0, p[j] = 0, doomed[j] = false;
       if (i < n) {
         const uint32_t e = P.first ? ((P.slot0 + i) | kQFirst) : P.q_in[i];  // (a group's first bounce: entry i is path slot0 + i)
-        p[j] = e & (kQPathMask | kQFirst);
-        dest[j] = (e & kQSssBit) ? 1u : 0xFFu;
+        p[j] = e & (kQPathMask | kQFirst | kQDoomed);  // (kQDoomed rides along: a held path hands it back, kernels.h::kRHold)
+        dest[j] = (!P.no_medium && (e & kQSssBit)) ? 1u : 0xFFu;  // (without media bit 31 is kQHold: the path is routed by its hit like any other)
         doomed[j] = (e & kQDoomed) != 0u;
       }
     }
@@ -431,7 +461,7 @@ __global__ __launch_bounds__(kBlock) void k_classify(PathState P, DScene sc) {
         if (code == kNone || (!(code & kHitLight) && (doomed[j] || (code & kHitNoMaterial)))) dest[j] = 0u;
         // a path whose ray was suspended (its ray goes on in the next launch) rides through the principled queue untouched: the shading
         // kernel turns its entry into a "resume" result word and k_compact re-queues it -- no atomic, no queue of its own
-        if (code == kHitSuspended) dest[j] = 4u, p[j] |= kQResume | (doomed[j] ? kQDoomed : 0u);
+        if (code == kHitSuspended) dest[j] = 4u, p[j] |= kQResume;
       }
     if (threadIdx.x < 2) tile_principled[threadIdx.x] = 0u;
     __syncthreads();
@@ -472,24 +502,27 @@ __global__ __launch_bounds__(kBlock) void k_compact(PathState P) {
     // a "resume" word (kRResume without kRAlive: the path's ray was suspended, kernels.h) goes back to the trace queue with kQResume
     // (everything below is a function of e[j]: nothing else is kept per item)
     auto resumes = [](uint32_t w) { return (w & (kRAlive | kRResume)) == kRResume; };
+    // ... and a "hold" word (kRHold alone: the path's shadow ray is suspended) with kQHold: its closest-hit ray is not traced again
+    auto holds = [](uint32_t w) { return (w & (kRAlive | kRResume | kRHold)) == kRHold; };
     // two independent streams share one pass: run the compactor once per stream
     TileCompactor<2, kItemsPerThread> ta = {wcount, base, {}};
     {
       uint32_t dest[kItemsPerThread];
 #pragma unroll
-      for (int j = 0; j < kItemsPerThread; j++) dest[j] = ((e[j] & kRAlive) || resumes(e[j])) ? 1u : 0u;
+      for (int j = 0; j < kItemsPerThread; j++) dest[j] = ((e[j] & kRAlive) || resumes(e[j]) || holds(e[j])) ? 1u : 0u;
       ta.run(dest, counters);
 #pragma unroll
       for (int j = 0; j < kItemsPerThread; j++)
         if (dest[j])
           P.q_out[ta.slot(j, 1u)] = resumes(e[j]) ? ((e[j] & (kRPathMask | kQDoomed)) | kQResume | ((e[j] & kRResumeFirst) ? kQFirst : 0u))
-                                                  : (e[j] & (kRPathMask | kQSssBit | kQDoomed));
+                                    : (holds(e[j]) ? ((e[j] & kRPathMask) | kQHold | ((e[j] & kRHoldDoomed) ? kQDoomed : 0u))
+                                                   : (e[j] & (kRPathMask | kQSssBit | kQDoomed)));
       __syncthreads();
     }
     {
       uint32_t dest[kItemsPerThread];
 #pragma unroll
-      for (int j = 0; j < kItemsPerThread; j++) dest[j] = ((e[j] & kRShadow) && !resumes(e[j])) ? 2u : 0u;
+      for (int j = 0; j < kItemsPerThread; j++) dest[j] = ((e[j] & kRShadow) && !resumes(e[j]) && !holds(e[j])) ? 2u : 0u;
       ta.run(dest, counters);
 #pragma unroll
       for (int j = 0; j < kItemsPerThread; j++)
@@ -508,22 +541,36 @@ struct PathHead {
   Rng rng;
   uint32_t flags;
 };
-__device__ __forceinline__ bool path_head(const PathState& P, const DScene& sc, uint32_t p, uint64_t rng_inc, PathHead& c, bool first) {
+// Returns kHeadEnds when the path ends here, kHeadHeld when its shadow ray of the previous bounce is still suspended (PathState::hold:
+// nothing is touched, the path waits one more iteration), else kHeadGoes.
+enum : int { kHeadEnds = 0, kHeadGoes = 1, kHeadHeld = 2 };
+// HOLD: the kernel can meet held paths (scenes without media only: compiled out of the kernel of scenes with media, kShadeMedia, which sits at the
+// edge of its register class; the kShadeFull instances also serve scenes without media -- the statistics build of k_tail -- and keep the hold word
+// initialised: a hair shading of the same path reads it)
+template <bool HOLD = true>
+__device__ __forceinline__ int path_head(const PathState& P, const DScene& sc, uint32_t p, uint64_t rng_inc, PathHead& c, bool first) {
   float4 h4 = P.hit[p];
   float4 o4 = make_float4(P.cam_org[0], P.cam_org[1], P.cam_org[2], 0.0f), t4 = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
   c.flags = first ? 0u : kFlagNotFirst;  // set by every head after the first (render.cc:43-61: depth-0 emission has weight 1)
   uint64_t rng_state;
+  bool held = false;
   if (!first) {
     o4 = P.ray_o[p], t4 = P.thr[p];
     c.dir = ld3(P.ray_d[p]);
-    rng_state = P.rng[p];
+    if (HOLD) {
+      const uint4 r4 = P.rng4[p];  // generator state | hold | - : one 16-byte word of the path's record
+      rng_state = (uint64_t)r4.x | ((uint64_t)r4.y << 32);
+      held = P.no_medium != 0u && r4.z != 0u;
+    } else {
+      rng_state = P.rng[p];
+    }
   } else {
     camera_sample(P, p - P.slot0, c.dir, rng_state);  // the camera ray's values are implied or recomputed (PathState::first)
   }
   c.h.t = h4.x, c.h.u = h4.y, c.h.v = h4.z, c.h.slot = __float_as_uint(h4.w);
   c.s = make_surface(sc, ld3(o4), c.dir, c.h);
   c.thr = ld3(t4);
-  if (c.s.face == kFront && c.s.lightrec != kNone) {  // render.cc:43-62, LightManager::ImplicitAreaLight
+  if (!held && c.s.face == kFront && c.s.lightrec != kNone) {  // render.cc:43-62, LightManager::ImplicitAreaLight
     const float4* lr = reinterpret_cast<const float4*>(sc.lrecs + c.s.lightrec);
     float pdf_area = lr[0].w;
     V3 emission = ld3(lr[4]);
@@ -535,10 +582,17 @@ __device__ __forceinline__ bool path_head(const PathState& P, const DScene& sc, 
   c.rng.state = rng_state, c.rng.inc = rng_inc;
   float rr = spectrum_norm(c.thr);  // render.cc:66-68 (Q1)
   float u = draw(c.rng);
-  if (rr < u) return false;
+  if (held) return kHeadHeld;  // (nothing was stored: the path is shaded when its shadow ray has been delivered)
+  if (rr < u) return kHeadEnds;
   c.thr = c.thr * V3(1.0f / rr);
   c.flags |= kFlagNotFirst;
-  return (c.s.flags & kSlotMatNone) == 0;  // shader.cc:11-17: no material -> throughput 0 -> path ends
+  return (c.s.flags & kSlotMatNone) == 0 ? kHeadGoes : kHeadEnds;  // shader.cc:11-17: no material -> throughput 0 -> path ends
+}
+// a continuing path's generator state, with its hold flag cleared (the 16-byte word of its record: kernels.h::PathState)
+template <bool HOLD = true>
+__device__ __forceinline__ void store_rng(const PathState& P, uint32_t p, uint64_t state) {
+  if (HOLD) P.rng4[p] = make_uint4((uint32_t)state, (uint32_t)(state >> 32), 0u, 0u);
+  else P.rng[p] = state;
 }
 
 // kQDoomed for a path that continues with throughput `thr` and generator state `state`: the head of its next shading
@@ -639,7 +693,8 @@ __device__ __forceinline__ uint32_t shade_principled_path(const PathState& P, co
     nee.dir = V3(0.f), nee.emission = V3(0.f), nee.dist = 0.f, nee.pdf_sigma = 0.f;
     uint32_t sh_mode = kShNormal, qbit = 0u;
     PathHead c;
-    if (active && path_head(P, sc, p, rng_inc, c, first)) {
+    const int head = path_head<MODE != kShadeMedia>(P, sc, p, rng_inc, c, first);
+    if (active && head == kHeadGoes) {
       const Hit& h = c.h;
       const V3 dir = c.dir, thr = c.thr;
       const Surface& s = c.s;
@@ -773,7 +828,7 @@ __device__ __forceinline__ uint32_t shade_principled_path(const PathState& P, co
               P.ray_o[p] = mk4(s.pos, 1e-3f);
               P.ray_d[p] = mk4(next_dir, kInf);
               P.thr[p] = mk4(t2, new_pdf);
-              P.rng[p] = rng.state;
+              store_rng<MODE != kShadeMedia>(P, p, rng.state);
             } else {
               qbit = 0u;
               count_pruned(P);
@@ -783,7 +838,7 @@ __device__ __forceinline__ uint32_t shade_principled_path(const PathState& P, co
       }
     }
     if (shadow) put_shadow(P, sh_pos, nee, c_vis, V3(0.f), p, sh_mode, alive);
-    return (shadow ? kRShadow : 0u) | (alive ? kRAlive : 0u) | qbit;
+    return head == kHeadHeld ? kRHold : ((shadow ? kRShadow : 0u) | (alive ? kRAlive : 0u) | qbit);
   }
 }
 #ifndef PB_SHADE_WAVES
@@ -832,6 +887,7 @@ __global__ __launch_bounds__(kBlock, MODE == kShadePlain ? PB_SHADE_WAVES : (MOD
       go = false, r = kRResume | (e & kQDoomed) | ((e & kQFirst) ? kRResumeFirst : 0u);
     }
     if (go) r = shade_principled_path<MODE>(P, sc, p, rng_inc, P.first != 0u || (e & kQFirst) != 0u, staged ? lds_bsdf : nullptr, lights_staged ? lds_lights : nullptr);
+    if (r == kRHold && (e & kQDoomed) && !direct) r |= kRHoldDoomed;  // (a held path hands its queue entry's kQDoomed back)
     P.q_principled[i] = p | r;
   }
 }
@@ -847,7 +903,8 @@ __device__ __forceinline__ uint32_t shade_hair_path(const PathState& P, const DS
     Nee nee;
     nee.dir = V3(0.f), nee.emission = V3(0.f), nee.dist = 0.f, nee.pdf_sigma = 0.f;
     PathHead c;
-    if (active && path_head(P, sc, p, rng_inc, c, first)) {
+    const int head = path_head(P, sc, p, rng_inc, c, first);
+    if (active && head == kHeadGoes) {
       const Hit& h = c.h;
       const V3 dir = c.dir, thr = c.thr;
       const Surface& s = c.s;
@@ -892,7 +949,7 @@ __device__ __forceinline__ uint32_t shade_hair_path(const PathState& P, const DS
             P.ray_o[p] = mk4(s.pos, 1e-3f);
             P.ray_d[p] = mk4(next_dir, kInf);
             P.thr[p] = mk4(t2, pdf);
-            P.rng[p] = rng.state;
+            store_rng(P, p, rng.state);
           } else {
             qbit = 0u;
             count_pruned(P);
@@ -901,7 +958,7 @@ __device__ __forceinline__ uint32_t shade_hair_path(const PathState& P, const DS
       }
     }
     if (shadow) put_shadow(P, sh_pos, nee, c_vis, V3(0.f), p, kShNormal, alive);
-    return (shadow ? kRShadow : 0u) | (alive ? kRAlive : 0u) | qbit;
+    return head == kHeadHeld ? kRHold : ((shadow ? kRShadow : 0u) | (alive ? kRAlive : 0u) | qbit);
   }
 }
 __global__ __launch_bounds__(kBlock) void k_shade_hair(PathState P, DScene sc, uint64_t rng_inc) {
@@ -911,7 +968,9 @@ __global__ __launch_bounds__(kBlock) void k_shade_hair(PathState P, DScene sc, u
   const uint32_t n = P.counts[kCntHair];
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
     const uint32_t e = P.q_hair[i], p = e & kQPathMask;
-    P.q_hair[i] = p | shade_hair_path(P, sc, p, rng_inc, P.first != 0u || (e & kQFirst) != 0u, lights_staged ? lds_lights : nullptr);
+    uint32_t r = shade_hair_path(P, sc, p, rng_inc, P.first != 0u || (e & kQFirst) != 0u, lights_staged ? lds_lights : nullptr);
+    if (r == kRHold && (e & kQDoomed)) r |= kRHoldDoomed;  // (a held path hands its queue entry's kQDoomed back)
+    P.q_hair[i] = p | r;
   }
 }
 
@@ -1257,7 +1316,7 @@ __global__ __launch_bounds__(kBlock, PB_TAIL_WAVES) void k_tail(PathState P, DSc
     uint32_t state = 0u;
     if (lane < per_wave && base + lane < n) {
       const uint32_t e = P.first ? P.slot0 + base + lane : P.q_in[base + lane];
-      state = (e & kQPathMask) | kHave | ((e & kQSssBit) ? kMedium : 0u) | ((P.first || (e & kQFirst)) ? kFirst : 0u);  // the tail starts at the very first bounce of tiny renders (kQFirst: a camera ray that was suspended on its way)
+      state = (e & kQPathMask) | kHave | ((!P.no_medium && (e & kQSssBit)) ? kMedium : 0u) | ((P.first || (e & kQFirst)) ? kFirst : 0u);  // the tail starts at the very first bounce of tiny renders (kQFirst: a camera ray that was suspended on its way)
     }
     uint32_t team = 1u;  // lanes per path: 1, 2 (pairs) or 8 (octets)
     for (;;) {

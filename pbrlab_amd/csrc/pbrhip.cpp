@@ -677,7 +677,7 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
     std::vector<uint32_t> piece_point(np, kNone);
     {
       uint32_t prev_inst = kNone, prev_geom = kNone;
-      for (uint32_t g = 0; g < np && !(env_u32("PBRHIP_CURVE_RECORDS", PB_CURVE_RECORDS) != 0u); g++) {  // (curve records: no chains)
+      for (uint32_t g = 0; g < np && !PB_CURVE_RECORDS; g++) {  // (curve records: no chains)
         const PrimRef& pr = prims[g];
         if (pr.kind != 1 || pr.sub != 0) continue;
         float wcps[16], pt[5][4];
@@ -735,7 +735,7 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
       return rec;
     };
     size_t leaves_one = 0, leaves_pair = 0, leaves_split = 0;  // curve leaves of one piece / of two pieces / binary leaves cut in two (PBRHIP_DEBUG)
-    const bool curve_records = env_u32("PBRHIP_CURVE_RECORDS", PB_CURVE_RECORDS) != 0u;
+    const bool curve_records = PB_CURVE_RECORDS != 0;  // (a build option: the traversal kernels are compiled for one leaf format)
     auto map_leaf = [&](uint32_t ref, const float* blo, const float* bhi, QChild* o) -> int {
       const uint32_t first = (ref & 0x3FFFFFFFu) >> 3, count = (ref & 7u) + 1u;
       if (!(ref & kCurveBit)) {
@@ -1230,6 +1230,8 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
     P.pass_run = 1u;
     P.ray_o.base = s->rec.p, P.ray_d.base = s->rec.p + 1, P.thr.base = s->rec.p + 2, P.L = s->L.p, P.hit = s->hit.p;
     P.rng.base = reinterpret_cast<uint64_t*>(s->rec.p + 3);
+    P.hold.base = reinterpret_cast<uint32_t*>(s->rec.p + 3) + 2;
+    P.rng4.base = reinterpret_cast<uint4*>(s->rec.p + 3);
     P.sss_sigt.base = s->ssrec.p, P.sss_sigs.base = s->ssrec.p + 1, P.sss_thr.base = s->ssrec.p + 2;
     P.sss_ez.base = s->ssrec.p + 3, P.sss_A = s->sss_A.p;
     P.q_in = s->q[0].p, P.q_out = s->q[1].p, P.q_principled = s->q[2].p, P.q_hair = s->q[3].p, P.q_sss = s->q[4].p, P.q_shadow = s->q[5].p, P.q_shadow_in = s->q[6].p;
@@ -1519,10 +1521,10 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
     if (want_stats) {
       unsigned long long hs[kStatNum];
       HIPCHK(hipMemcpy(hs, s->stats.p, sizeof(hs), hipMemcpyDeviceToHost));
-      S.closest_rays = hs[kStatClosestRays] - hs[kStatSuspended], S.closest_nodes = hs[kStatClosestNodes];  // (a suspended ray is counted by the launch that suspends it and by the one that resumes it)
-      S.suspended_rays = hs[kStatSuspended];
+      S.closest_rays = hs[kStatClosestRays] - hs[kStatSuspended] - hs[kStatHeld], S.closest_nodes = hs[kStatClosestNodes];  // (a suspended ray is counted by the launch that suspends it and by the one that resumes it)
+      S.suspended_rays = hs[kStatSuspended] + hs[kStatSuspendedShadow];
       S.closest_tris = hs[kStatClosestTris], S.closest_curves = hs[kStatClosestCurves];
-      S.shadow_rays = hs[kStatShadowRays], S.shadow_nodes = hs[kStatShadowNodes];
+      S.shadow_rays = hs[kStatShadowRays] - hs[kStatSuspendedShadow], S.shadow_nodes = hs[kStatShadowNodes];
       S.tail_closest_rays = hs[kStatTailClosestRays], S.tail_shadow_rays = hs[kStatTailShadowRays];
       S.pruned_rays = hs[kStatPrunedRays];
       S.shadow_tris = hs[kStatShadowTris], S.shadow_curves = hs[kStatShadowCurves];

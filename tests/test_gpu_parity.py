@@ -142,6 +142,52 @@ def test_path_order_inside_a_block_does_not_matter(pa, pairs, tile, monkeypatch)
         assert acc.tobytes() == rgba.tobytes() and np.array_equal(cacc, cnt), (tile, w, h)
 
 
+@pytest.mark.parametrize("turns", ["0", "1", "3", "24"])
+@pytest.mark.parametrize("name", ["lambert", "ggx", "sss", "hair", "textured"])
+def test_resumable_rays_are_exact(pa, pairs, name, turns, monkeypatch):
+    """Round 6: a k_trace wave that has found the ray queue empty suspends the rays it still traces after PBRHIP_SUSP_TURNS more loop turns
+    (closest-hit rays everywhere; shadow rays in scenes without media, whose paths are then HELD until the ray is delivered) and the
+    next launch resumes them where they stopped (kernels.h::PathState::susp_turns).  With 1 or 3 turns nearly every ray of these small
+    frames is suspended, many of them several times; a suspended ray loses nothing and its hit does not change, so the frame is the
+    oracle's bit for bit and the ray counts are the reference's -- with the wavefront kernels alone and with a hand-over to k_tail in the
+    middle, with the host one iteration ahead or three, shadow rays first or last in the launch."""
+    desc, sg, so = pairs[name]
+    monkeypatch.setenv("PBRHIP_SUSP_TURNS", turns)
+    rgba, cnt, ost = so.render(96, 80, 5, threads=8, math_mode=O.MATH_DEVICE)
+    seen = 0
+    for tail, depth, shadow_first in [(0xFFFFFFFF, "2", "1"), (2500, "3", "0"), (0xFFFFFFFF, "1", "0")]:
+        monkeypatch.setenv("PBRHIP_PIPE_DEPTH", depth)
+        monkeypatch.setenv("PBRHIP_SHADOW_FIRST", shadow_first)
+        layer = pa.RenderLayer()
+        ok, st = pa.Render(sg, 96, 80, 5, layer=layer, flags=pa.api.RENDER_STATS, tail_paths=tail)
+        assert np.array_equal(layer.count, cnt) and layer.rgba.tobytes() == rgba.tobytes(), (name, turns, tail, depth)
+        assert (st["closest_rays"] + st["tail_closest_rays"] + st["pruned_rays"], st["shadow_rays"] + st["tail_shadow_rays"]) == (ost["closest_rays"], ost["shadow_rays"])
+        seen += st["suspended_rays"]
+    assert (seen == 0) == (turns == "0"), (name, turns, seen)
+    if turns in ("1", "3"):
+        assert seen > 1000, (name, turns, seen)     # (the case really exercises the path)
+
+
+def test_patch_order_does_not_matter(pa, pairs, monkeypatch):
+    """Round 6: the 8 x 8 pixel patches of a pass are laid out in a scattered order (PBRHIP_PATCH_SHUFFLE: a batch of k_trace's ray queue is
+    eight image regions instead of one).  A permutation of the work: the image is the oracle's either way, alone and sharded.  (The
+    curve leaves of the Q tree are 64-byte records of one or two arbitrary pieces since round 6 -- a build option, PB_CURVE_RECORDS --:
+    every hair / curve test of this file runs on them, and test_wide_and_binary_trees_agree compares them with the binary tree.)"""
+    for name in ("hair", "ggx"):
+        desc, sg, so = pairs[name]
+        rgba, cnt, _ = so.render(131, 77, 3, threads=8, math_mode=O.MATH_DEVICE)
+        for shuffle in ("1", "0"):
+            monkeypatch.setenv("PBRHIP_PATCH_SHUFFLE", shuffle)
+            for tail, world in ((0xFFFFFFFF, 1), (0, 1), (0, 3)):
+                acc, cacc = np.zeros_like(rgba), np.zeros_like(cnt)
+                for r in range(world):
+                    part = pa.RenderLayer()
+                    pa.Render(sg, 131, 77, 3, layer=part, tail_paths=tail, tile_rank=r, tile_world=world, shard_block=16 if world > 1 else 0)
+                    acc += part.rgba
+                    cacc += part.count
+                assert np.array_equal(cacc, cnt) and acc.tobytes() == rgba.tobytes(), (name, shuffle, tail, world)
+
+
 @pytest.mark.parametrize("run", ["1", "2", "4", "8", "64"])
 @pytest.mark.parametrize("name", ["hair", "ggx"])
 def test_pass_runs_do_not_matter(pa, pairs, name, run, monkeypatch):

@@ -20,7 +20,7 @@ BUDGETS = {
     "k_trace<false, false, false, false>": (80, 0),    # binary tree, triangles: 6 waves per SIMD (7 until round 6)
     "k_trace<false, true, false, false>": (80, 0),     # binary tree, curves: 6 waves
     "k_trace<false, false, true, false>": (80, 0),     # Q tree, triangles: 6 waves
-    "k_trace<false, true, true, false>": (80, 0),      # Q tree, curves: 6 waves
+    "k_trace<false, true, true, false>": (96, 0),      # Q tree, curves: 5 waves since round 6 (curve records: both pieces of a leaf in one turn; 6 before)
     # a group's first launch (camera rays computed in the refill path): one block per CU fewer, nothing spilled into the loop
     "k_trace<false, false, true, true>": (80, 0),      # (triangle-only scenes: the same six blocks as the other launches since round 5)
     "k_trace<false, true, true, true>": (96, 0),
@@ -43,7 +43,7 @@ BUDGETS = {
     "k_shade_hair": (128, 0),
     "k_sss_step": (128, 0),
     "k_classify": (64, 0),
-    "k_compact": (96, 0),
+    "k_compact": (104, 0),
 }
 
 def kernel_table():
@@ -76,11 +76,11 @@ def kernel_table():
 # silently is the number of waves a SIMD holds): waves per SIMD = 512 // VGPRs rounded up to 8, at most 8.
 MIN_WAVES_PER_SIMD = {
     "k_trace<false, false, false, false>": 6, "k_trace<false, true, false, false>": 6, "k_trace<false, false, true, false>": 6,
-    "k_trace<false, true, true, false>": 6, "k_trace<false, false, true, true>": 6, "k_trace<false, true, true, true>": 5,
+    "k_trace<false, true, true, false>": 5, "k_trace<false, false, true, true>": 6, "k_trace<false, true, true, true>": 5,
     "k_sss_walk<false, false, true>": 4, "k_shade_principled<0>": 4, "k_shade_principled<1>": 4, "k_shade_principled<2>": 3,
     "k_tail<0, false, false, true>": 3, "k_tail<1, false, false, true>": 3, "k_shade_hair": 4,
     "k_sss_step": 4,
-    "k_classify": 8, "k_compact": 5,
+    "k_classify": 8, "k_compact": 4,
 }
 
 
