@@ -218,6 +218,31 @@ struct LightHead {
   uint32_t first, count;  // range in LightRec / prim cdf
 };
 
+// Round 6: where the rays of a random walk start (k_sss_walk).  A walk's ray is a short segment inside its instance and two node visits
+// long, the first of which is always the root.  Per instance, at commit: the CUT of the Q tree that covers everything a segment inside the
+// instance's bounds can meet -- every reference (inner node or leaf) whose box meets the instance's bounds widened by a margin, found by
+// descending from the root wherever that drops a child; one inner node of it (the one that holds the instance) is the ENTRY, the others
+// -- primitives of OTHER instances inside the bounds: the floor under a statue; a hit on them ends the walk in the reference,
+// random-walk-sss.h:371-384 -- are FOREIGN references with the boxes their parents present.  A ray whose end points lie inside `lo / hi`
+// (the bounds widened by the smaller margin) starts at the entry, with the foreign references its interval meets (the tree's own
+// conservative slab test on those very boxes) on its stack; any other ray starts at the root.  Sound because a hit is accepted only inside
+// the ray's interval through the primitive's own box (dtrace.h): a primitive whose box is more than the margin away from every point of
+// the segment cannot be hit -- and the closest of what is left is the closest (hits do not depend on the visiting order).
+constexpr uint32_t kSssMaxForeign = 7;
+struct alignas(16) SssEntry {
+  float lo[3];
+  uint32_t entry;     // index of the Q node the walk's rays start at; 0 with nforeign = 0: the root, always
+  float hi[3];
+  uint32_t nforeign;
+  struct {
+    float lo[3];
+    uint32_t ref;
+    float hi[3];
+    uint32_t pad;
+  } foreign[kSssMaxForeign];
+};
+static_assert(sizeof(SssEntry) == 16 * (2 + 2 * kSssMaxForeign), "SssEntry is read as 16-byte words");
+
 struct DScene {
   const BvhNode* nodes;
   const float4* slots;
@@ -239,6 +264,8 @@ struct DScene {
   uint32_t top_nodes;           // nodes 0 .. top_nodes-1 are the breadth-first top of the tree (<= kTopNodes; 0: not numbered that way)
   uint32_t wide_top_nodes;      // the same for the Q tree
   uint32_t lights_transformed;  // an emissive instance has a transform: lrecs / light_boxes are not what the raytracer sees
+  const SssEntry* sss_entries;  // per instance (num_sss_entries), or null: where its random walks' rays start
+  uint32_t num_sss_entries;
 };
 
 // camera of RenderingTile (render.cc:132-158), derived on the host from the scene AABB

@@ -307,6 +307,15 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
           hit.u = 0.f, hit.v = 0.f, hit.slot = kNone;
           sp = 0, steps = 0;
           advance = true, have_next = true, next = 0u;  // root is always an internal node
+          if constexpr (Sink::kWalk && WIDE) {
+            // a random walk's ray starts below the root where its instance has an entry (dscene.h::SssEntry): `next` becomes the entry node
+            // and the foreign references the ray's interval meets go on the stack
+            sink.entry(sc, o, d, inv, tmin, hit.t, next, [&](uint32_t ref) {
+              if (sp < kLds) stk_base[(uint32_t)sp * stride] = ref;
+              else spill[(uint32_t)(sp - kLds) * spill_stride] = ref;
+              sp++;
+            });
+          }
         }
       }
       batch_cur += taken;

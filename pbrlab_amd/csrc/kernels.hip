@@ -1176,7 +1176,7 @@ __global__ __launch_bounds__(kBlock) void k_sss_step(PathState P, DScene sc, uin
 #define PB_WALK_CAP 24u  // A/B on C3 (walk + step kernels, ms per frame): no cap 230, 128: 183, 64: 164, 32: 149, 24: 140, 16: 139, 12: 134 (but more iterations), 8: 138
 #endif
 constexpr uint32_t kWalkCap = PB_WALK_CAP;
-constexpr uint32_t kWalkWords = 21;  // words of walk state per lane in LDS (WalkSink)
+constexpr uint32_t kWalkWords = 22;  // words of walk state per lane in LDS (WalkSink)
 struct WalkSink {
   static constexpr bool kWalk = true;
   const PathState& P;
@@ -1193,6 +1193,7 @@ struct WalkSink {
     const float4 h4 = P.hit[p];
     h.t = h4.x, h.u = h4.y, h.v = h4.z, h.slot = __float_as_uint(h4.w);
     wl[7 * kBlock] = __uint_as_float(0u), wl[8 * kBlock] = __uint_as_float(p);
+    wl[21 * kBlock] = __uint_as_float(kNone);  // (the walk's instance: known once the walk is fetched)
     if (h.slot == kNone) {  // a scattering is pending: fetch the walk
       const float4 o4 = P.ray_o[p], d4 = P.ray_d[p], wt4 = P.sss_thr[p];
       const uint64_t r = P.rng[p];
@@ -1202,6 +1203,7 @@ struct WalkSink {
       const float4 st4 = P.sss_sigt[p], ss4 = P.sss_sigs[p];
       wl[9 * kBlock] = st4.x, wl[10 * kBlock] = st4.y, wl[11 * kBlock] = st4.z;
       wl[12 * kBlock] = ss4.x, wl[13 * kBlock] = ss4.y, wl[14 * kBlock] = ss4.z;
+      wl[21 * kBlock] = ss4.w;  // the instance the walk entered (its bits)
       const V3 albedo = safe_divide_spectrum(ld3(ss4), ld3(st4));  // what scatter_channel_pdf derives from them every time
       wl[18 * kBlock] = albedo.x, wl[19 * kBlock] = albedo.y, wl[20 * kBlock] = albedo.z;
     }
@@ -1239,6 +1241,47 @@ struct WalkSink {
     }
     return false;
   }
+  // Where this walk's next ray starts (dscene.h::SssEntry): the entry node of the walk's instance when both ends of the ray lie inside the
+  // instance's (widened) bounds, with the foreign references the ray's interval meets pushed on its stack; otherwise the root.  The box
+  // test of a foreign reference is the binary tree's (box_test2's operations on the box the reference's parent presents): conservative and
+  // monotone in the box, so no reference that can hold an accepted hit is dropped.
+  template <typename Push>
+  __device__ __forceinline__ void entry(const DScene& sc, V3 o, V3 d, V3 inv, float tmin, float tmax, uint32_t& next, Push push) const {
+    const uint32_t inst = __float_as_uint(wl[21 * kBlock]);
+    if (sc.sss_entries == nullptr) return;
+    // the far end of the ray (any rounding is far inside the margins the bounds were widened by; a NaN fails the test below)
+    const V3 end(o.x + tmax * d.x, o.y + tmax * d.y, o.z + tmax * d.z);
+    // The lanes of a wave nearly always walk in ONE instance: the instance's record is fetched with scalar loads (a wave-uniform
+    // address: one fetch for the wave instead of sixteen 16-byte loads per lane) -- a waterfall loop over the distinct instances.
+    for (unsigned long long todo = __ballot(true); todo != 0ull;) {
+      const uint32_t u = (uint32_t)__builtin_amdgcn_readlane((int)inst, __ffsll((long long)todo) - 1);
+      const bool mine = inst == u;
+      todo &= ~__ballot(mine);
+      if (u >= sc.num_sss_entries) continue;
+      // (the constant address space: read-only during the launch and wave-uniform -> s_load_dwordx4)
+      typedef const __attribute__((address_space(4))) float* ConstF;
+      const ConstF ef = (ConstF)(reinterpret_cast<uintptr_t>(sc.sss_entries + u));
+      auto word = [&](uint32_t i) { return make_float4(ef[4 * i], ef[4 * i + 1], ef[4 * i + 2], ef[4 * i + 3]); };
+      const float4 e0 = word(0), e1 = word(1);
+      const uint32_t ent = __float_as_uint(e0.w), nf = __float_as_uint(e1.w);
+      if (ent == 0u) continue;
+      const bool inside = mine && o.x >= e0.x && o.y >= e0.y && o.z >= e0.z && o.x <= e1.x && o.y <= e1.y && o.z <= e1.z && end.x >= e0.x &&
+                          end.y >= e0.y && end.z >= e0.z && end.x <= e1.x && end.y <= e1.y && end.z <= e1.z;
+      if (inside) next = ent;
+      for (uint32_t k = 0; k < nf; k++) {
+        const float4 f0 = word(2 + 2 * k), f1 = word(3 + 2 * k);
+        float t0 = (f0.x - o.x) * inv.x, t1 = (f1.x - o.x) * inv.x;
+        float a = __builtin_fminf(t0, t1), b = __builtin_fmaxf(t0, t1);
+        t0 = (f0.y - o.y) * inv.y, t1 = (f1.y - o.y) * inv.y;
+        a = __builtin_fmaxf(a, __builtin_fminf(t0, t1)), b = __builtin_fminf(b, __builtin_fmaxf(t0, t1));
+        t0 = (f0.z - o.z) * inv.z, t1 = (f1.z - o.z) * inv.z;
+        a = __builtin_fmaxf(a, __builtin_fminf(t0, t1)), b = __builtin_fminf(b, __builtin_fmaxf(t0, t1));
+        const float eps = 1.52587890625e-05f;
+        a = __builtin_fmaf(-fabsf(a), eps, a), b = __builtin_fmaf(fabsf(b), eps, b);
+        if (inside && a <= b && b >= tmin && a <= tmax) push(__float_as_uint(f0.w));
+      }
+    }
+  }
   // (trace_pv only calls these for sinks that do not walk)
   __device__ __forceinline__ bool load(uint32_t, uint32_t&, V3&, V3&, float&, float&) const { return false; }
   __device__ __forceinline__ void done(uint32_t, const Hit&, bool) const {}
@@ -1247,7 +1290,7 @@ struct WalkSink {
 #define PB_WALK_WAVES 3  // waves per SIMD of k_sss_walk: <= 168 VGPRs, nothing spilled
 #endif
 #ifndef PB_WALK_WAVES_TRI
-#define PB_WALK_WAVES_TRI 4  // ... on the Q tree of a triangle-only scene (C3): 116-120 VGPRs, nothing spilled, 37.9 KB of LDS since round 5: four blocks per CU, 26.8 -> 25.9 ms per 64 spp of C3
+#define PB_WALK_WAVES_TRI 4  // ... on the Q tree of a triangle-only scene (C3): 116-121 VGPRs, nothing spilled, 38.9 KB of LDS: four blocks per CU (round 5: 26.8 -> 25.9 ms per 64 spp of C3; round 6, measured and not kept: the entry node tested inside the step turn needs ~150 registers = three blocks, which costs what it saves)
 #endif
 constexpr uint32_t walk_blocks_per_cu(bool curves, bool wide) { return (!curves && wide) ? PB_WALK_WAVES_TRI : PB_WALK_WAVES; }
 template <bool STATS, bool CURVES, bool WIDE = false>

@@ -281,6 +281,7 @@ extern "C" int pbrhip_scene_replicate(const pbrhip_scene* src, int device, pbrhi
     if (int r = copy_buf(s->d_heads, device, src->d_heads, src->device)) return r;
     if (int r = copy_buf(s->d_lrecs, device, src->d_lrecs, src->device)) return r;
     if (int r = copy_buf(s->d_light_boxes, device, src->d_light_boxes, src->device)) return r;
+    if (int r = copy_buf(s->d_sss_entries, device, src->d_sss_entries, src->device)) return r;
     HIPCHK(hipDeviceSynchronize());
     DScene& dd = s->dscene;
     dd = src->dscene;
@@ -289,6 +290,7 @@ extern "C" int pbrhip_scene_replicate(const pbrhip_scene* src, int device, pbrhi
     dd.q_hitcode = src->dscene.wide ? s->d_qhit.p : nullptr;
     dd.materials = s->d_materials.p, dd.light_cdf = s->d_light_cdf.p, dd.light_heads = s->d_heads.p;
     dd.lprim_cdf = s->d_lprim_cdf.p, dd.lrecs = s->d_lrecs.p, dd.light_boxes = s->d_light_boxes.p;
+    dd.sss_entries = src->dscene.sss_entries ? s->d_sss_entries.p : nullptr;
     dd.tex_pixels = s->d_tex_pixels.p, dd.textures = s->d_tex_descs.p;
     s->committed = true;
     *out = guard.release();

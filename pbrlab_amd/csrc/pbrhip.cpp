@@ -786,6 +786,87 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
     qhit.resize(qpts.size(), kNone);
     if (getenv("PBRHIP_DEBUG")) fprintf(stderr, "pbrhip: commit: curve leaves of the Q tree (counted over the collapse's visits): %zu of one piece, %zu of two pieces, %zu binary leaves cut in two\n", leaves_one, leaves_pair, leaves_split);
   }
+  // Where the random walks' rays start (dscene.h::SssEntry): per instance, the cut of the Q tree around its bounds
+  std::vector<SssEntry> sss_entries;
+  if (!wide.empty() && env_u32("PBRHIP_SSS_ENTRY", 1u) != 0u) {  // (whatever the materials are now: pbrhip_scene_update_* can switch subsurface on later)
+    const size_t ninst = s->instances.size();
+    // (every foreign reference costs each walk ray a slab test: a deeper entry is only worth so many)
+    const uint32_t max_foreign = std::min(env_u32("PBRHIP_SSS_FOREIGN", 3u), kSssMaxForeign);
+    sss_entries.assign(ninst, SssEntry{});
+    std::vector<float> ilo(3 * ninst, INFINITY), ihi(3 * ninst, -INFINITY);
+    for (uint32_t g = 0; g < np; g++)
+      for (int a = 0; a < 3; a++) {
+        float& l = ilo[3 * (size_t)prims[g].instance_id + a];
+        float& h = ihi[3 * (size_t)prims[g].instance_id + a];
+        l = std::min(l, lo[3 * (size_t)g + a]), h = std::max(h, hi[3 * (size_t)g + a]);
+      }
+    struct CutRef {
+      uint32_t ref;
+      float lo[3], hi[3];
+    };
+    for (size_t i = 0; i < ninst; i++) {
+      SssEntry& E = sss_entries[i];
+      if (!(ilo[3 * i] <= ihi[3 * i])) continue;  // (no primitive)
+      float ext = 0.f;
+      for (int a = 0; a < 3; a++) ext = std::max(ext, ihi[3 * i + a] - ilo[3 * i + a]);
+      if (!(ext > 0.f) || !std::isfinite(ext)) continue;
+      const float m1 = 1e-4f * ext, m2 = 2e-3f * ext;  // the region rays may stay in / how far beyond it a primitive's box can matter
+      float rlo[3], rhi[3], wlo[3], whi[3];
+      for (int a = 0; a < 3; a++) rlo[a] = ilo[3 * i + a] - m1, rhi[a] = ihi[3 * i + a] + m1, wlo[a] = rlo[a] - m2, whi[a] = rhi[a] + m2;
+      std::vector<CutRef> cut{{0u, {-INFINITY, -INFINITY, -INFINITY}, {INFINITY, INFINITY, INFINITY}}};
+      for (bool changed = true; changed;) {
+        changed = false;
+        for (size_t c = 0; c < cut.size() && !changed; c++) {
+          if (cut[c].ref & kLeafBit) continue;
+          const QNode& nd = wide[cut[c].ref];
+          const float org[3] = {nd.org[0], nd.org[1], nd.org[2]}, st3[3] = {nd.sx, nd.sy, nd.sz};
+          const uint32_t ql[3] = {nd.qlo_x, nd.qlo_y, nd.qlo_z}, qh[3] = {nd.qhi_x, nd.qhi_y, nd.qhi_z};
+          std::vector<CutRef> kids;
+          int nchild = 0;
+          for (int k = 0; k < 4; k++) {
+            if (nd.c[k] == kEmptyChild) continue;
+            nchild++;
+            CutRef r;
+            r.ref = nd.c[k];
+            bool meets = true;
+            for (int a = 0; a < 3; a++) {  // the box the traversal rebuilds for this child (dtrace.h::box_test4q): fma(q, s, org)
+              r.lo[a] = fmaf((float)((ql[a] >> (8 * k)) & 255u), st3[a], org[a]);
+              r.hi[a] = fmaf((float)((qh[a] >> (8 * k)) & 255u), st3[a], org[a]);
+              meets = meets && r.lo[a] <= whi[a] && r.hi[a] >= wlo[a];
+            }
+            if (meets) kids.push_back(r);
+          }
+          // descend where that drops a child (or leads to an only child), while the cut stays small
+          if (((int)kids.size() < nchild || kids.size() == 1) && cut.size() - 1 + kids.size() <= 1u + max_foreign) {
+            cut.erase(cut.begin() + (ptrdiff_t)c);
+            cut.insert(cut.end(), kids.begin(), kids.end());
+            changed = true;
+          }
+        }
+      }
+      // the entry: the inner node of the cut that shares the most volume with the instance's bounds
+      int best = -1;
+      double best_v = -1.0;
+      for (size_t c = 0; c < cut.size(); c++) {
+        if (cut[c].ref & kLeafBit) continue;
+        double v = 1.0;
+        for (int a = 0; a < 3; a++) v *= std::max(0.0, (double)std::min(cut[c].hi[a], ihi[3 * i + a]) - (double)std::max(cut[c].lo[a], ilo[3 * i + a]));
+        if (v > best_v) best_v = v, best = (int)c;
+      }
+      if (best < 0 || cut[(size_t)best].ref == 0u) continue;  // (the root, or leaves only: start at the root)
+      E.entry = cut[(size_t)best].ref;
+      for (int a = 0; a < 3; a++) E.lo[a] = rlo[a], E.hi[a] = rhi[a];
+      for (size_t c = 0; c < cut.size(); c++) {
+        if ((int)c == best) continue;
+        auto& f = E.foreign[E.nforeign++];
+        f.ref = cut[c].ref;
+        for (int a = 0; a < 3; a++) f.lo[a] = cut[c].lo[a], f.hi[a] = cut[c].hi[a];
+      }
+      if (getenv("PBRHIP_DEBUG")) fprintf(stderr, "pbrhip: commit: instance %zu: random walks start at Q node %u with %u foreign references\n", i, E.entry, E.nforeign);
+    }
+  }
+  if (sss_entries.empty()) s->d_sss_entries.release();
+  else HIPCHK(s->d_sss_entries.upload(sss_entries, st));
   if (wide.empty()) s->d_wide.release(), s->d_qhit.release();
   if (getenv("PBRHIP_DEBUG")) fprintf(stderr, "pbrhip: commit: %u binary nodes, %zu wide nodes, %zu slots, %zu triangle leaves + %zu points in the Q tree\n", num_nodes, wide.size(), (size_t)ns, qtri.size() / kTriPairWords, qpts.size());
   if (!wide.empty()) {
@@ -832,6 +913,7 @@ extern "C" int pbrhip_scene_commit(pbrhip_scene* s) {
   // light sampling works on the meshes' local positions (light-manager.h:128-136 "TODO transform"), the raytracer on the
   // transformed ones: the doomed-path pretest against the light primitives (kernels.hip::misses_all_lights) is only the
   // traversal's own test when the two coincide
+  d.sss_entries = sss_entries.empty() ? nullptr : s->d_sss_entries.p, d.num_sss_entries = (uint32_t)sss_entries.size();
   d.lights_transformed = 0;
   for (const HostLight& L : s->lights) d.lights_transformed |= s->instances[L.instance_id].identity ? 0u : 1u;
   s->committed = true;

@@ -102,6 +102,7 @@ struct pbrhip_scene {
   pb::DevBuf<pb::LightHead> d_heads;
   pb::DevBuf<pb::LightRec> d_lrecs;
   pb::DevBuf<pb::BvhNode> d_light_boxes;
+  pb::DevBuf<pb::SssEntry> d_sss_entries;  // DScene::sss_entries
   pb::DScene dscene;
   // render working set (grown on demand, reused across calls)
   pb::DevBuf<float4> rec, srec, ssrec, L, hit, sss_A, sh_e;  // path state (kernels.h::PathState): rec = 4 words of 16 B per path, srec = 2

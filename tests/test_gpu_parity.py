@@ -857,6 +857,44 @@ def test_degenerate_scenes_render_parity(pa, case):
         assert not rgba[..., :3].any()
 
 
+@pytest.mark.parametrize("foreign", ["0", "1", "3", "7"])
+def test_random_walks_start_below_the_root(pa, foreign, monkeypatch):
+    """Round 6 (dscene.h::SssEntry): the rays of a random walk start at the Q node that holds the walk's instance, with the references
+    of OTHER instances' primitives inside its bounds on their stack.  Scene: a subdivided subsurface blob whose bounds are cut by a wall
+    (a slab through the blob: a walk that meets it ends, random-walk-sss.h:371-384), which stands on the floor and touches a second,
+    diffuse blob; the cap on foreign references (PBRHIP_SSS_FOREIGN, read at commit) moves the entry up and down the tree.  Image and ray
+    counts are the oracle's whatever the entry."""
+    from pbrlab_amd import scenes
+    monkeypatch.setenv("PBRHIP_SSS_FOREIGN", foreign)
+    m = lambda **kw: dict(scenes.PRINCIPLED_DEFAULTS, kind="principled", name="m", **kw)     # noqa: E731
+    mats = [m(base_color=(0.8, 0.8, 0.8)), m(base_color=(0, 0, 0)), m(base_color=(0.9, 0.6, 0.4), subsurface=1.0, subsurface_radius=(0.5, 0.3, 0.2), subsurface_color=(0.9, 0.7, 0.5)),
+            m(base_color=(0.3, 0.5, 0.8), specular=0.6, roughness=0.2)]
+    v, f = scenes._icosphere(4)
+    quad = [[0, 1, 2], [0, 2, 3]]
+    vg, fg = [], []                                                                                          # a floor of 8 x 8 quads: the tree has something to drop
+    for i in range(8):
+        for j in range(8):
+            x0, z0 = -2 + 0.5 * i, -2 + 0.5 * j
+            fg += [[len(vg), len(vg) + 1, len(vg) + 2], [len(vg), len(vg) + 2, len(vg) + 3]]
+            vg += [[x0, -0.5, z0 + 0.5], [x0 + 0.5, -0.5, z0 + 0.5], [x0 + 0.5, -0.5, z0], [x0, -0.5, z0]]
+    spec = [("floor", vg, fg, 0),
+            ("back", [[-2, -0.5, -2], [2, -0.5, -2], [2, 2, -2], [-2, 2, -2]], quad, 0),
+            ("light", [[-0.5, 1.8, -0.5], [0.5, 1.8, -0.5], [0.5, 1.8, 0.5], [-0.5, 1.8, 0.5]], quad, 1),
+            ("blob", v * 0.5 + np.array([0.9, 0.0, 0.9]), f, 2),                                            # rests on the floor (y = -0.5)
+            ("wall", [[1.05, -0.5, 0.5], [1.05, -0.5, 1.3], [1.05, 0.4, 1.3], [1.05, 0.4, 0.5]], quad, 3),  # a small wall that cuts through the blob
+            ("other", v * 0.3 + np.array([0.15, -0.2, 1.0]), f, 3)]                                         # touches the blob's bounds
+    desc = _mini_scene(spec, mats)
+    so = O.oracle_scene_from_desc(desc)
+    sg = pa.scene_from_desc(desc)
+    rgba, cnt, ost = so.render(64, 48, 6, threads=8, math_mode=O.MATH_DEVICE)
+    for tail in (0xFFFFFFFF, 0):
+        layer = pa.RenderLayer()
+        ok, st = pa.Render(sg, 64, 48, 6, layer=layer, flags=pa.api.RENDER_STATS, tail_paths=tail)
+        assert np.array_equal(layer.count, cnt) and layer.rgba.tobytes() == rgba.tobytes(), (foreign, tail)
+        assert (st["closest_rays"] + st["tail_closest_rays"] + st["pruned_rays"], st["shadow_rays"] + st["tail_shadow_rays"]) == (ost["closest_rays"], ost["shadow_rays"])
+    assert rgba[..., :3].any()
+
+
 @pytest.mark.parametrize("nlight,nshapes", [(1, 1), (2, 1), (8, 1), (9, 1), (40, 1), (16, 8), (9, 9), (27, 9)])
 def test_doomed_path_pruning_around_the_light_limits(pa, nlight, nshapes):
     """Paths whose next Russian roulette is known to fail are ended in shading when their ray cannot reach a light: with <= 8
