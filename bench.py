@@ -161,11 +161,11 @@ def csrc_hash():
 
 
 def pmc_record(workload, spp, world, kernel):
-    """Counters cannot be read live, so they come from the committed PMC passes of this round (profiles/r5_<workload>_pmc.json,
+    """Counters cannot be read live, so they come from the committed PMC passes of this round (profiles/r6_<workload>_pmc.json,
     written by scripts/profile_round.py: FETCH_SIZE, WRITE_SIZE and SQ counters in separate --pmc passes over one render of
     the same workload, per kernel).  They are only used when that file was collected on the very kernel sources that are
     running (csrc_hash) and on the same configuration; otherwise the counter-based fields are null."""
-    path = os.path.join(ROOT, "profiles", f"r5_{workload}_pmc.json")
+    path = os.path.join(ROOT, "profiles", f"r6_{workload}_pmc.json")
     if world != 1 or not os.path.exists(path):
         return None, "no PMC record for this configuration"
     rec = json.load(open(path))
@@ -187,7 +187,7 @@ def pmc_live(workload, spp, kernel, budget_s):
     """The counters of `kernel` measured by THIS run: rocprofv3 --pmc passes (counters only: no trace flag next to --pmc, one
     pass per counter group as MI355X_MICROARCH.md prescribes; FETCH_SIZE / WRITE_SIZE apart) over one render of the workload as
     one path group in child processes (scripts/render_once.py: the program itself after `--`), after the timed region.
-    Returns (record like profiles/r5_<workload>_pmc.json's kernel entry, note) or (None, why) -- the caller then falls back
+    Returns (record like profiles/r6_<workload>_pmc.json's kernel entry, note) or (None, why) -- the caller then falls back
     to the committed record."""
     import collections
     import csv

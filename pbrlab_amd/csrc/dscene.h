@@ -87,6 +87,9 @@ constexpr uint32_t kCurvePairBit = 4u;
 #ifndef PB_CURVE_RECORDS
 #define PB_CURVE_RECORDS 1
 #endif
+#ifndef PB_CURVE_TWO
+#define PB_CURVE_TWO 1  // curve records: 1 = both pieces of a leaf in ONE traversal turn (88-91 registers: five blocks per CU), 0 = one piece per turn (six blocks per CU)
+#endif
 struct alignas(16) QNode {
   float org[3], sx;
   float sy, sz;

@@ -31,7 +31,7 @@ constexpr uint32_t kPvGuide = PB_GUIDE;   // a grab takes 1 / (kPvGuide x waves)
 #endif
 constexpr int kPvLdsStack = PB_LDS_STACK;  // stack entries per lane kept in LDS
 #ifndef PB_LDS_STACK_DEEP
-#define PB_LDS_STACK_DEEP (PB_CURVE_RECORDS ? 20 : 16)  // (five blocks per CU with curve records: 30.7 KB of LDS each)
+#define PB_LDS_STACK_DEEP ((PB_CURVE_RECORDS && PB_CURVE_TWO) ? 20 : 16)  // (five blocks per CU when both pieces of a curve record are tested in one turn: 30.7 KB of LDS each)
 #endif
 // ... and for the Q tree of scenes with curves (hair: trees 14-16 levels deep, up to three entries per level): a wave whose
 // lanes are on both sides of the LDS / spill boundary runs both push paths every node turn
@@ -58,6 +58,7 @@ constexpr int kPvRefillIdleCurves = PB_REFILL_CURVES;  // the same for scenes wi
 #ifndef PB_W_TRI
 #define PB_W_TRI 2
 #endif
+constexpr uint32_t kRemSecond = 8u;  // rem bit: the record's second piece is next
 #ifndef PB_W_CURVE
 #define PB_W_CURVE 2  // (round 3, Q tree: 1 -> 216.6 ms per C4 frame, 2 -> 213.5; together with the refill at 24 idle lanes 210.2)
 #endif
@@ -463,36 +464,34 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
           } else {
             advance = true;  // leaf done: pop
           }
-        } else if (PB_CURVE_RECORDS && WIDE && CURVES && mine && is_curve) {
+        } else if (PB_CURVE_RECORDS && PB_CURVE_TWO && WIDE && CURVES && mine && is_curve) {
           // A curve leaf of the Q tree is a RECORD (round 6, dscene.h): the end points a0 a1 (b0 b1) of its one or two pieces in D0, D1
-          // (D2, D3w), both tested in this ONE turn (rem & kCurvePairBit: a second piece; the pieces' indices in their cubics are the low
-          // bits of cur and of rem).  Piece by piece the operations, their order and the accept rule are those of two one-piece turns:
-          // the same bits.
+          // (D2, D3w) (rem & kCurvePairBit: a second piece; the pieces' indices in their cubics are the low bits of cur and of rem).
+          // PB_CURVE_TWO: both pieces in this one turn (needs 88-91 registers: five blocks per CU); otherwise one piece per turn -- the
+          // second piece's turn needs no fetch, the record is in the lane's registers (rem & kRemSecond) -- at the register budget of
+          // rounds 3-5 (six blocks per CU).  Piece by piece the operations, their order and the accept rule are the same: the same bits.
           const bool two = (rem & kCurvePairBit) != 0u;
-          if (STATS) steps += two ? 2u : 1u, (any_ray ? st.acurves : st.curves) += two ? 2u : 1u;
-          // (the frame is read again for the second piece instead of being held across the first piece's test: twenty LDS reads
-          // instead of ten, but no register more than a one-piece turn needs)
-          auto read_frame = [&]() {
-            RayFrame f;
-            f.dn = V3(frame[0], frame[stride], frame[2 * stride]), f.bx = V3(frame[3 * stride], frame[4 * stride], frame[5 * stride]);
-            f.by = V3(frame[6 * stride], frame[7 * stride], frame[8 * stride]), f.inv_len = frame[9 * stride];
-            return f;
-          };
+          RayFrame f;
+          f.dn = V3(frame[0], frame[stride], frame[2 * stride]), f.bx = V3(frame[3 * stride], frame[4 * stride], frame[5 * stride]);
+          f.by = V3(frame[6 * stride], frame[7 * stride], frame[8 * stride]), f.inv_len = frame[9 * stride];
           const V3 i3(inv4.x, inv4.y, inv4.z);
           const uint32_t pt = (cur & ~3u) - sc.q_pt0;  // point index of the first piece
           bool occ = false;
+          const bool second = false;
+          if (STATS) steps++, (any_ray ? st.acurves : st.curves)++;
           {
-            const RayFrame f = read_frame();
+            // (one piece per turn: the piece of this turn is in D0, D1 -- the second piece was moved there when the first was done)
             const V3 pa = segment_project(D0, o, f), pb = segment_project(D1, o, f);
             float t, u, v;
-            bool ok = segment_core(D0, D1, pa, pb, cur & 3u, o, f.inv_len, i3, tmin, hit.t, t, u, v);
-            const uint32_t code = kQPointHit | pt;
+            bool ok = segment_core(D0, D1, pa, pb, second ? (rem & 3u) : (cur & 3u), o, f.inv_len, i3, tmin, hit.t, t, u, v);
+            const uint32_t code = kQPointHit | (pt + (second ? 2u : 0u));
             if (ok && !any_ray && t == hit.t && hit.slot != kNone) ok = q_gid(sc, code) < q_gid(sc, hit.slot);
             if (ok) hit.t = t, hit.u = u, hit.v = v, hit.slot = code;
             occ = any_ray && ok;
           }
+#if PB_CURVE_TWO
           if (two && !occ) {
-            const RayFrame f = read_frame();
+            if (STATS) steps++, (any_ray ? st.acurves : st.curves)++;
             const V3 pa = segment_project(D2, o, f), pb = segment_project(D3w, o, f);
             float t, u, v;
             bool ok = segment_core(D2, D3w, pa, pb, rem & 3u, o, f.inv_len, i3, tmin, hit.t, t, u, v);
@@ -501,9 +500,13 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
             if (ok) hit.t = t, hit.u = u, hit.v = v, hit.slot = code;
             occ = any_ray && ok;
           }
+#endif
           if (occ) {
             state = kStDoneOccluded;
             if (STATS) st.ahist[steps <= 16u ? 0 : (28 - __clz(steps - 1u) > 7 ? 7 : 28 - __clz(steps - 1u))]++, st.amax_steps = steps > st.amax_steps ? steps : st.amax_steps;
+          } else if (!PB_CURVE_TWO && two && !second) {
+            rem |= kRemSecond;  // the second piece: next curve turn, nothing to fetch -- it moves to where the turn's piece is expected
+            D0 = D2, D1 = D3w;
           } else {
             advance = true;  // leaf done: pop
           }
@@ -519,12 +522,15 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
             RayFrame f;
             f.dn = V3(frame[0], frame[stride], frame[2 * stride]), f.bx = V3(frame[3 * stride], frame[4 * stride], frame[5 * stride]);
             f.by = V3(frame[6 * stride], frame[7 * stride], frame[8 * stride]), f.inv_len = frame[9 * stride];
-            ok = segment_test(D0, D1, WIDE ? ((cur - sc.q_pt0) & 3u) : __float_as_uint(D2.x), o, f, WIDE ? V3(inv4.x, inv4.y, inv4.z) : inv, tmin,
-                              hit.t, t, u, v);
+            // (a curve record of the Q tree, one piece per turn: the turn's piece is in D0, D1 -- the second piece, kRemSecond, was moved
+            // there when the first was done; the pieces' indices in their cubics are the low bits of cur and of rem)
+            const uint32_t sub = !WIDE ? __float_as_uint(D2.x) : (PB_CURVE_RECORDS ? ((rem & kRemSecond) ? (rem & 3u) : (cur & 3u)) : ((cur - sc.q_pt0) & 3u));
+            ok = segment_test(D0, D1, sub, o, f, WIDE ? V3(inv4.x, inv4.y, inv4.z) : inv, tmin, hit.t, t, u, v);
           }
           // the hit code: slot + routing bits (dscene.h); Q tree: a triangle slot carries its code, a curve hit is held as its point
+          const uint32_t qpt = PB_CURVE_RECORDS ? (cur & ~3u) - sc.q_pt0 + ((rem & kRemSecond) ? 2u : 0u) : cur - sc.q_pt0;
           const uint32_t code = !WIDE ? ((cur - slot0) | __float_as_uint(D2.w))
-                                      : ((CURVES && is_curve) ? (kQPointHit | (cur - sc.q_pt0)) : __float_as_uint(D2.w));
+                                      : ((CURVES && is_curve) ? (kQPointHit | qpt) : __float_as_uint(D2.w));
           if (ok && !any_ray && t == hit.t && hit.slot != kNone)
             ok = WIDE ? q_gid(sc, code) < q_gid(sc, hit.slot) : sc.shade[cur - slot0].gid < sc.shade[hit.slot & kHitSlotMask].gid;
           if (ok) {
@@ -533,6 +539,13 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
           if (any_ray && ok) {
             state = kStDoneOccluded;
             if (STATS) st.ahist[steps <= 16u ? 0 : (28 - __clz(steps - 1u) > 7 ? 7 : 28 - __clz(steps - 1u))]++, st.amax_steps = steps > st.amax_steps ? steps : st.amax_steps;
+          } else if (PB_CURVE_RECORDS && WIDE && CURVES && is_curve) {
+            if ((rem & (kCurvePairBit | kRemSecond)) == kCurvePairBit) {
+              rem |= kRemSecond;  // the record's second piece: next curve turn, nothing to fetch -- it moves to where the turn's piece is expected
+              D0 = D2, D1 = D3w;
+            } else {
+              advance = true;  // leaf done: pop
+            }
           } else if (rem != 0u) {  // next primitive of the same leaf
             rem--, cur += WIDE ? ((CURVES && is_curve) ? 1u : 3u) : 1u;
             need_load = true;
@@ -583,7 +596,8 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
       } else {
         // (a curve record: four words; the low bits of its address carry a piece index)
         const bool at_rec = PB_CURVE_RECORDS && CURVES && state == kStCurve;
-        const float4* g = items + (at_rec ? (cur & ~3u) : cur);
+        // (a ray that was suspended at the second piece of its record -- kRemSecond -- resumes with that piece where the turn expects it)
+        const float4* g = items + (at_rec ? (cur & ~3u) + ((!PB_CURVE_TWO && (rem & kRemSecond)) ? 2u : 0u) : cur);
         D0 = g[0], D1 = g[1];
         if (!CURVES || state != kStCurve || at_rec) D2 = g[2];
         if (!CURVES || state == kStNode || at_rec) D3w = g[3];

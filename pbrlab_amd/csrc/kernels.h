@@ -143,7 +143,7 @@ enum : uint32_t {
 #ifndef PB_TRACE_BLOCKS_WIDE_CURVES
 // round 6: with curve records -- both pieces of a leaf in one turn (PB_CURVE_RECORDS, dscene.h) -- the kernel needs 91-93 registers: five
 // waves per SIMD (at six, 36 bytes of scratch in the loop: +40 %); the one-piece-per-turn kernel of rounds 3-5 fits six
-#define PB_TRACE_BLOCKS_WIDE_CURVES (PB_CURVE_RECORDS ? 5 : 6)
+#define PB_TRACE_BLOCKS_WIDE_CURVES ((PB_CURVE_RECORDS && PB_CURVE_TWO) ? 5 : 6)
 #endif
 constexpr uint32_t kTraceBlocksPerCUWide = PB_TRACE_BLOCKS_WIDE, kTraceBlocksPerCUWideCurves = PB_TRACE_BLOCKS_WIDE_CURVES;  // the Q tree's kernels
 constexpr uint32_t kTraceBlocksPerCU = PB_TRACE_BLOCKS, kTraceBlocksPerCUCurves = PB_TRACE_BLOCKS_CURVES;

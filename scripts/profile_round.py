@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Collects the round's profile evidence for one workload on the GPU box and writes it under profiles/ (via gpurun_out/):
 
-  r5_<wl>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary of `bench.py --workload <wl> --steps 3 --warmup 1`
-  r5_<wl>_pmc.json           per kernel: FETCH_SIZE, WRITE_SIZE (HBM-side traffic, separate passes as MI355X_MICROARCH.md
+  r6_<wl>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary of `bench.py --workload <wl> --steps 3 --warmup 1`
+  r6_<wl>_pmc.json           per kernel: FETCH_SIZE, WRITE_SIZE (HBM-side traffic, separate passes as MI355X_MICROARCH.md
                              prescribes; gfx950: FETCH_SIZE counts 128-B requests as 64 B -> x2), SQ instruction / wait
                              counters and TCC hit / miss / EA read requests, over ONE render of the workload
                              (scripts/render_once.py, one path group: every launch alone on the GPU), plus csrc_hash --
@@ -70,7 +70,7 @@ def main():
     json.dump({"csrc_hash": bench.csrc_hash(), "workload": wl, "spp": w["spp"], "kernels": kernels,
                "source": f"scripts/profile_round.py {wl}: rocprofv3 --pmc passes {[p.split()[0] for p in PASSES]} over one 1920x1080 x "
                          f"{w['spp']} spp render (one path group); FETCH_SIZE / WRITE_SIZE in KiB, FETCH_SIZE x2 on gfx950"},
-              open(os.path.join(out, f"r5_{wl}_pmc.json"), "w"), indent=1, sort_keys=True)
+              open(os.path.join(out, f"r6_{wl}_pmc.json"), "w"), indent=1, sort_keys=True)
     for k, rec in kernels.items():
         print(f"{k[:44]:44s} n={rec['dispatches']:4d} hbm/launch {rec['hbm_bytes_per_dispatch_fetch_x2'] / 1e9:7.3f} GB  valu {rec.get('SQ_INSTS_VALU', 0):.3g} "
               f"lanes {rec.get('lanes_per_valu', 0):.1f}  tcc hit {rec.get('tcc_hit_rate', 0):.3f}")
@@ -82,9 +82,9 @@ def main():
         r = subprocess.run(cmd, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp", capture_output=True, text=True, timeout=1500)
         print("kernel-trace: rc", r.returncode, r.stdout.strip().splitlines()[-1][:300] if r.stdout.strip() else r.stderr[-500:])
         for f in glob.glob(d + "/**/*kernel_stats.csv", recursive=True):
-            shutil.copy(f, os.path.join(out, f"r5_{wl}_kernel_stats.csv"))
+            shutil.copy(f, os.path.join(out, f"r6_{wl}_kernel_stats.csv"))
         if r.stdout.strip():
-            open(os.path.join(out, f"r5_{wl}_bench_under_rocprof.json"), "w").write(r.stdout.strip().splitlines()[-1] + "\n")
+            open(os.path.join(out, f"r6_{wl}_bench_under_rocprof.json"), "w").write(r.stdout.strip().splitlines()[-1] + "\n")
         shutil.rmtree(d, ignore_errors=True)
     shutil.rmtree(tmp, ignore_errors=True)
 
