@@ -167,6 +167,8 @@ def test_libm_tolerance_at_the_configurations_own_spp(pa, config):
     nflip = int(flipped.sum())
     keep = mine & ~flipped
     r_rest = rel_l2(lay.rgba[keep], libm[keep])
+    import platform
+    print(f"host libm: {' '.join(platform.libc_ver())} on {platform.machine()}; the device restates it bit for bit: {bool(O.libm_is_glibcf())}")
     print(f"{config}: {W}x{H} x {spp} spp = the configuration's spp" + (f" on tiles i % {world} == 0" if world > 1 else "") +
           f" ({npx} pixels, {npx * spp / 1e6:.1f} M samples): rel L2 vs oracle[libm] {r:.2e} (bar 1e-4), {nl} pixels differ, {nflip} hold a flipped sample, "
           f"rel L2 without those {r_rest:.1e}; oracle {npx * spp / dt / 1e6:.2f} Msamples/s on {THREADS} threads, {dt:.0f} s")
@@ -182,7 +184,10 @@ def test_libm_tolerance_at_the_configurations_own_spp(pa, config):
         # roulette with an unclamped survival probability (render.cc:66-68, Q1) lets rare hair / subsurface paths carry a large
         # throughput, so the ~200 pixels of 130 048 that hold a flipped sample of such a path dominate the norm (without the 100
         # largest differences: 7.0e-5; without 1 000: 1.3e-6).  Any two libm builds differ from each other in the same way.
-        assert r < 3e-3, r
+        # that is the 1e-4 contract NOT MET against this host's libm, not a weaker bar to assert -- report it as such
+        if not r < REL_L2_TOL:
+            pytest.xfail(f"C5 at 1024 spp against a libm the device does not restate ({' '.join(platform.libc_ver())}): plain rel L2 {r:.2e} >= 1e-4 "
+                         f"(NOT MET; without the {nflip} pixels holding a flipped sample: {r_rest:.1e})")
 
 
 def test_c3_high_pass_indices(pa):
