@@ -22,6 +22,11 @@ namespace pb {
 #define PB_BATCH 512
 #endif
 constexpr uint32_t kPvBatch = PB_BATCH;   // rays grabbed per atomicAdd, at most
+#ifndef PB_BATCH_HEADS
+#define PB_BATCH_HEADS 256  // (A/B, eight heads: 64 / 128 / 256 rays: eighth of C2 7.86 / 7.86 / 7.78 ms, frame 46.5 / 45.4 / 44.8; one head with 512: 8.49 / 44.8 -- profiles/README.md)
+#endif
+constexpr uint32_t kPvBatchHeads = PB_BATCH_HEADS;  // ... when the queue has several heads (k_trace)
+constexpr uint32_t kPvHeadStride = 64;  // == kernels.h::kHeadStride: words between two heads (a cache line of its own each)
 #ifndef PB_GUIDE
 #define PB_GUIDE 2
 #endif
@@ -106,11 +111,17 @@ constexpr uint32_t kSuspRecWords = 72;  // == kernels.h::kSuspWords: hit (4 word
 // curve pieces as chains of 16-byte points) instead of the binary one -- half the dependent fetches per ray and half the bytes
 // per fetch; hit children are visited nearest first (sorted by entry distance), like the binary tree's.  `cur` then counts
 // 16-byte words of sc.wide instead of 64-byte items.
-template <int MODE, bool STATS, bool CURVES, bool WIDE, typename Sink>
+template <int MODE, bool STATS, bool CURVES, bool WIDE, uint32_t NHEADS = 1u, typename Sink>
 __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t* head, Sink& sink, uint32_t* stk_base,
                                          uint32_t stride, uint32_t* spill, uint32_t spill_stride, TravStats& st,
                                          uint32_t* overflow, float* frame = nullptr, const float4* top = nullptr,
                                          uint32_t ntop = 0) {
+  constexpr uint32_t nheads = NHEADS;
+  // NHEADS (round 6): the queue [0, n) is cut into nheads equal ranges, head[h] counts inside range h; a wave draws from the head of its
+  // block (block b: head b % nheads -- blocks go round the XCDs) and, when that range is dealt, from the next ones.  Why: ONE counter
+  // sustains ~88 atomics per microsecond, which is what made the batches 512 rays -- ~0.4 ms of work for one wave -- and the waves that
+  // drew their last batch late found the queue empty up to 0.3 ms after the first wave had (per-wave timelines: profiles/README.md);
+  // eight counters take eight times the rate, so the batches can be a quarter of that.
   // top / ntop: LDS copy of nodes 0 .. ntop-1 (the breadth-first top of the tree, 64 bytes each), or none
   // frame (CURVES): 10 words per lane in LDS (frame[k * stride]), the ray's RayFrame, written when the ray is fetched
   constexpr int kLds = pv_lds_stack<CURVES, WIDE>();  // stack entries of this lane that live in LDS
@@ -124,10 +135,12 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
   // being walked serially by a few (a 20 k-ray launch took 1.5 ms with fixed 512-ray batches).
   uint32_t batch_cur = 0, batch_end = 0;
   const uint32_t waves_total = gridDim.x * (blockDim.x >> 6);
+  uint32_t hsel = nheads > 1u ? blockIdx.x % nheads : 0u, heads_left = nheads;  // the head this wave draws from now; heads not yet found empty
+  const uint32_t kBatchCap = nheads > 1u ? kPvBatchHeads : kPvBatch;
   uint32_t batch = n / waves_total;
   if (batch >= 64u) {
     batch = (kPvGuide ? n / (waves_total * kPvGuide) : batch) & ~63u;
-    batch = batch > kPvBatch ? kPvBatch : (batch < 64u ? 64u : batch);
+    batch = batch > kBatchCap ? kBatchCap : (batch < 64u ? 64u : batch);
   } else {
     // fewer rays than resident lanes: spread them thin (a few lanes per wave, every SIMD busy).  A launch like this is
     // bound by the latency of its longest ray, and a ray advances fastest when its wave has no other phase to vote for
@@ -202,18 +215,30 @@ __device__ __forceinline__ void trace_pv(const DScene& sc, uint32_t n, uint32_t*
       const unsigned long long t_refill = STATS ? wall_clock64() : 0ull;
       did = 3;
       if (!exhausted && batch_cur == batch_end) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(head, batch);
-        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)base, 0));
-        batch_cur = base < n ? base : n;
-        batch_end = (base + batch) < n ? (base + batch) : n;
-        if (batch_cur >= n) exhausted = true, st.t_exhausted = wall_clock64();
-        // guided self-scheduling: the batches shrink as the queue empties (down to one wave-full), so that the waves run
-        // dry at about the same time.  With fixed 512-ray batches the last batch of the unlucky waves was ~0.35 ms of a
-        // 16 M-ray launch during which the rest of the chip idled (one wave traces a ray in ~0.8 us).
-        if (kPvGuide && batch >= 64u) {
-          uint32_t nb = ((n - batch_end) / (waves_total * kPvGuide)) & ~63u;
-          batch = nb > kPvBatch ? kPvBatch : (nb < 64u ? 64u : nb);
+        for (;;) {  // (wave-uniform: the next head when this one's range is dealt)
+          // range of head hsel: [hsel * nq, + nq) -- the last one takes the remainder; the head counts inside its range
+          const uint32_t nq = n / nheads, lo_h = hsel * nq, len_h = hsel + 1u == nheads ? n - lo_h : nq;
+          uint32_t base = 0;
+          if (lane == 0) base = atomicAdd(head + hsel * kPvHeadStride, batch);
+          base = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)base, 0));
+          if (base < len_h) {  // (a head that has overshot its range keeps growing by what later visitors add: far below 2^32)
+            const uint32_t end = (base + batch) < len_h ? base + batch : len_h;
+            batch_cur = lo_h + base, batch_end = lo_h + end;
+            // guided self-scheduling: the batches shrink as the range empties (down to one wave-full), so that the waves run
+            // dry at about the same time
+            if (kPvGuide && batch >= 64u) {
+              const uint32_t nb = ((len_h - end) / ((waves_total / nheads + 1u) * kPvGuide)) & ~63u;
+              batch = nb > kBatchCap ? kBatchCap : (nb < 64u ? 64u : nb);
+            }
+            break;
+          }
+          if (--heads_left == 0u) {
+            exhausted = true, st.t_exhausted = wall_clock64();
+            batch_cur = batch_end = n;
+            break;
+          }
+          hsel = hsel + 1u == nheads ? 0u : hsel + 1u;
+          batch = 64u;  // (a guest in another range: small bites)
         }
       }
       bool fresh = false;  // the lane has a new ray in (o, d, tmin, hit.t)

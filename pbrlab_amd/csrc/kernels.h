@@ -41,6 +41,7 @@ struct PathState {
   float4* sh_e;
   uint32_t* spill;               // traversal-stack spill area: (kStackDepth - LDS part) x resident threads
   uint32_t* counts;              // kCnt*
+  uint32_t* heads;               // the kTraceHeads heads of k_trace's ray queue, kHeadStride words apart (reset by k_advance)
   unsigned long long* stats;     // kStat*; null unless the render collects statistics
   unsigned long long* wave_log;  // debugging (PBRHIP_WAVE_LOG): per k_trace launch and wave: start, end (100 MHz clock), rays, loop turns
   uint32_t wave_log_launch;      // index of this launch in wave_log
@@ -159,6 +160,11 @@ constexpr size_t kSuspRecords = (size_t)kTraceGridCap * 256;  // suspend records
 static_assert((size_t)(kStackDepth - kSimpleLdsStack) * 4096 * 256 <= kSpillWords, "spill area of the one-ray-per-lane hook grids (grid_for(n, 4096))");
 constexpr uint32_t kShadeGridCap = 256 * 8;
 constexpr int kMaxGroups = 8;
+#ifndef PB_TRACE_HEADS
+#define PB_TRACE_HEADS 8
+#endif
+constexpr uint32_t kTraceHeads = PB_TRACE_HEADS;  // heads of k_trace's ray queue: one per XCD (block b draws from head b % 8 first)
+constexpr uint32_t kHeadStride = 64;  // words between two heads: each in a 256-byte block of its own (atomics on one cache line serialise: eight heads in ONE line were twice as slow as one head)
 constexpr uint32_t kRingSlots = 16;  // iterations of one group the host may have enqueued and not yet heard of
 constexpr uint32_t kWaveLogWaves = 8192, kWaveLogLaunches = 64;  // PBRHIP_WAVE_LOG buffer: launches x waves x 4 words  // concurrent path groups (one HIP stream each)
 
@@ -180,7 +186,7 @@ void launch_sss_step(hipStream_t s, const PathState& P, const DScene& sc, uint32
 void launch_sss_walk(hipStream_t s, const PathState& P, const DScene& sc, uint32_t n_upper, uint64_t rng_inc, bool stats);
 void launch_accumulate(hipStream_t s, const PathState& P, const uint32_t* pix_index, uint32_t npix, uint32_t npass,
                        float* rgba, uint32_t* count);
-void launch_advance(hipStream_t s, const PathState& P, uint32_t* ring_slot, uint32_t stamp);  // ring_slot: 4 words of device-visible host memory (or null)
+void launch_advance(hipStream_t s, const PathState& P, uint32_t* ring_slot, uint32_t stamp);  // (also resets P.heads)  // ring_slot: 4 words of device-visible host memory (or null)
 void launch_texture_fetch(hipStream_t s, const DScene& sc, uint32_t tex_id, const float* uv, uint32_t n, float* rgb);  // test hook: Texture::FetchFloat3
 void launch_leaf_eval(hipStream_t s, uint32_t op, const float* in, uint32_t n, uint32_t in_words, float* out, uint32_t out_words);  // test hook: the device's leaf functions
 // RenderLayer shard of a pixel list: shard = npix x rgba (16 B) followed by npix x count (4 B); 16-byte aligned

@@ -291,7 +291,7 @@ __global__ __launch_bounds__(kBlock, trace_blocks_per_cu(CURVES, WIDE) - (FIRST 
   const unsigned long long t_start = P.wave_log ? wall_clock64() : 0ull;
   uint32_t wave_idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * kBlock + threadIdx.x) >> 6));
   asm volatile("" : "+s"(wave_idx));  // (a scalar, computed before the loop: threadIdx.x does not stay alive across it)
-  trace_pv<FIRST ? 0 : 2, STATS, CURVES, WIDE>(sc, n_closest + (FIRST ? 0u : n_shadow), &P.counts[kCntHead], sink, stk + threadIdx.x, kBlock,
+  trace_pv<FIRST ? 0 : 2, STATS, CURVES, WIDE, kTraceHeads>(sc, n_closest + (FIRST ? 0u : n_shadow), P.heads, sink, stk + threadIdx.x, kBlock,
                              P.spill + blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, st, &overflow,
                              CURVES ? frm + threadIdx.x : nullptr, top, ntop);
   if (overflow) P.counts[kCntOverflow] = 1u;
@@ -1734,7 +1734,7 @@ __global__ __launch_bounds__(kBlock) void k_hook_quad(DScene sc, const float4* _
 
 // queue flip between iterations: counts[In] = counts[Out]; the per-iteration counters restart at 0
 // ... and the host is told (ring: four words of pinned host memory, the stamp last): it sizes the launches after the next from these
-__global__ void k_advance(uint32_t* counts, uint32_t* ring, uint32_t stamp) {
+__global__ void k_advance(uint32_t* counts, uint32_t* heads, uint32_t* ring, uint32_t stamp) {
   if (threadIdx.x == 0) {
     counts[kCntIn] = counts[kCntOut];
     counts[kCntShadowIn] = counts[kCntShadow];
@@ -1745,6 +1745,7 @@ __global__ void k_advance(uint32_t* counts, uint32_t* ring, uint32_t stamp) {
     }
     counts[kCntOut] = 0, counts[kCntPrincipled] = 0, counts[kCntHair] = 0, counts[kCntSss] = 0, counts[kCntShadow] = 0;
     counts[kCntHead] = 0, counts[kCntWalkHead] = 0;
+    for (uint32_t h = 0; h < kTraceHeads; h++) heads[h * kHeadStride] = 0;
   }
 }
 
@@ -1913,7 +1914,7 @@ void launch_layer_unpack_add(hipStream_t s, const uint32_t* pix, uint32_t npix, 
                      reinterpret_cast<const float4*>(shard), reinterpret_cast<const uint32_t*>(shard + 4 * (size_t)npix),
                      reinterpret_cast<float4*>(rgba), count);
 }
-void launch_advance(hipStream_t s, const PathState& P, uint32_t* ring_slot, uint32_t stamp) { hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, s, P.counts, ring_slot, stamp); }
+void launch_advance(hipStream_t s, const PathState& P, uint32_t* ring_slot, uint32_t stamp) { hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, s, P.counts, P.heads, ring_slot, stamp); }
 // counts: kCntNum zeroed words (queue head + overflow flag); spill: traversal-stack spill area
 void launch_hook_closest(hipStream_t s, const DScene& sc, const float4* rays, uint32_t n, HookHit* out, uint32_t* counts,
                          uint32_t* spill, bool simple) {

@@ -1320,6 +1320,7 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
     P.sh_d.base = s->srec.p, P.sh_c.base = s->srec.p + 1, P.sh_e = s->sh_e.p;
     P.counts = s->counts.p, P.stats = want_stats ? s->stats.p : nullptr, P.spill = s->spill.p;
     P.first = 0u, P.cam_org[0] = P.cam_org[1] = P.cam_org[2] = 0.f;
+    P.heads = nullptr;
     P.susp_turns = 0u, P.susp_out = nullptr, P.susp_in = nullptr, P.shadow_first = 0u;
     P.no_medium = s->has_sss ? 0u : 1u;
     P.wave_log = nullptr, P.wave_log_launch = 0;
@@ -1363,6 +1364,7 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
     // exact counts (an iteration enqueued ahead would run as a full wavefront iteration on what k_tail finishes faster)
     const double pipe_stop = getenv("PBRHIP_PIPE_STOP") ? atof(getenv("PBRHIP_PIPE_STOP")) : 2.0;
     const uint32_t shadow_first = env_u32("PBRHIP_SHADOW_FIRST", 1u);
+    HIPCHK(s->heads.reserve((size_t)kMaxGroups * kTraceHeads * kHeadStride));
     HIPCHK(s->susp.reserve((size_t)std::max(1u, max_lanes) * 2u * kSuspRecords * kSuspWords));  // (264 MB per group in flight)
     struct Group {
       PathState P;
@@ -1493,6 +1495,8 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
         gr.tm.stream = gst;
         gr.P.counts = s->counts.p + lane * kCntNum;
         gr.P.spill = s->spill.p + (size_t)lane * kSpillWords;
+        gr.P.heads = s->heads.p + (size_t)lane * kTraceHeads * kHeadStride;
+        HIPCHK(hipMemsetAsync(gr.P.heads, 0, sizeof(uint32_t) * kTraceHeads * kHeadStride, gst));
         uint32_t* hc = s->h_counts + lane * kCntNum;
         memset(hc, 0, sizeof(uint32_t) * kCntNum);
         hc[kCntIn] = gr.n0;

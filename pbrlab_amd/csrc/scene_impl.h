@@ -121,6 +121,7 @@ struct pbrhip_scene {
   uint32_t* h_ring = nullptr;              // pinned, kMaxGroups x kRingSlots x 4
   uint32_t* d_ring = nullptr;              // the same memory as the device addresses it
   uint32_t ring_stamp = 0;                 // last stamp handed out
+  pb::DevBuf<uint32_t> heads;              // the heads of k_trace's ray queue: lanes x kTraceHeads x kHeadStride words
   pb::DevBuf<uint32_t> susp;               // suspend records of the resumable rays: lanes x 2 (written / read by alternate launches) x cap x kSuspWords
   std::vector<hipStream_t> group_streams;  // streams of path groups 1.. (group 0 uses `stream`)
   // pixel list cache key (ensure_pixels)

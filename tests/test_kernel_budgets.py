@@ -30,7 +30,7 @@ BUDGETS = {
     "k_sss_walk<false, false, true>": (128, 0),
     "k_sss_walk<false, false, false>": (128, 0),
     "k_sss_walk<false, true, false>": (128, 0),
-    "k_sss_walk<false, true, true>": (128, 0),
+    "k_sss_walk<false, true, true>": (168, 0),       # scenes with curves: three waves per SIMD (PB_WALK_WAVES)
     "k_shade_principled<0>": (128, 0),           # no medium, no texture (C2, C4): four waves (five spill: 10.5 -> 12.7 ms on C2)
     "k_shade_principled<1>": (128, 0),           # media, no texture (C3, C5): the medium's coefficients come from the material record
     "k_shade_principled<2>": (168, 16),          # textured materials: ParamToBsdf and the medium per hit
