@@ -109,9 +109,18 @@ constexpr uint32_t kRResume = kQSssBit, kRResumeFirst = kRShadow;
 constexpr uint32_t kRHold = kQDoomed, kRHoldDoomed = kRShadow;
 constexpr uint64_t kMaxPathsInFlight = (1ull << 28) - 1;
 enum : uint32_t { kShNormal = 0u, kShSssEntry = 1u, kShSssExit = 2u };
+// The counters of one path group.  Round 6: the ones the kernels hit with atomics (one per tile and queue in k_classify / k_compact, one per
+// batch in the traversal kernels) each sit in a 256-byte block of their own -- atomics on one cache line serialise (~88 per microsecond per
+// line: what the eight heads of k_trace's queue taught, dtrace_pv.h); the others share the first block.  PB_CNT_SPREAD=0: packed, as before.
+#ifndef PB_CNT_SPREAD
+#define PB_CNT_SPREAD 1
+#endif
 enum : uint32_t {
-  kCntIn = 0, kCntOut, kCntPrincipled, kCntHair, kCntSss, kCntShadow, kCntOverflow, kCntHead, kCntShadowIn, kCntWalkHead,
-  kCntNum = 12
+  kCntIn = 0, kCntOverflow = 1, kCntShadowIn = 2,
+  kCntStride = PB_CNT_SPREAD ? 64 : 1, kCntHot0 = PB_CNT_SPREAD ? 64 : 3,
+  kCntOut = kCntHot0, kCntPrincipled = kCntHot0 + kCntStride, kCntHair = kCntHot0 + 2 * kCntStride, kCntSss = kCntHot0 + 3 * kCntStride,
+  kCntShadow = kCntHot0 + 4 * kCntStride, kCntHead = kCntHot0 + 5 * kCntStride, kCntWalkHead = kCntHot0 + 6 * kCntStride,
+  kCntNum = kCntHot0 + 7 * kCntStride
 };
 enum : uint32_t {
   kStatClosestRays = 0, kStatClosestNodes, kStatClosestTris, kStatClosestCurves,

@@ -342,7 +342,13 @@ __global__ __launch_bounds__(kBlock) void k_trace_quad(PathState P, DScene sc) {
 // Tile sizes: k_classify gathers (its loads depend on the queue entry), more items per thread only cost it occupancy; k_compact
 // streams, and at 8 items per thread its two counters were the bottleneck (51 k atomics per launch on one word: 0.84 ms for
 // 105 M entries; 16 items -> 0.45, 32 -> 0.3).
-constexpr int kClassifyItems = 8, kCompactItems = 32;
+#ifndef PB_CLASSIFY_ITEMS
+#define PB_CLASSIFY_ITEMS 8
+#endif
+#ifndef PB_COMPACT_ITEMS
+#define PB_COMPACT_ITEMS 32
+#endif
+constexpr int kClassifyItems = PB_CLASSIFY_ITEMS, kCompactItems = PB_COMPACT_ITEMS;
 constexpr int kWavesPerBlock = kBlock / 64;
 
 template <int NQ, int kItemsPerThread>
