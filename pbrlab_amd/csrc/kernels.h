@@ -49,8 +49,10 @@ struct PathState {
   // so k_generate does not store ray_o / thr and the first trace and shading do not load them; the only per-path flag
   // ("not the first bounce", MIS weight of emission) is the same bit.
   float cam_org[3];
-  uint32_t first;   // 1: a group's first bounce; 3 (kFirstDirect): ... of a scene without hair -- every first hit takes the principled shader --:
-                    // k_classify is skipped, k_shade_principled walks the paths slot0 .. slot0 + n itself and drops misses
+  uint32_t first;   // 1: a group's first bounce
+  uint32_t direct;  // 1: k_classify is skipped -- every hit of this bounce takes the principled shader (a first bounce without hair; any bounce of
+                    // a scene without hair and media when PBRHIP_DIRECT is set) --: k_shade_principled walks the trace queue (first bounce:
+                    // the paths slot0 .. slot0 + n) itself and applies k_classify's drop rule
   // ... and the camera sample of path slot0 + j itself is a function of j (render.cc:160-171: pixel = pix_index[j % npix], pass =
   // first_pass + j / npix, two draws of the sample's own generator): the first k_trace and the first shading compute it
   // (kernels.hip::camera_sample) instead of reading a stored direction, generator state and queue entry (round 4: k_generate only
@@ -89,7 +91,6 @@ constexpr uint32_t kSuspWords = 72;  // hit (4) | cur, state | rem << 8 | sp << 
 static_assert(kStackDepth <= 64, "a suspend record holds the whole traversal stack");
 
 enum : uint32_t { kFlagNotFirst = 1u };
-constexpr uint32_t kFirstDirect = 3u;
 // queue entry = path slot | in-medium bit | "the Russian roulette at the head of this path's next shading fails" bit
 constexpr uint32_t kQSssBit = 0x80000000u, kQDoomed = 0x40000000u, kQPathMask = 0x0FFFFFFFu;
 // ... | "the path's pending shading is its FIRST bounce" (a camera ray that was suspended: its shading runs in a later iteration, next

@@ -493,7 +493,7 @@ __global__ __launch_bounds__(kBlock) void k_compact(PathState P) {
   constexpr int kItemsPerThread = kCompactItems, kTileItems = kItemsPerThread * kBlock;
   __shared__ uint32_t wcount[2][kItemsPerThread][kWavesPerBlock];
   __shared__ uint32_t base[2];
-  const uint32_t n0 = P.counts[P.first == kFirstDirect ? kCntIn : kCntPrincipled], n1 = P.counts[kCntHair], n2 = P.counts[kCntSss];
+  const uint32_t n0 = P.counts[P.direct ? kCntIn : kCntPrincipled], n1 = P.counts[kCntHair], n2 = P.counts[kCntSss];
   const uint32_t n = n0 + n1 + n2;
   const uint32_t ntiles = (n + kTileItems - 1) / kTileItems;
   uint32_t* const counters[2] = {&P.counts[kCntOut], &P.counts[kCntShadow]};
@@ -874,12 +874,14 @@ __global__ __launch_bounds__(kBlock, MODE == kShadePlain ? PB_SHADE_WAVES : (MOD
       dst[i] = reinterpret_cast<const uint32_t*>(&sc.materials[i / kWords].bsdf)[i % kWords];
   }
   if (staged || lights_staged) __syncthreads();
-  // kFirstDirect: the camera rays of a scene with one shader kind were not classified -- entry i is path slot0 + i, and the drop
-  // rule of k_classify for a first bounce (a miss, or a primitive without material that is no light) is applied here
-  const bool direct = P.first == kFirstDirect;
+  // P.direct: this bounce's rays were not classified (kernels.h) -- the entries are the trace queue's (a first bounce: entry i is path
+  // slot0 + i) and k_classify's drop rule is applied here
+  const bool direct = P.direct != 0u;
   const uint32_t n = P.counts[direct ? kCntIn : kCntPrincipled];
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-    const uint32_t e = direct ? P.slot0 + i : P.q_principled[i];
+    // (scenes with media are direct on a first bounce only: their kernel, at the edge of its register class, keeps the shorter code)
+    constexpr bool kAnyBounce = MODE != kShadeMedia;
+    const uint32_t e = direct ? ((!kAnyBounce || P.first) ? P.slot0 + i : P.q_in[i]) : P.q_principled[i];
     const uint32_t p = e & kQPathMask;
     uint32_t r = 0u;
     bool go = true;
@@ -887,13 +889,17 @@ __global__ __launch_bounds__(kBlock, MODE == kShadePlain ? PB_SHADE_WAVES : (MOD
     // path's kQDoomed / kQFirst ride along) and k_compact puts it back into the trace queue
     if (direct) {
       const uint32_t code = __float_as_uint(P.hit[p].w);
-      go = !(code == kNone || (!(code & kHitLight) && (code & kHitNoMaterial)));
-      if (code == kHitSuspended) go = false, r = kRResume | kRResumeFirst;
+      const bool doomed = kAnyBounce && (e & kQDoomed);
+      go = !(code == kNone || (!(code & kHitLight) && (doomed || (code & kHitNoMaterial))));  // (k_classify's drop rule)
+      if (code == kHitSuspended) {
+        go = false, r = kRResume | kRResumeFirst;
+        if (kAnyBounce && !P.first) r = kRResume | (e & kQDoomed) | ((e & kQFirst) ? kRResumeFirst : 0u);
+      }
     } else if (e & kQResume) {
       go = false, r = kRResume | (e & kQDoomed) | ((e & kQFirst) ? kRResumeFirst : 0u);
     }
     if (go) r = shade_principled_path<MODE>(P, sc, p, rng_inc, P.first != 0u || (e & kQFirst) != 0u, staged ? lds_bsdf : nullptr, lights_staged ? lds_lights : nullptr);
-    if (r == kRHold && (e & kQDoomed) && !direct) r |= kRHoldDoomed;  // (a held path hands its queue entry's kQDoomed back)
+    if (r == kRHold && (e & kQDoomed) && (kAnyBounce ? !P.first : !direct)) r |= kRHoldDoomed;  // (a held path hands its queue entry's kQDoomed back)
     P.q_principled[i] = p | r;
   }
 }

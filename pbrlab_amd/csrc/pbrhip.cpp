@@ -1319,7 +1319,7 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
     P.q_in = s->q[0].p, P.q_out = s->q[1].p, P.q_principled = s->q[2].p, P.q_hair = s->q[3].p, P.q_sss = s->q[4].p, P.q_shadow = s->q[5].p, P.q_shadow_in = s->q[6].p;
     P.sh_d.base = s->srec.p, P.sh_c.base = s->srec.p + 1, P.sh_e = s->sh_e.p;
     P.counts = s->counts.p, P.stats = want_stats ? s->stats.p : nullptr, P.spill = s->spill.p;
-    P.first = 0u, P.cam_org[0] = P.cam_org[1] = P.cam_org[2] = 0.f;
+    P.first = 0u, P.direct = 0u, P.cam_org[0] = P.cam_org[1] = P.cam_org[2] = 0.f;
     P.heads = nullptr;
     P.susp_turns = 0u, P.susp_out = nullptr, P.susp_in = nullptr, P.shadow_first = 0u;
     P.no_medium = s->has_sss ? 0u : 1u;
@@ -1358,6 +1358,7 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
     // pipe_depth: iterations of a group enqueued ahead of what the host has heard of (1: the old round trip per iteration).  An
     // iteration enqueued ahead sizes its launches by the last count the host saw (live paths only ever decrease: an upper bound).
     const uint32_t susp_turns = env_u32("PBRHIP_SUSP_TURNS", 24u);
+    const bool direct_all = env_u32("PBRHIP_DIRECT", 1u) != 0u;  // scenes of principled surfaces only (no hair, no media): no k_classify on any bounce (C2 frame -3 %)
     const uint32_t pipe_depth = std::min(std::max(1u, env_u32("PBRHIP_PIPE_DEPTH", 2u)), kRingSlots - 1u);
     const uint32_t pipe_depth_small = std::min(std::max(1u, env_u32("PBRHIP_PIPE_DEPTH_SMALL", 8u)), kRingSlots - 1u);  // below 256 Ki live paths (renders without k_tail)
     // close to the hand-over to k_tail (live paths <= pipe_stop x tail_paths) nothing is enqueued ahead: the hand-over is decided on
@@ -1437,10 +1438,10 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
           return PBRHIP_OK;
         }
         // a first bounce in a scene without hair needs no routing -- every hit takes the principled shader --: the shading kernel
-        // walks the group's paths itself (kFirstDirect)
+        // walks the group's paths itself (PathState::direct)
         // (media do not matter here: no path is inside one before its first shading)
-        const bool direct = gr.P.first && !s->has_hair && env_u32("PBRHIP_FIRST_DIRECT", 1u) != 0u;
-        if (direct) gr.P.first = kFirstDirect;
+        const bool direct = !s->has_hair && ((gr.P.first && env_u32("PBRHIP_FIRST_DIRECT", 1u) != 0u) || (!s->has_sss && direct_all));
+        gr.P.direct = direct ? 1u : 0u;
         if (!direct) {
           HIPCHK(gr.tm.begin(&S.ms_surface));
           launch_classify(gst, gr.P, sc, n);

@@ -16,7 +16,7 @@ rgba = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda"); cnt = torch.z
 torch.cuda.synchronize()
 REPS = int(os.environ.get("REPS", "3"))
 KEYS = ("PBRHIP_WIDE", "PBRHIP_WIDE_WALK", "PBRHIP_RAYS_PER_WAVE", "PBRHIP_GROUPS", "PBRHIP_WINDOW", "PBRHIP_BULK_DIV", "PBRHIP_GROUP_MIN_PATHS", "PBRHIP_STREAMS", "PBRHIP_TAIL_PATHS", "PBRHIP_QUAD_RAYS", "PBRHIP_PIXEL_TILE", "PBRHIP_TRACE_BLOCKS_SMALL", "PBRHIP_TRACE_BLOCKS", "PBRHIP_RETIRE",
-        "PBRHIP_SUSP_TURNS", "PBRHIP_PIPE_DEPTH", "PBRHIP_PIPE_DEPTH_SMALL", "PBRHIP_PIPE_STOP", "PBRHIP_SHADOW_FIRST", "PBRHIP_PATCH_SHUFFLE")
+        "PBRHIP_SUSP_TURNS", "PBRHIP_PIPE_DEPTH", "PBRHIP_PIPE_DEPTH_SMALL", "PBRHIP_PIPE_STOP", "PBRHIP_SHADOW_FIRST", "PBRHIP_PATCH_SHUFFLE", "PBRHIP_DIRECT")
 CONFIGS = [
     {"PBRHIP_STREAMS": "1"},
     {"PBRHIP_STREAMS": "2"},                                 # round 1's default for big chunks

@@ -188,6 +188,22 @@ def test_patch_order_does_not_matter(pa, pairs, monkeypatch):
                 assert np.array_equal(cacc, cnt) and acc.tobytes() == rgba.tobytes(), (name, shuffle, tail, world)
 
 
+def test_shading_without_classify_is_exact(pa, pairs, monkeypatch):
+    """Round 6: in a scene of principled surfaces only (no hair, no medium) k_classify is skipped on EVERY bounce -- k_shade_principled
+    reads the trace queue itself and applies the drop rule (miss, known-to-fail roulette, no material) -- PBRHIP_DIRECT (default 1).
+    With and without it the image is the oracle's; with suspended closest-hit and shadow rays (held paths) in the queue as well."""
+    desc, sg, so = pairs["ggx"]
+    rgba, cnt, _ = so.render(131, 77, 3, threads=8, math_mode=O.MATH_DEVICE)
+    for direct in ("1", "0"):
+        monkeypatch.setenv("PBRHIP_DIRECT", direct)
+        for turns in ("24", "1"):
+            monkeypatch.setenv("PBRHIP_SUSP_TURNS", turns)
+            for tail in (0xFFFFFFFF, 0):
+                layer = pa.RenderLayer()
+                pa.Render(sg, 131, 77, 3, layer=layer, tail_paths=tail)
+                assert np.array_equal(layer.count, cnt) and layer.rgba.tobytes() == rgba.tobytes(), (direct, turns, tail)
+
+
 @pytest.mark.parametrize("run", ["1", "2", "4", "8", "64"])
 @pytest.mark.parametrize("name", ["hair", "ggx"])
 def test_pass_runs_do_not_matter(pa, pairs, name, run, monkeypatch):
