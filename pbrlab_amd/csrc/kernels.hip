@@ -348,6 +348,9 @@ __global__ __launch_bounds__(kBlock) void k_trace_quad(PathState P, DScene sc) {
 #ifndef PB_COMPACT_ITEMS
 #define PB_COMPACT_ITEMS 32
 #endif
+#ifndef PB_CLASSIFY_RUNS
+#define PB_CLASSIFY_RUNS 2  // the principled hits of a tile leave it in two runs (kHitMore first); 1: in queue order
+#endif
 constexpr int kClassifyItems = PB_CLASSIFY_ITEMS, kCompactItems = PB_COMPACT_ITEMS;
 constexpr int kWavesPerBlock = kBlock / 64;
 
@@ -463,7 +466,7 @@ __global__ __launch_bounds__(kBlock) void k_classify(PathState P, DScene sc) {
     for (int j = 0; j < kItemsPerThread; j++)
       if (dest[j] == 0xFFu) {
         const uint32_t code = __float_as_uint(P.hit[p[j] & kQPathMask].w);
-        dest[j] = (code & kHitHair) ? 3u : ((code & kHitMore) ? 2u : 4u);
+        dest[j] = (code & kHitHair) ? 3u : ((PB_CLASSIFY_RUNS == 2 && (code & kHitMore)) ? 2u : 4u);
         if (code == kNone || (!(code & kHitLight) && (doomed[j] || (code & kHitNoMaterial)))) dest[j] = 0u;
         // a path whose ray was suspended (its ray goes on in the next launch) rides through the principled queue untouched: the shading
         // kernel turns its entry into a "resume" result word and k_compact re-queues it -- no atomic, no queue of its own
