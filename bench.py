@@ -549,7 +549,8 @@ def main():
 
     # `value`: the frame is complete in rank 0's HBM when a step ends (the scene was resident when it started); the copy of the
     # RenderLayer to the host -- pbrlab's layer is host memory -- is measured separately below ("host_layer", PCIe-inclusive)
-    elapsed, agg = timed(spp, args.steps, args.warmup, 0 if args.no_roofline else api.RENDER_TIMING)
+    # (HIP events around the k_trace launches only -- the roofline's kernel --: events around every launch cost the frame ~1 %)
+    elapsed, agg = timed(spp, args.steps, args.warmup, 0 if args.no_roofline else api.RENDER_TIMING_TRACE)
     diag = rank_diagnostics(dist, dev, clock["render"] / args.steps * 1e3, clock["exchange"] / args.steps * 1e3) if dist is not None else None
     check_layer(spp)
     h_elapsed, _ = timed(spp, args.steps, 1, 0, to_host=True)   # (one untimed step first: the pinned destination is touched, the copy engine is warm)

@@ -94,6 +94,8 @@ typedef struct {
 #define PBRHIP_RENDER_STATS 1u   /* count BVH nodes / primitives visited (slower; for algorithmic bytes) */
 #define PBRHIP_RENDER_TIMING 2u  /* time every kernel launch with HIP events on the render stream */
 #define PBRHIP_RENDER_NO_CLEAR 4u /* keep the layer's current contents (Render() clears: render.cc:99-100) */
+#define PBRHIP_RENDER_TIMING_TRACE 8u /* time only the k_trace launches (ms_trace_closest / n_trace_closest): a sixth of the events of
+                                         PBRHIP_RENDER_TIMING, for measurements that must not slow the frame (bench.py's timed region) */
 
 /* filled by pbrhip_render when stats != NULL */
 typedef struct {

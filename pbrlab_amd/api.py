@@ -15,7 +15,7 @@ NONE = 0xFFFFFFFF
 fp = C.POINTER(C.c_float)
 u32p = C.POINTER(C.c_uint32)
 
-RENDER_STATS, RENDER_TIMING, RENDER_NO_CLEAR = 1, 2, 4
+RENDER_STATS, RENDER_TIMING, RENDER_NO_CLEAR, RENDER_TIMING_TRACE = 1, 2, 4, 8
 
 
 class PrincipledParam(C.Structure):

@@ -1050,14 +1050,18 @@ struct Timer {
   // first / last event of every enqueued iteration of the group: the gaps between them are the time the stream sat empty
   std::vector<std::pair<size_t, size_t>> iters;
   double* idle_acc = nullptr;
+  const double* only = nullptr;  // PBRHIP_RENDER_TIMING_TRACE: only the launches that report into this accumulator are timed
+  bool skipped = false;
   void iteration_begins() {
-    if (on) iters.push_back({used, used});
+    if (on && !only) iters.push_back({used, used});
   }
   void iteration_ends() {
-    if (on && !iters.empty() && used >= 1) iters.back().second = used - 1;
+    if (on && !only && !iters.empty() && used >= 1) iters.back().second = used - 1;
   }
   hipError_t begin(double* acc) {
     if (!on) return hipSuccess;
+    skipped = only && acc != only;
+    if (skipped) return hipSuccess;
     while (events.size() < used + 2) {
       hipEvent_t e;
       if (!s->events.empty()) {
@@ -1073,7 +1077,7 @@ struct Timer {
     return hipEventRecord(events[used], stream);
   }
   hipError_t end() {
-    if (!on) return hipSuccess;
+    if (!on || skipped) return hipSuccess;
     hipError_t rc = hipEventRecord(events[used + 1], stream);
     used += 2;
     return rc;
@@ -1278,7 +1282,8 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
   if (int rc = ensure_pixels(s, d->width, d->height, d->tile_rank, world, d->shard_block)) return rc;
   const uint32_t npix = s->pk_npix;
   const bool want_stats = (d->flags & PBRHIP_RENDER_STATS) != 0;
-  const bool want_timing = (d->flags & PBRHIP_RENDER_TIMING) != 0;
+  const bool trace_timing_only = (d->flags & PBRHIP_RENDER_TIMING) == 0 && (d->flags & PBRHIP_RENDER_TIMING_TRACE) != 0;
+  const bool want_timing = (d->flags & (PBRHIP_RENDER_TIMING | PBRHIP_RENDER_TIMING_TRACE)) != 0;
   uint32_t done = 0;  // passes accumulated into the layer
   if (npix > 0 && d->num_sample > 0) {
     // default: as many paths in flight as 60 % of the free HBM holds (288 GB: a whole 1080p x 64 spp frame,
@@ -1398,6 +1403,7 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
         gr.P.pass_run = pass_run_for(gr.npass, sc.num_curves != 0);
         gr.P.shadow_first = shadow_first, gr.P.susp_turns = 0u;
         gr.tm = Timer{s, want_timing, nullptr};
+        gr.tm.only = trace_timing_only ? &S.ms_trace_closest : nullptr;
         gr.tm.idle_acc = &S.ms_host_idle;
       }
       bool lane_busy[kMaxGroups] = {};
@@ -1563,6 +1569,7 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
           PathState PA = P;
           PA.L = P.L + gr.slot0, PA.pass_run = gr.P.pass_run;
           Timer tm{s, want_timing, st};
+          tm.only = trace_timing_only ? &S.ms_trace_closest : nullptr;
           HIPCHK(tm.begin(&S.ms_accumulate));
           launch_accumulate(st, PA, s->path_pix.p, npix, gr.npass, d_rgba, d_count);
           HIPCHK(tm.end());

@@ -188,6 +188,20 @@ def test_patch_order_does_not_matter(pa, pairs, monkeypatch):
                 assert np.array_equal(cacc, cnt) and acc.tobytes() == rgba.tobytes(), (name, shuffle, tail, world)
 
 
+def test_timing_flags_do_not_change_the_image(pa, pairs):
+    """PBRHIP_RENDER_TIMING times every launch, PBRHIP_RENDER_TIMING_TRACE only the k_trace launches (bench.py's timed region): the same
+    image either way, and the trace-only flag reports nothing but k_trace."""
+    desc, sg, so = pairs["ggx"]
+    ref = pa.RenderLayer()
+    pa.Render(sg, 96, 64, 3, layer=ref, tail_paths=0xFFFFFFFF)
+    for flag in (pa.api.RENDER_TIMING, pa.api.RENDER_TIMING_TRACE):
+        layer = pa.RenderLayer()
+        ok, st = pa.Render(sg, 96, 64, 3, layer=layer, flags=flag, tail_paths=0xFFFFFFFF)
+        assert layer.rgba.tobytes() == ref.rgba.tobytes() and np.array_equal(layer.count, ref.count)
+        assert st["ms_trace_closest"] > 0.0 and st["n_trace_closest"] > 0
+        assert (st["ms_shade_principled"] > 0.0) == (flag == pa.api.RENDER_TIMING), (flag, st["ms_shade_principled"])
+
+
 def test_shading_without_classify_is_exact(pa, pairs, monkeypatch):
     """Round 6: in a scene of principled surfaces only (no hair, no medium) k_classify is skipped on EVERY bounce -- k_shade_principled
     reads the trace queue itself and applies the drop rule (miss, known-to-fail roulette, no material) -- PBRHIP_DIRECT (default 1).
