@@ -26,6 +26,9 @@ constexpr int kBins = PB_SAH_BINS;
 #ifndef PB_SAH_SWEEP
 #define PB_SAH_SWEEP 256  // ranges of at most this many primitives are split by the exact SAH (all positions of all axes) instead of by bins
 #endif
+#ifndef PB_MAX_LEAF_CURVES
+#define PB_MAX_LEAF_CURVES PB_MAX_LEAF  // curve pieces per leaf (1: every piece behind its own box)
+#endif
 constexpr float kTraversalCost = 1.0f;
 constexpr float kPrimCost = 1.5f;
 
@@ -88,7 +91,8 @@ struct Builder {
     pool.nodes[id].box = box;
     pool.nodes[id].depth = depth;
     bool uni = uniform_kind(first, count);
-    if (count <= (uint32_t)kMaxLeaf && uni) {
+    const uint32_t max_leaf = (uni && kinds[order[first]] != 0) ? (uint32_t)PB_MAX_LEAF_CURVES : (uint32_t)kMaxLeaf;
+    if (count <= max_leaf && uni) {
       pool.nodes[id].first = first, pool.nodes[id].count = count, pool.nodes[id].kind = kinds[order[first]];
       return id;
     }
@@ -101,7 +105,7 @@ struct Builder {
     } else if (count <= (uint32_t)PB_SAH_SWEEP) {
       // small ranges: the exact SAH -- every split position of every axis (the bins are too coarse down here), the two sides
       // priced by the LEAVES they will make (kMaxLeaf primitives each: an odd split of four triangles costs a third leaf)
-      auto leaves = [](uint32_t n) { return (float)((n + (uint32_t)kMaxLeaf - 1u) / (uint32_t)kMaxLeaf); };
+      auto leaves = [max_leaf](uint32_t n) { return (float)((n + max_leaf - 1u) / max_leaf); };
       std::vector<uint32_t> idx(order.begin() + first, order.begin() + first + count), best_idx;
       std::vector<float> rarea(count);
       float best_cost = std::numeric_limits<float>::infinity();
