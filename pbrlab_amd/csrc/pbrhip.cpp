@@ -1574,7 +1574,7 @@ int pb::render_impl(pbrhip_scene* s, const pbrhip_render_desc* d, const volatile
           launch_accumulate(st, PA, s->path_pix.p, npix, gr.npass, d_rgba, d_count);
           HIPCHK(tm.end());
           HIPCHK(hipGetLastError());
-          if (want_timing) {
+          if (want_timing && !trace_timing_only) {  // (trace-only timing has nothing to collect here and must not stall the host)
             HIPCHK(hipStreamSynchronize(st));
             HIPCHK(tm.collect());
           }
